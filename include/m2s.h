@@ -1,0 +1,150 @@
+/*
+ * m2s.h — C ABI of the MI355X-native mesh -> 3D-Gaussian-splat conversion pass.
+ *
+ * This is the drop-in boundary for the ONE hot path of electronicarts/mesh2splat: the
+ * per-triangle UV-space rasterisation conversion,
+ *     class ConversionPass : IRenderPass { void execute(RenderContext&); }
+ *     (src/renderer/renderPasses/ConversionPass.{hpp,cpp}, RenderPass.hpp:11-29)
+ * whose device side is the GLSL program converter{VS,GS,FS}.glsl.  The reference has no
+ * FFI layer (it is a C++ virtual call inside one executable); the entry points below are
+ * what a binding for that call would need — the inputs ConversionPass reads from
+ * RenderContext, the outputs it leaves there — with every GL object replaced by plain
+ * pointers and sizes.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: status-code returns, no exceptions cross the ABI, caller-owned input memory
+ * is only borrowed for the duration of a call, device memory is owned by the context unless
+ * the *_into variant is used, one context per host thread (like the single GL context).
+ * All functions are implemented by hand-written HIP kernels for gfx950; there is NO CPU
+ * fallback: on a machine without a usable device m2s_create fails with M2S_ERR_NO_DEVICE.
+ */
+#ifndef M2S_H
+#define M2S_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M2S_ABI_VERSION 1
+
+typedef enum m2s_status {
+    M2S_OK = 0,
+    M2S_ERR_INVALID = 1,   /* bad argument                                              */
+    M2S_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range                 */
+    M2S_ERR_HIP = 3,       /* a HIP runtime call failed (m2s_last_error has the string) */
+    M2S_ERR_OOM = 4,       /* device or host allocation failed                          */
+    M2S_ERR_CAPACITY = 5,  /* destination too small                                     */
+    M2S_ERR_IO = 6,        /* file could not be written                                 */
+    M2S_ERR_STATE = 7      /* call order violated (e.g. convert before upload)          */
+} m2s_status;
+
+typedef struct m2s_ctx m2s_ctx;
+
+/* One RGBA8 image as tiny_gltf leaves it (always 4 components, tiny_gltf.h:2609; row 0 first,
+ * no flip) == utils::TextureDataGl (utils.hpp:190-211).  rgba8 == NULL means "map absent"
+ * (ConversionPass.cpp:77-99 leaves has*Map = 0). */
+typedef struct m2s_texture {
+    const uint8_t* rgba8;
+    uint32_t width, height;
+} m2s_texture;
+
+enum { M2S_TEX_ALBEDO = 0, M2S_TEX_NORMAL = 1, M2S_TEX_METALLIC_ROUGHNESS = 2 }; /* tex units 0,1,2 */
+
+/* One glTF primitive == one std::pair<utils::Mesh, utils::GLMesh> of
+ * RenderContext::dataMeshAndGlMesh (RenderContext.hpp:86).
+ *   vertices      : the VBO built by SceneManager::setupMeshBuffers (SceneManager.cpp:483-512),
+ *                   de-indexed, 3 vertices per triangle; per vertex
+ *                   pos3 normal3 tangent4 uv2 [normalizedUv2 scale3].  stride_floats is 17 for
+ *                   the reference layout, 12 for the live attributes only (the trailing 5 floats
+ *                   are never read: converterGS.glsl uses neither normalizedUv nor scale).
+ *   bbox_min/max  : Mesh::bbox == u_bboxMin/u_bboxMax (ConversionPass.cpp:111-112).  NOTE the
+ *                   reference computes it cumulatively over the mesh list (SceneManager.cpp:476-527).
+ *   base_color    : material.baseColorFactor == u_materialFactor (ConversionPass.cpp:110).
+ *   tex           : meshToTextureData[mesh.name][BASE_COLOR|NORMAL|METALLIC_ROUGHNESS]. */
+typedef struct m2s_mesh {
+    const float* vertices;
+    uint32_t n_vertices;
+    uint32_t stride_floats;
+    float bbox_min[3];
+    float bbox_max[3];
+    float base_color[4];
+    m2s_texture tex[3];
+} m2s_mesh;
+
+/* == utils::GaussianDataSSBO (utils.hpp:145-152) == GLSL GaussianVertex (converterFS.glsl:21-28):
+ * position (P,1) | color rgba*factor | scale (|Ju|,|Jv|,1e-7,0) | normal (n,0) | rotation (w,x,y,z) |
+ * pbr (metallic, roughness, 0, 1).  96 bytes, std430. */
+typedef struct m2s_gaussian {
+    float position[4];
+    float color[4];
+    float scale[4];
+    float normal[4];
+    float rotation[4];
+    float pbr[4];
+} m2s_gaussian;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+uint32_t m2s_abi_version(void);
+/* Creates a context on HIP device `device` (>= 0). */
+m2s_status m2s_create(int device, m2s_ctx** out_ctx);
+void m2s_destroy(m2s_ctx* ctx);
+/* Message of the last failure on this context (never NULL).  ctx == NULL: last create failure. */
+const char* m2s_last_error(const m2s_ctx* ctx);
+
+/* ---- scene upload == SceneManager::setupMeshBuffers + glUtils::generateTextures ---------------- */
+/* Restricts the context to triangles [first, first+count) of the flattened (mesh-major, draw-order)
+ * triangle list of the NEXT m2s_upload_scene: the multi-GPU shard of this rank.  count ==
+ * UINT64_MAX (default) means "to the end".  Mesh uniforms and textures are always complete. */
+m2s_status m2s_set_triangle_range(m2s_ctx* ctx, uint64_t first, uint64_t count);
+/* Copies vertices to HBM (re-laid out as 144 B/triangle SoA planes), uploads the mesh table and the
+ * RGBA8 textures and generates mip levels 1..4 (glUtils.cpp:292-313).  Replaces any previous scene. */
+m2s_status m2s_upload_scene(m2s_ctx* ctx, const m2s_mesh* meshes, uint32_t n_meshes);
+
+/* ---- the pass == ConversionPass::execute ------------------------------------------------------- */
+/* u_maxGaussians policy (converterFS.glsl:46-51): -1 (default) = the reference formula
+ * min(R*R*6*max(1,meshes), 7'000'000) in 32-bit unsigned arithmetic (ConversionPass.cpp:21-24);
+ * 0 = unlimited; > 0 = explicit cap.  Records with index >= cap are not stored. */
+m2s_status m2s_set_max_gaussians(m2s_ctx* ctx, int64_t cap);
+/* Runs the conversion at resolutionTarget R into the context-owned record buffer (re-allocated when
+ * its size changes, ConversionPass.cpp:25-33).  Synchronous like execute() (glFinish + counter
+ * read-back, ConversionPass.cpp:54-59).  *out_total = value of the fragment counter, i.e. the number
+ * of fragments generated — NOT clamped to the cap, exactly like renderContext.numberOfGaussians. */
+m2s_status m2s_convert(m2s_ctx* ctx, uint32_t R, uint64_t* out_total);
+/* Same, but records go to caller-owned DEVICE memory (e.g. a torch tensor feeding an RCCL gather),
+ * kernels are enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and the call returns
+ * after that stream has drained.  capacity_records additionally bounds what is stored. */
+m2s_status m2s_convert_into(m2s_ctx* ctx, uint32_t R, void* d_records, uint64_t capacity_records,
+                            void* hip_stream, uint64_t* out_total);
+/* Number of records actually stored by the last convert: min(total, cap[, capacity]). */
+uint64_t m2s_num_stored(const m2s_ctx* ctx);
+/* Device pointer of the context-owned records of the last m2s_convert (zero-copy consumers). */
+const void* m2s_device_records(const m2s_ctx* ctx);
+/* == glGetBufferSubData in SceneManager::exportPly (SceneManager.cpp:659-664). */
+m2s_status m2s_download(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacity_records);
+/* Per-triangle fragment counts of the last convert (shard balancing / diagnostics); n = triangles in range. */
+m2s_status m2s_download_triangle_counts(m2s_ctx* ctx, uint32_t* dst, uint64_t n);
+
+/* ---- export == SceneManager::exportPly + parsers::savePlyVector -------------------------------- */
+/* format 0 standard 3DGS (62 floats/row), 1 PBR (19 floats/row), 2 compressed PBR (48 B/row); any
+ * other value behaves like 0 (parsers.cpp:646-648).  scale_multiplier = gaussianStd / R. */
+m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format,
+                         float scale_multiplier);
+/* Downloads the last convert's records and writes them: scaleMultiplier = gaussian_std / R
+ * (SceneManager.cpp:668). */
+m2s_status m2s_export_ply(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_N = 4 };
+/* When enabled every convert brackets each kernel with hipEvents on its stream. */
+m2s_status m2s_set_profiling(m2s_ctx* ctx, int enabled);
+/* Kernel durations (ms) of the last profiled convert, indexed by M2S_K_*. */
+m2s_status m2s_last_kernel_ms(const m2s_ctx* ctx, float out_ms[4]);
+/* Scene facts for roofline accounting: triangles in range, meshes. */
+uint64_t m2s_num_triangles(const m2s_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2S_H */

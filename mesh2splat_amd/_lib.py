@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI (include/m2s.h) implemented by mesh2splat_amd/_build/libm2s_hip.so.
+
+There is deliberately NO fallback: if the HIP library is missing or no device is usable the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "_build", "libm2s_hip.so")
+
+M2S_OK = 0
+STATUS_NAMES = {0: "M2S_OK", 1: "M2S_ERR_INVALID", 2: "M2S_ERR_NO_DEVICE", 3: "M2S_ERR_HIP", 4: "M2S_ERR_OOM",
+                5: "M2S_ERR_CAPACITY", 6: "M2S_ERR_IO", 7: "M2S_ERR_STATE"}
+KERNEL_NAMES = ("count", "scan", "offsets", "emit")  # M2S_K_*
+
+# every symbol include/m2s.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "m2s_abi_version", "m2s_create", "m2s_destroy", "m2s_last_error", "m2s_set_triangle_range", "m2s_upload_scene",
+    "m2s_set_max_gaussians", "m2s_convert", "m2s_convert_into", "m2s_num_stored", "m2s_device_records", "m2s_download",
+    "m2s_download_triangle_counts", "m2s_write_ply", "m2s_export_ply", "m2s_set_profiling", "m2s_last_kernel_ms",
+    "m2s_num_triangles",
+)
+
+
+class M2SError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class MeshC(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("n_vertices", C.c_uint32), ("stride_floats", C.c_uint32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("base_color", C.c_float * 4),
+                ("tex", Texture * 3)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "m2s.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", CSRC, "all"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode:
+            raise RuntimeError("building libm2s_hip.so failed:\n" + r.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library; raise loudly if it is missing (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the conversion pass)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64
+    sigs = {
+        "m2s_abi_version": (u32, []),
+        "m2s_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "m2s_destroy": (None, [vp]),
+        "m2s_last_error": (C.c_char_p, [vp]),
+        "m2s_set_triangle_range": (C.c_int, [vp, u64, u64]),
+        "m2s_upload_scene": (C.c_int, [vp, C.POINTER(MeshC), u32]),
+        "m2s_set_max_gaussians": (C.c_int, [vp, i64]),
+        "m2s_convert": (C.c_int, [vp, u32, C.POINTER(u64)]),
+        "m2s_convert_into": (C.c_int, [vp, u32, vp, u64, vp, C.POINTER(u64)]),
+        "m2s_num_stored": (u64, [vp]),
+        "m2s_device_records": (vp, [vp]),
+        "m2s_download": (C.c_int, [vp, vp, u64]),
+        "m2s_download_triangle_counts": (C.c_int, [vp, vp, u64]),
+        "m2s_write_ply": (C.c_int, [C.c_char_p, vp, u64, u32, C.c_float]),
+        "m2s_export_ply": (C.c_int, [vp, C.c_char_p, u32, C.c_float]),
+        "m2s_set_profiling": (C.c_int, [vp, C.c_int]),
+        "m2s_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "m2s_num_triangles": (u64, [vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

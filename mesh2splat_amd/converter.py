@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's operator interface for the conversion path.
+
+Reference                                             | here
+------------------------------------------------------+--------------------------------------------
+IRenderPass / ConversionPass::execute(RenderContext&) | ConversionPass.execute(RenderContext)
+  (RenderPass.hpp:11-29, ConversionPass.cpp:9-68)     |
+RenderContext fields the pass reads / writes          | RenderContext (same names)
+  (RenderContext.hpp:64,73,83,86,90)                  |
+SceneManager::exportPly(outputFile, exportFormat)     | SceneManager.exportPly
+  (SceneManager.cpp:651-678)                          |
+parsers::savePlyVector                                | write_ply
+
+All compute happens in the HIP library behind include/m2s.h; this file only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .scene import RECORD_FLOATS, TEXTURE_SLOTS, Scene
+
+
+class Converter:
+    """Thin owner of one m2s_ctx (one per host thread / per GPU rank)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        st = self._L.m2s_create(int(device), C.byref(h))
+        if st != _lib.M2S_OK:
+            raise _lib.M2SError(st, self._L.m2s_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self._keep = None
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _check(self, st: int):
+        if st != _lib.M2S_OK:
+            raise _lib.M2SError(st, self._L.m2s_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.m2s_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene ------------------------------------------------------------------------------------
+    def set_triangle_range(self, first: int, count: Optional[int]):
+        self._check(self._L.m2s_set_triangle_range(self._h, int(first), (1 << 64) - 1 if count is None else int(count)))
+
+    def upload_scene(self, scene: Scene):
+        n = scene.n_meshes
+        arr = (_lib.MeshC * max(1, n))()
+        keep = []
+        for i, m in enumerate(scene.meshes):
+            v = np.ascontiguousarray(m.vertices, np.float32)
+            keep.append(v)
+            arr[i].vertices = v.ctypes.data
+            arr[i].n_vertices = v.shape[0]
+            arr[i].stride_floats = v.shape[1]
+            for k in range(3):
+                arr[i].bbox_min[k] = float(m.bbox_min[k])
+                arr[i].bbox_max[k] = float(m.bbox_max[k])
+            for k in range(4):
+                arr[i].base_color[k] = float(m.base_color[k])
+            for k, key in enumerate(TEXTURE_SLOTS):
+                t = m.textures.get(key)
+                if t is None:
+                    continue
+                keep.append(t)
+                arr[i].tex[k].rgba8 = t.ctypes.data
+                arr[i].tex[k].width = t.shape[1]
+                arr[i].tex[k].height = t.shape[0]
+        self._check(self._L.m2s_upload_scene(self._h, arr, n))
+        del keep
+
+    # -- the pass ---------------------------------------------------------------------------------
+    def set_max_gaussians(self, cap: int):
+        """-1 reference formula (default), 0 unlimited, >0 explicit."""
+        self._check(self._L.m2s_set_max_gaussians(self._h, int(cap)))
+
+    def convert(self, R: int) -> int:
+        total = C.c_uint64()
+        self._check(self._L.m2s_convert(self._h, int(R), C.byref(total)))
+        return int(total.value)
+
+    def convert_into(self, R: int, device_ptr: int, capacity_records: int, stream: int = 0) -> int:
+        total = C.c_uint64()
+        self._check(self._L.m2s_convert_into(self._h, int(R), C.c_void_p(device_ptr), int(capacity_records),
+                                             C.c_void_p(stream), C.byref(total)))
+        return int(total.value)
+
+    @property
+    def num_stored(self) -> int:
+        return int(self._L.m2s_num_stored(self._h))
+
+    @property
+    def num_triangles(self) -> int:
+        return int(self._L.m2s_num_triangles(self._h))
+
+    @property
+    def device_records(self) -> int:
+        return int(self._L.m2s_device_records(self._h) or 0)
+
+    def download(self) -> np.ndarray:
+        n = self.num_stored
+        out = np.empty((n, RECORD_FLOATS), np.float32)
+        self._check(self._L.m2s_download(self._h, out.ctypes.data, n))
+        return out
+
+    def download_triangle_counts(self) -> np.ndarray:
+        n = self.num_triangles
+        out = np.empty(n, np.uint32)
+        self._check(self._L.m2s_download_triangle_counts(self._h, out.ctypes.data, n))
+        return out
+
+    def export_ply(self, path: str, fmt: int = 0, gaussian_std: float = 0.65):
+        self._check(self._L.m2s_export_ply(self._h, os.fsencode(path), int(fmt), float(gaussian_std)))
+
+    # -- measurement --------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self._L.m2s_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self) -> dict:
+        ms = (C.c_float * 4)()
+        self._check(self._L.m2s_last_kernel_ms(self._h, ms))
+        return {k: float(ms[i]) for i, k in enumerate(_lib.KERNEL_NAMES)}
+
+
+def write_ply(path: str, records: np.ndarray, fmt: int, scale_multiplier: float):
+    """parsers::savePlyVector (parsers.cpp:631-651) on a host array of 96-byte records."""
+    r = np.ascontiguousarray(records, np.float32)
+    if r.ndim != 2 or r.shape[1] != RECORD_FLOATS:
+        raise ValueError("records must be (n, 24) float32")
+    st = _lib.load().m2s_write_ply(os.fsencode(path), r.ctypes.data, r.shape[0], int(fmt), float(scale_multiplier))
+    if st != _lib.M2S_OK:
+        raise _lib.M2SError(st, f"could not write {path}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# reference-shaped interface
+# ---------------------------------------------------------------------------------------------------
+class RenderContext:
+    """The slice of RenderContext (RenderContext.hpp:28-124) that the conversion path touches."""
+
+    def __init__(self, scene: Optional[Scene] = None, resolutionTarget: int = 520, gaussianStd: float = 0.65,
+                 device: int = 0):
+        self.scene = scene                        # dataMeshAndGlMesh + meshToTextureData
+        self.resolutionTarget = int(resolutionTarget)  # main.cpp:26 default quality 0.5 -> 520
+        self.gaussianStd = float(gaussianStd)     # main.cpp:26
+        self.numberOfGaussians = 0                # written by ConversionPass::execute
+        self.device = int(device)
+        self.converter: Optional[Converter] = None  # owns gaussianBuffer (the SSBO equivalent)
+        self._uploaded_scene = None
+
+
+class IRenderPass:
+    """RenderPass.hpp:11-29."""
+
+    def __init__(self):
+        self._enabled = False
+
+    def execute(self, context: RenderContext):
+        raise NotImplementedError
+
+    def isEnabled(self) -> bool:
+        return self._enabled
+
+    def setIsEnabled(self, enabled: bool):
+        self._enabled = bool(enabled)
+
+
+class ConversionPass(IRenderPass):
+    """ConversionPass::execute (ConversionPass.cpp:9-68): synchronous; leaves the Gaussians in the
+    context's device buffer and their count in context.numberOfGaussians (not clamped to the cap)."""
+
+    def execute(self, context: RenderContext):
+        if context.scene is None:
+            raise ValueError("RenderContext.scene is not set (SceneManager::loadModel has not run)")
+        if context.converter is None:
+            context.converter = Converter(context.device)
+        if context._uploaded_scene is not context.scene:
+            context.converter.upload_scene(context.scene)
+            context._uploaded_scene = context.scene
+        context.numberOfGaussians = context.converter.convert(context.resolutionTarget)
+
+
+class SceneManager:
+    """The export half of SceneManager (SceneManager.cpp:651-678)."""
+
+    def __init__(self, context: RenderContext):
+        self.renderContext = context
+
+    def exportPly(self, outputFile: str, exportFormat: int = 0):
+        ctx = self.renderContext
+        if ctx.converter is None:
+            raise RuntimeError("nothing converted yet")
+        ctx.converter.export_ply(outputFile, exportFormat, ctx.gaussianStd)

@@ -1,0 +1,434 @@
+// m2s_api.cpp — host side of the C ABI (include/m2s.h): context, scene upload, the conversion
+// pass driver (== ConversionPass::execute, src/renderer/renderPasses/ConversionPass.cpp:9-68) and
+// read-back.  Compiled with hipcc; no CPU compute path exists here.
+#include "../../include/m2s.h"
+#include "m2s_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+using namespace m2s;
+
+namespace {
+thread_local std::string g_create_error = "";
+
+constexpr uint32_t kMaxGaussiansToSort = 7000000u;  // RenderPass.hpp:9
+constexpr uint64_t kMaxTriangles = 0x7FFFFFFFull;   // triangle indices are 32-bit on the device
+constexpr size_t kStagingBytes = 256ull << 20;      // H2D staging for the AoS -> SoA repack
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+struct m2s_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    void* tri_mem = nullptr;
+    SceneDev scene{};
+    MeshParams* d_meshes = nullptr;
+    uint32_t* d_mesh_first = nullptr;
+    std::vector<void*> tex_mem;
+    uint32_t n_meshes_total = 0;
+    bool has_scene = false;
+    uint64_t range_first = 0, range_count = UINT64_MAX;
+
+    // work buffers (sized by the scene)
+    uint32_t* d_cnt = nullptr;
+    uint32_t* d_off = nullptr;
+    uint32_t* d_partials = nullptr;
+    uint32_t* d_start = nullptr;
+    size_t start_cap = 0;
+    unsigned long long* d_total = nullptr;
+    unsigned long long* h_total = nullptr;  // pinned
+
+    // output
+    void* d_records = nullptr;
+    uint64_t records_cap = 0;  // records
+    const void* last_records = nullptr;
+    int64_t cap_policy = -1;
+    uint64_t last_total = 0, last_stored = 0;
+    uint32_t last_R = 0;
+
+    // measurement
+    bool profiling = false;
+    hipEvent_t ev[M2S_K_N + 1] = {};
+    float last_ms[M2S_K_N] = {};
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return e_ == hipErrorOutOfMemory ? M2S_ERR_OOM : M2S_ERR_HIP;                         \
+        }                                                                                         \
+    } while (0)
+
+static m2s_status fail(m2s_ctx* c, m2s_status s, const std::string& msg) {
+    if (c) c->err = msg;
+    return s;
+}
+
+static void free_scene(m2s_ctx* c) {
+    if (c->tri_mem) (void)hipFree(c->tri_mem);
+    if (c->d_meshes) (void)hipFree(c->d_meshes);
+    if (c->d_mesh_first) (void)hipFree(c->d_mesh_first);
+    for (void* p : c->tex_mem) (void)hipFree(p);
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
+    c->tex_mem.clear();
+    c->d_cnt = c->d_off = c->d_partials = nullptr;
+    c->scene = SceneDev{};
+    c->has_scene = false;
+}
+
+extern "C" {
+
+uint32_t m2s_abi_version(void) { return M2S_ABI_VERSION; }
+
+const char* m2s_last_error(const m2s_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
+    if (!out_ctx) { g_create_error = "out_ctx is NULL"; return M2S_ERR_INVALID; }
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                         "); this library has no CPU path";
+        return M2S_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return M2S_ERR_NO_DEVICE; }
+    m2s_ctx* c = new (std::nothrow) m2s_ctx();
+    if (!c) { g_create_error = "host allocation failed"; return M2S_ERR_OOM; }
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t he) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(he);
+        delete c;
+        return M2S_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->h_total, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+    for (auto& ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    *out_ctx = c;
+    return M2S_OK;
+}
+
+void m2s_destroy(m2s_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    if (c->d_start) (void)hipFree(c->d_start);
+    if (c->d_records) (void)hipFree(c->d_records);
+    if (c->d_total) (void)hipFree(c->d_total);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+m2s_status m2s_set_triangle_range(m2s_ctx* c, uint64_t first, uint64_t count) {
+    if (!c) return M2S_ERR_INVALID;
+    c->range_first = first;
+    c->range_count = count;
+    return M2S_OK;
+}
+
+m2s_status m2s_set_max_gaussians(m2s_ctx* c, int64_t cap) {
+    if (!c) return M2S_ERR_INVALID;
+    if (cap < -1) return fail(c, M2S_ERR_INVALID, "cap must be -1 (reference formula), 0 (unlimited) or > 0");
+    c->cap_policy = cap;
+    return M2S_OK;
+}
+
+m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshes) {
+    if (!c) return M2S_ERR_INVALID;
+    if (n_meshes && !meshes) return fail(c, M2S_ERR_INVALID, "meshes is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    // ---- validate + global triangle index space -------------------------------------------------
+    std::vector<uint32_t> mesh_first(n_meshes + 1, 0);
+    uint64_t T = 0;
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const m2s_mesh& m = meshes[i];
+        if (m.stride_floats < 12) return fail(c, M2S_ERR_INVALID, "stride_floats must be >= 12");
+        if (m.n_vertices % 3) return fail(c, M2S_ERR_INVALID, "n_vertices must be a multiple of 3");
+        if (m.n_vertices && !m.vertices) return fail(c, M2S_ERR_INVALID, "vertices is NULL");
+        for (int k = 0; k < 3; ++k)
+            if (m.tex[k].rgba8 && (!m.tex[k].width || !m.tex[k].height || m.tex[k].width > 32768 || m.tex[k].height > 32768))
+                return fail(c, M2S_ERR_INVALID, "texture dimensions must be in [1, 32768]");
+        mesh_first[i] = (uint32_t)T;
+        T += m.n_vertices / 3;
+        if (T > kMaxTriangles) return fail(c, M2S_ERR_INVALID, "more than 2^31-1 triangles");
+    }
+    mesh_first[n_meshes] = (uint32_t)T;
+    const uint64_t first = std::min<uint64_t>(c->range_first, T);
+    const uint64_t last = (c->range_count == UINT64_MAX || c->range_count > T - first) ? T : first + c->range_count;
+    const uint32_t n_tri = (uint32_t)(last - first);
+
+    free_scene(c);
+    c->n_meshes_total = n_meshes;
+    c->scene.n_meshes = n_meshes;
+    c->scene.n_tri = n_tri;
+    c->scene.tri_first = (uint32_t)first;
+
+    // ---- geometry planes: 144 B / triangle ------------------------------------------------------
+    const size_t np = std::max<size_t>(n_tri, 1);
+    size_t offs[11], cur = 0;
+    const size_t widths[11] = { 16, 16, 4, 16, 8, 16, 16, 4, 16, 16, 16 };
+    for (int k = 0; k < 11; ++k) { offs[k] = cur; cur = align_up(cur + np * widths[k], 256); }
+    HIPCHK(c, hipMalloc(&c->tri_mem, cur));
+    char* b = (char*)c->tri_mem;
+    TriPlanes& tp = c->scene.tri;
+    tp.A0 = (const float4*)(b + offs[0]); tp.A1 = (const float4*)(b + offs[1]); tp.A2 = (const float*)(b + offs[2]);
+    tp.B0 = (const float4*)(b + offs[3]); tp.B1 = (const float2*)(b + offs[4]);
+    tp.C0 = (const float4*)(b + offs[5]); tp.C1 = (const float4*)(b + offs[6]); tp.C2 = (const float*)(b + offs[7]);
+    tp.D0 = (const float4*)(b + offs[8]); tp.D1 = (const float4*)(b + offs[9]); tp.D2 = (const float4*)(b + offs[10]);
+
+    if (n_tri) {
+        void* staging = nullptr;
+        size_t need = 0;
+        for (uint32_t i = 0; i < n_meshes; ++i) {
+            const uint64_t s = std::max<uint64_t>(first, mesh_first[i]), e = std::min<uint64_t>(last, mesh_first[i + 1]);
+            if (e > s) need = std::max<size_t>(need, (size_t)(e - s) * 3 * meshes[i].stride_floats * sizeof(float));
+        }
+        const size_t stage_bytes = std::min(need, kStagingBytes);
+        HIPCHK(c, hipMalloc(&staging, std::max<size_t>(stage_bytes, 256)));
+        for (uint32_t i = 0; i < n_meshes; ++i) {
+            const uint64_t s = std::max<uint64_t>(first, mesh_first[i]), e = std::min<uint64_t>(last, mesh_first[i + 1]);
+            if (e <= s) continue;
+            const size_t tri_bytes = (size_t)3 * meshes[i].stride_floats * sizeof(float);
+            const uint64_t per_chunk = std::max<uint64_t>(1, stage_bytes / tri_bytes);
+            for (uint64_t t0 = s; t0 < e; t0 += per_chunk) {
+                const uint64_t n = std::min<uint64_t>(per_chunk, e - t0);
+                const float* src = meshes[i].vertices + (size_t)(t0 - mesh_first[i]) * 3 * meshes[i].stride_floats;
+                hipError_t he = hipMemcpyAsync(staging, src, n * tri_bytes, hipMemcpyHostToDevice, c->stream);
+                if (he == hipSuccess) {
+                    launch_repack((const float*)staging, meshes[i].stride_floats, (uint32_t)n, 0, (uint32_t)n,
+                                  (uint32_t)(t0 - first), tp, c->stream);
+                    he = hipStreamSynchronize(c->stream);  // staging is reused by the next chunk
+                }
+                if (he != hipSuccess) { (void)hipFree(staging); HIPCHK(c, he); }
+            }
+        }
+        (void)hipFree(staging);
+    }
+
+    // ---- textures: level 0 upload + mip levels 1..4 (glUtils.cpp:292-313) ------------------------
+    std::vector<MeshParams> mp(std::max<uint32_t>(n_meshes, 1));
+    std::map<std::tuple<const uint8_t*, uint32_t, uint32_t>, TexDesc> dedup;
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const m2s_mesh& m = meshes[i];
+        MeshParams& p = mp[i];
+        memset(&p, 0, sizeof p);
+        memcpy(p.bmin, m.bbox_min, 12);
+        memcpy(p.bmax, m.bbox_max, 12);
+        memcpy(p.color, m.base_color, 16);
+        for (int k = 0; k < 3; ++k) {
+            const m2s_texture& t = m.tex[k];
+            if (!t.rgba8) continue;
+            auto key = std::make_tuple(t.rgba8, t.width, t.height);
+            auto it = dedup.find(key);
+            if (it != dedup.end()) { p.tex[k] = it->second; continue; }
+            TexDesc d{};
+            d.w = t.width; d.h = t.height;
+            uint32_t mx = std::max(t.width, t.height), nl = 1;
+            while (mx > 1 && nl < 5) { mx >>= 1; nl++; }
+            d.n_levels = nl;
+            size_t tot = 0;
+            for (uint32_t l = 0; l < nl; ++l) {
+                d.off[l] = (uint32_t)tot;
+                tot += (size_t)std::max(1u, t.width >> l) * std::max(1u, t.height >> l);
+            }
+            void* mem = nullptr;
+            HIPCHK(c, hipMalloc(&mem, tot * 4));
+            c->tex_mem.push_back(mem);
+            d.texels = (const uint32_t*)mem;
+            HIPCHK(c, hipMemcpyAsync(mem, t.rgba8, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice, c->stream));
+            for (uint32_t l = 1; l < nl; ++l)
+                launch_mip_level(d.texels + d.off[l - 1], std::max(1u, t.width >> (l - 1)), std::max(1u, t.height >> (l - 1)),
+                                 (uint32_t*)mem + d.off[l], std::max(1u, t.width >> l), std::max(1u, t.height >> l), c->stream);
+            p.tex[k] = d;
+            dedup[key] = d;
+        }
+    }
+    HIPCHK(c, hipMalloc((void**)&c->d_meshes, mp.size() * sizeof(MeshParams)));
+    HIPCHK(c, hipMemcpyAsync(c->d_meshes, mp.data(), mp.size() * sizeof(MeshParams), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMalloc((void**)&c->d_mesh_first, mesh_first.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpyAsync(c->d_mesh_first, mesh_first.data(), mesh_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             c->stream));
+    c->scene.meshes = c->d_meshes;
+    c->scene.mesh_first = c->d_mesh_first;
+
+    // ---- work buffers -----------------------------------------------------------------------------
+    HIPCHK(c, hipMalloc((void**)&c->d_cnt, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_off, (np + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_partials, std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries
+    c->has_scene = true;
+    c->last_total = c->last_stored = 0;
+    c->last_records = nullptr;
+    return M2S_OK;
+}
+
+static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
+    if (c->cap_policy == 0) return 0;
+    if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
+    // ConversionPass.cpp:21-24 (unsigned int arithmetic wraps)
+    const uint32_t mc = std::max<uint32_t>(1u, c->n_meshes_total);
+    const uint32_t mx = R * R * 6u * mc;
+    return std::min(mx, kMaxGaussiansToSort);
+}
+
+static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total) {
+    if (!c->has_scene) return fail(c, M2S_ERR_STATE, "m2s_upload_scene has not been called");
+    if (R == 0 || R > 8192) return fail(c, M2S_ERR_INVALID, "R must be in [1, 8192]");
+    HIPCHK(c, hipSetDevice(c->device));
+    const SceneDev& sc = c->scene;
+    const uint64_t cap = resolve_cap(c, R);
+    const bool prof = c->profiling;
+    c->last_R = R;
+    memset(c->last_ms, 0, sizeof c->last_ms);
+
+    if (sc.n_tri == 0) {
+        c->last_total = c->last_stored = 0;
+        c->last_records = d_user ? d_user : c->d_records;
+        if (out_total) *out_total = 0;
+        return M2S_OK;
+    }
+
+    // K1 + scan: fragment counter (== the atomic counter of converterFS.glsl:46, but exact and ordered)
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_count(sc, R, c->d_cnt, c->d_partials, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+
+    // where do the records go, and how many may be stored?
+    uint64_t limit;
+    float4* d_out;
+    if (d_user) {
+        limit = cap ? std::min(cap, user_cap) : user_cap;
+        d_out = (float4*)d_user;
+    } else {
+        uint64_t want = cap;
+        if (!cap) {  // unlimited: size the SSBO from the counter (one extra host round trip)
+            HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            want = std::max<uint64_t>(*c->h_total, 1);
+        }
+        // ConversionPass.cpp:25-33: (re)allocate when the size differs (grow-only for the unlimited policy)
+        if ((cap && c->records_cap != want) || (!cap && c->records_cap < want)) {
+            if (c->d_records) { (void)hipFree(c->d_records); c->d_records = nullptr; c->records_cap = 0; }
+            HIPCHK(c, hipMalloc(&c->d_records, want * sizeof(m2s_gaussian)));
+            c->records_cap = want;
+        }
+        limit = cap ? cap : c->records_cap;
+        d_out = (float4*)c->d_records;
+    }
+    if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
+    const uint64_t n_blocks64 = (limit + kEmitF - 1) / kEmitF;
+    const uint32_t n_blocks = (uint32_t)n_blocks64;
+    if (c->start_cap < n_blocks) {
+        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_start, std::max<size_t>(n_blocks, 1) * sizeof(uint32_t)));
+        c->start_cap = n_blocks;
+    }
+
+    launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    HIPCHK(c, hipGetLastError());
+
+    // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint64_t total = *c->h_total;
+    if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
+    c->last_total = total;
+    c->last_stored = std::min(total, limit);
+    c->last_records = d_out;
+    if (prof)
+        for (int k = 0; k < M2S_K_N; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+    if (out_total) *out_total = total;
+    return M2S_OK;
+}
+
+m2s_status m2s_convert(m2s_ctx* c, uint32_t R, uint64_t* out_total) {
+    if (!c) return M2S_ERR_INVALID;
+    return run_pass(c, R, nullptr, 0, c->stream, out_total);
+}
+
+m2s_status m2s_convert_into(m2s_ctx* c, uint32_t R, void* d_records, uint64_t capacity_records, void* hip_stream,
+                            uint64_t* out_total) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!d_records && capacity_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL");
+    if (!d_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL (use m2s_convert for the context-owned buffer)");
+    return run_pass(c, R, d_records, capacity_records, (hipStream_t)hip_stream, out_total);
+}
+
+uint64_t m2s_num_stored(const m2s_ctx* c) { return c ? c->last_stored : 0; }
+const void* m2s_device_records(const m2s_ctx* c) { return c ? c->last_records : nullptr; }
+uint64_t m2s_num_triangles(const m2s_ctx* c) { return c ? c->scene.n_tri : 0; }
+
+m2s_status m2s_download(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_records) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->last_stored) return M2S_OK;
+    if (!dst) return fail(c, M2S_ERR_INVALID, "dst is NULL");
+    if (capacity_records < c->last_stored) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer records than were stored");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->last_records, c->last_stored * sizeof(m2s_gaussian), hipMemcpyDeviceToHost));
+    return M2S_OK;
+}
+
+m2s_status m2s_download_triangle_counts(m2s_ctx* c, uint32_t* dst, uint64_t n) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->has_scene || !c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
+    if (n < c->scene.n_tri) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer entries than triangles in range");
+    if (!c->scene.n_tri) return M2S_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->d_cnt, (size_t)c->scene.n_tri * 4, hipMemcpyDeviceToHost));
+    return M2S_OK;
+}
+
+m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std) {
+    if (!c || !path) return M2S_ERR_INVALID;
+    if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
+    std::vector<m2s_gaussian> host;
+    try { host.resize(c->last_stored); } catch (...) { return fail(c, M2S_ERR_OOM, "host allocation failed"); }
+    m2s_status s = m2s_download(c, host.data(), host.size());
+    if (s != M2S_OK) return s;
+    // SceneManager.cpp:668
+    const float scale_multiplier = gaussian_std / static_cast<float>(c->last_R);
+    s = m2s_write_ply(path, host.data(), host.size(), format, scale_multiplier);
+    if (s != M2S_OK) c->err = std::string("could not write ") + path;
+    return s;
+}
+
+m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
+    if (!c) return M2S_ERR_INVALID;
+    c->profiling = enabled != 0;
+    return M2S_OK;
+}
+
+m2s_status m2s_last_kernel_ms(const m2s_ctx* c, float out_ms[4]) {
+    if (!c || !out_ms) return M2S_ERR_INVALID;
+    memcpy(out_ms, c->last_ms, sizeof c->last_ms);
+    return M2S_OK;
+}
+
+}  // extern "C"

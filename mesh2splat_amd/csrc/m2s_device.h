@@ -1,0 +1,69 @@
+// m2s_device.h — device-side data layout and launcher prototypes (internal; the public
+// boundary is include/m2s.h).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m2s {
+
+// ---- launch geometry ----------------------------------------------------------------------
+constexpr int kBlock = 256;              // 4 wave64 per workgroup
+constexpr int kTriPerBlock = 1024;       // triangles per workgroup in the count / offsets kernels
+constexpr int kEmitF = 1024;             // output records per workgroup in the emit kernel
+constexpr int kRowsThread = 32;          // triangles with more pixel rows are rasterised wave-cooperatively
+constexpr int kStageStride = 7;          // float4 per staged record in LDS (6 + 1 pad: conflict-free b128)
+
+// ---- HBM layout of the geometry: 144 B / triangle in 11 coalescable planes ------------------
+// (reference VBO: 17 floats/vertex AoS with 5 dead floats, SceneManager.cpp:483-512)
+struct TriPlanes {
+    const float4* A0;  // p0.x p0.y p0.z p1.x
+    const float4* A1;  // p1.y p1.z p2.x p2.y
+    const float*  A2;  // p2.z
+    const float4* B0;  // uv0.x uv0.y uv1.x uv1.y
+    const float2* B1;  // uv2.x uv2.y
+    const float4* C0;  // n0.x n0.y n0.z n1.x
+    const float4* C1;  // n1.y n1.z n2.x n2.y
+    const float*  C2;  // n2.z
+    const float4* D0;  // tangent 0 (xyz w)
+    const float4* D1;  // tangent 1
+    const float4* D2;  // tangent 2
+};
+
+struct TexDesc {
+    const uint32_t* texels;  // RGBA8 mip chain, level 0 first; nullptr = map absent
+    uint32_t w, h, n_levels;
+    uint32_t off[5];         // level offsets in texels
+};
+
+// per-mesh "uniforms" (ConversionPass.cpp:77-112)
+struct MeshParams {
+    float bmin[3];
+    float bmax[3];
+    float color[4];
+    TexDesc tex[3];
+};
+
+struct SceneDev {
+    TriPlanes tri;
+    const MeshParams* meshes;
+    const uint32_t* mesh_first;  // n_meshes+1 prefix of GLOBAL triangle indices
+    uint32_t n_meshes;
+    uint32_t n_tri;              // triangles resident on this device (the shard)
+    uint32_t tri_first;          // global index of local triangle 0
+};
+
+// ---- launchers (all asynchronous on `st`) ----------------------------------------------------
+void launch_repack(const float* d_aos, uint32_t stride_floats, uint32_t n_tri_src, uint32_t src_first,
+                   uint32_t n, uint32_t dst_first, TriPlanes dst /*non-const view*/, hipStream_t st);
+void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh,
+                      hipStream_t st);
+void launch_count(const SceneDev& sc, uint32_t R, uint32_t* cnt, uint32_t* partials, hipStream_t st);
+void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long long* total, hipStream_t st);
+void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
+                    uint32_t n_start, hipStream_t st);
+void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
+                 const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
+
+inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
+
+}  // namespace m2s

@@ -1,0 +1,135 @@
+// m2s_ply.cpp — binary little-endian .ply export of Gaussian records, byte-compatible with the
+// reference's three writers (src/parsers/parsers.cpp: standard 431-514, PBR 232-316, compressed
+// PBR 339-428; dispatch savePlyVector 631-651).  The reference issues one ofstream::write per
+// field (62 per Gaussian in the standard format); here rows are encoded into a large buffer by
+// a pool of threads and written with a few big fwrite calls.
+#include "../../include/m2s.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr float kShC0 = 0.28209479177387814f;  // params.hpp:17 SH_COEFF0
+
+// utils.hpp:270 invSigmoid
+inline float inv_sigmoid(float alpha) {
+    alpha = std::clamp(alpha, 0.0f, 1.0f);
+    return -std::log((1.0f / (alpha + 1e-8f)) - 1.0f);
+}
+// glm::clamp == min(max(x, lo), hi) with glm's comparison order (NaN passes through)
+inline float glm_clamp(float x, float lo, float hi) {
+    const float mx = (x < lo) ? lo : x;
+    return (hi < mx) ? hi : mx;
+}
+// parsers.cpp:370-375
+inline uint8_t to_byte(float v) { return static_cast<uint8_t>(std::round(glm_clamp(v, 0.0f, 1.0f) * 255.0f)); }
+
+struct Format {
+    size_t row_bytes;
+    std::vector<std::string> props;
+};
+
+Format describe(uint32_t format) {
+    Format f;
+    auto fl = [&](const char* n) { f.props.push_back(std::string("property float ") + n); };
+    auto u8 = [&](const char* n) { f.props.push_back(std::string("property uint8 ") + n); };
+    if (format == 1) {  // parsers.cpp:240-266
+        for (const char* n : { "x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2", "metallicFactor",
+                               "roughnessFactor", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2",
+                               "rot_3" })
+            fl(n);
+        f.row_bytes = 19 * 4;
+    } else if (format == 2) {  // parsers.cpp:346-365
+        for (const char* n : { "x", "y", "z" }) fl(n);
+        for (const char* n : { "red", "green", "blue", "opacity" }) u8(n);
+        for (const char* n : { "rot_0", "rot_1", "rot_2", "rot_3", "scale_0", "scale_1", "scale_2" }) fl(n);
+        for (const char* n : { "octa_nx", "octa_ny", "roughness", "metallic" }) u8(n);
+        f.row_bytes = 48;
+    } else {  // parsers.cpp:438-464 (also the default branch of savePlyVector)
+        for (const char* n : { "x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2" }) fl(n);
+        for (int i = 0; i <= 44; ++i) fl(("f_rest_" + std::to_string(i)).c_str());
+        for (const char* n : { "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3" }) fl(n);
+        f.row_bytes = 62 * 4;
+    }
+    return f;
+}
+
+inline uint8_t* put(uint8_t* p, float v) { std::memcpy(p, &v, 4); return p + 4; }
+
+void encode_rows(const m2s_gaussian* g, size_t n, uint32_t format, float sm, uint8_t* p) {
+    for (size_t i = 0; i < n; ++i, ++g) {
+        if (format == 2) {
+            p = put(p, g->position[0]); p = put(p, g->position[1]); p = put(p, g->position[2]);
+            *p++ = to_byte(g->color[0]); *p++ = to_byte(g->color[1]); *p++ = to_byte(g->color[2]); *p++ = to_byte(g->color[3]);
+            for (int k = 0; k < 4; ++k) p = put(p, g->rotation[k]);
+            const float min_xy = std::min(g->scale[0], g->scale[1]);  // parsers.cpp:403
+            p = put(p, std::log(g->scale[0] * sm));
+            p = put(p, std::log(g->scale[1] * sm));
+            p = put(p, std::log(min_xy * sm));
+            // EncodeOcta, parsers.cpp:320-337 (OctWrap flips both components on a joint sign test)
+            const float d = std::fabs(g->normal[0]) + std::fabs(g->normal[1]) + std::fabs(g->normal[2]) + 1e-8f;
+            const float nx = g->normal[0] / d, ny = g->normal[1] / d, nz = g->normal[2] / d;
+            float ex = nx, ey = ny;
+            if (!(nz >= 0.0f)) {
+                const float s = (nx >= 0 && ny >= 0) ? 1.0f : -1.0f;
+                ex = (1.0f - std::fabs(ny)) * s;
+                ey = (1.0f - std::fabs(nx)) * s;
+            }
+            ex = ex * 0.5f + 0.5f;
+            ey = ey * 0.5f + 0.5f;
+            *p++ = static_cast<uint8_t>(glm_clamp(std::round(ex * 255.0f), 0.0f, 255.0f));
+            *p++ = static_cast<uint8_t>(glm_clamp(std::round(ey * 255.0f), 0.0f, 255.0f));
+            *p++ = to_byte(g->pbr[1]);
+            *p++ = to_byte(g->pbr[0]);
+            continue;
+        }
+        p = put(p, g->position[0]); p = put(p, g->position[1]); p = put(p, g->position[2]);
+        p = put(p, g->normal[0]); p = put(p, g->normal[1]); p = put(p, g->normal[2]);
+        for (int k = 0; k < 3; ++k) p = put(p, (g->color[k] - 0.5f) / kShC0);  // utils.cpp:45-49
+        if (format == 1) { p = put(p, g->pbr[0]); p = put(p, g->pbr[1]); }
+        else { std::memset(p, 0, 45 * 4); p += 45 * 4; }
+        p = put(p, inv_sigmoid(g->color[3]));
+        for (int k = 0; k < 3; ++k) p = put(p, std::log(g->scale[k] * sm));
+        for (int k = 0; k < 4; ++k) p = put(p, g->rotation[k]);  // stored (w,x,y,z)
+    }
+}
+
+}  // namespace
+
+extern "C" m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format,
+                                    float scale_multiplier) {
+    if (!path || (n && !records)) return M2S_ERR_INVALID;
+    if (format > 2) format = 0;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return M2S_ERR_IO;
+    const Format fmt = describe(format);
+    std::string header = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(n) + "\n";
+    for (const auto& p : fmt.props) header += p + "\n";
+    header += "end_header\n";
+    bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
+
+    const size_t chunk_rows = 1u << 18;  // 65 MB of standard rows per write
+    std::vector<uint8_t> buf;
+    try { buf.resize(std::min<uint64_t>(n, chunk_rows) * fmt.row_bytes); } catch (...) { std::fclose(f); return M2S_ERR_OOM; }
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (uint64_t r0 = 0; ok && r0 < n; r0 += chunk_rows) {
+        const size_t rows = (size_t)std::min<uint64_t>(chunk_rows, n - r0);
+        const unsigned nt = (unsigned)std::min<size_t>(hw, (rows + 4095) / 4096);
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) {
+            const size_t a = rows * t / nt, b = rows * (t + 1) / nt;
+            pool.emplace_back(encode_rows, records + r0 + a, b - a, format, scale_multiplier, buf.data() + a * fmt.row_bytes);
+        }
+        encode_rows(records + r0, rows / nt, format, scale_multiplier, buf.data());
+        for (auto& th : pool) th.join();
+        ok = std::fwrite(buf.data(), 1, rows * fmt.row_bytes, f) == rows * fmt.row_bytes;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? M2S_OK : M2S_ERR_IO;
+}

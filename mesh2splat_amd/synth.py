@@ -1,0 +1,173 @@
+"""Deterministic synthetic scenes for parity tests and bench.py (no assets ship with the
+reference and there is no network): SURVEY.md section 8(d) inputs I-1 .. I-5.
+
+Every generator returns host-side :class:`mesh2splat_amd.scene.Scene` objects whose vertex
+arrays use the reference's VBO layout (SceneManager.cpp:483-512: pos3 normal3 tangent4 uv2
+[normalizedUv2 scale3]), de-indexed, three vertices per triangle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .scene import Mesh, Scene
+
+SEED = 0x4D32535F5345454F  # "M2S_SEED"
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 arrays."""
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x += np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _hash_u8(w: int, h: int, seed: int, lane: int) -> np.ndarray:
+    idx = np.arange(w * h, dtype=np.uint64) + np.uint64((seed + lane * 0x1000003) & 0xFFFFFFFFFFFFFFFF)
+    return (splitmix64(idx) >> np.uint64(56)).astype(np.uint8).reshape(h, w)
+
+
+def procedural_textures(size: int, seed: int = SEED) -> dict:
+    """Albedo = 32x32 checker x per-texel hash noise; normal = normalise((hx,hy,4));
+    metallic-roughness: G = row gradient, B = 64x64 checker, A = 255."""
+    w = h = int(size)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cell = max(1, w // 32)
+    checker = (((xx // cell) + (yy // cell)) & 1).astype(np.float32) * 0.5 + 0.5
+    albedo = np.empty((h, w, 4), np.uint8)
+    for c in range(3):
+        noise = _hash_u8(w, h, seed, c).astype(np.float32)
+        albedo[..., c] = np.clip(np.rint(noise * checker), 0, 255).astype(np.uint8)
+    albedo[..., 3] = 255
+    hx = _hash_u8(w, h, seed, 3).astype(np.float32) / 127.5 - 1.0
+    hy = _hash_u8(w, h, seed, 4).astype(np.float32) / 127.5 - 1.0
+    nz = np.full_like(hx, 4.0)
+    inv = 1.0 / np.sqrt(hx * hx + hy * hy + nz * nz)
+    normal = np.empty((h, w, 4), np.uint8)
+    normal[..., 0] = np.clip(np.rint((hx * inv * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    normal[..., 1] = np.clip(np.rint((hy * inv * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    normal[..., 2] = np.clip(np.rint((nz * inv * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    normal[..., 3] = 255
+    mr = np.empty((h, w, 4), np.uint8)
+    mr[..., 0] = 0
+    mr[..., 1] = np.clip(np.rint(yy * (255.0 / max(1, h - 1))), 0, 255).astype(np.uint8)
+    cell2 = max(1, w // 64)
+    mr[..., 2] = ((((xx // cell2) + (yy // cell2)) & 1) * 255).astype(np.uint8)
+    mr[..., 3] = 255
+    return {
+        "baseColorTexture": np.ascontiguousarray(albedo),
+        "normalTexture": np.ascontiguousarray(normal),
+        "metallicRoughnessTexture": np.ascontiguousarray(mr),
+    }
+
+
+def unit_quad(textures: dict | None = None, stride: int = 17, name: str = "quad_0") -> Scene:
+    """I-1: verts (0,0,0),(1,0,0),(1,1,0),(0,1,0); tris (0,1,2),(0,2,3); n=(0,0,1); t=(1,0,0,1); uv=xy."""
+    corners = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    idx = [0, 1, 2, 0, 2, 3]
+    v = np.zeros((6, stride), np.float32)
+    for k, i in enumerate(idx):
+        v[k, 0:3] = corners[i]
+        v[k, 3:6] = (0, 0, 1)
+        v[k, 6:10] = (1, 0, 0, 1)
+        v[k, 10:12] = corners[i, :2]
+    m = Mesh(name=name, vertices=v, base_color=(1.0, 1.0, 1.0, 1.0), textures=dict(textures or {}))
+    return Scene([m])
+
+
+def cube_sphere_vertices(n: int, radius: float = 1.0, center=(0.0, 0.0, 0.0), stride: int = 12) -> np.ndarray:
+    """Cube-sphere with n x n quads per cube face => 12*n*n triangles, de-indexed.
+    Normals analytic, tangent = d/d(longitude) (w=+1), equirectangular UVs."""
+    n = int(n)
+    g = np.linspace(-1.0, 1.0, n + 1, dtype=np.float64)
+    a, b = np.meshgrid(g, g, indexing="xy")  # (n+1, n+1)
+    one = np.ones_like(a)
+    faces = [
+        np.stack([one, b, -a], -1), np.stack([-one, b, a], -1),
+        np.stack([a, one, -b], -1), np.stack([a, -one, b], -1),
+        np.stack([a, b, one], -1), np.stack([-a, b, -one], -1),
+    ]
+    out = []
+    for f in faces:
+        d = f / np.linalg.norm(f, axis=-1, keepdims=True)  # unit directions on the grid points
+        p00, p10 = d[:-1, :-1], d[:-1, 1:]
+        p01, p11 = d[1:, :-1], d[1:, 1:]
+        tri = np.stack([p00, p10, p11, p00, p11, p01], axis=2)  # (n, n, 6, 3)
+        out.append(tri.reshape(-1, 3))
+    d = np.concatenate(out, 0)  # (72 n^2 / 6 * 6 ... = 36 n^2, 3)
+    pos = d * radius + np.asarray(center, np.float64)
+    lon = np.arctan2(d[:, 2], d[:, 0])
+    u = lon / (2.0 * np.pi) + 0.5
+    v_ = np.arccos(np.clip(d[:, 1], -1.0, 1.0)) / np.pi
+    tang = np.stack([-d[:, 2], np.zeros(len(d)), d[:, 0]], -1)
+    tl = np.linalg.norm(tang, axis=-1, keepdims=True)
+    pole = tl[:, 0] < 1e-12
+    tang = np.where(pole[:, None], np.array([1.0, 0.0, 0.0]), tang / np.where(tl == 0, 1.0, tl))
+    verts = np.zeros((len(d), stride), np.float32)
+    verts[:, 0:3] = pos
+    verts[:, 3:6] = d
+    verts[:, 6:9] = tang
+    verts[:, 9] = 1.0
+    verts[:, 10] = u
+    verts[:, 11] = v_
+    return verts
+
+
+def cube_sphere(n: int, tex_size: int = 0, seed: int = SEED, stride: int = 12, name: str = "sphere_0") -> Scene:
+    """I-2 (n=76, 2048^2 maps) / I-3 (n=289, 2048^2 maps): one textured cube-sphere mesh."""
+    tex = procedural_textures(tex_size, seed) if tex_size else {}
+    m = Mesh(name=name, vertices=cube_sphere_vertices(n, stride=stride), base_color=(1.0, 1.0, 1.0, 1.0), textures=tex)
+    return Scene([m])
+
+
+def sphere_grid(n_meshes_side: int = 4, n: int = 18, tex_size: int = 1024, spacing: float = 1.0,
+                radius_frac: float = 0.2, seed: int = SEED, stride: int = 12) -> Scene:
+    """I-4 (Sponza stand-in): side^3 meshes x cube-sphere(n), distinct materials, one grid cell each.
+    Exercises the cumulative bbox (SceneManager.cpp:476-527) and per-mesh texture switching."""
+    meshes = []
+    k = 0
+    for iz in range(n_meshes_side):
+        for iy in range(n_meshes_side):
+            for ix in range(n_meshes_side):
+                c = (ix * spacing, iy * spacing, iz * spacing)
+                v = cube_sphere_vertices(n, radius=radius_frac * spacing, center=c, stride=stride)
+                tex = procedural_textures(tex_size, seed + k) if tex_size else {}
+                col = (0.5 + 0.5 * ((k * 37) % 11) / 10.0, 0.5 + 0.5 * ((k * 17) % 7) / 6.0, 1.0, 1.0)
+                meshes.append(Mesh(name=f"sphere_{k}", vertices=v, base_color=col, textures=tex))
+                k += 1
+    return Scene(meshes)
+
+
+def colocated_spheres(count: int, n: int, tex_size: int, seed: int = SEED, stride: int = 12) -> Scene:
+    """Weak-scaling scene: `count` identical-geometry cube-spheres at the origin (so the cumulative
+    bbox is the same for every mesh and every mesh yields the same number of Gaussians), one
+    material per mesh sharing the same texel data."""
+    base = cube_sphere_vertices(n, stride=stride)
+    tex = procedural_textures(tex_size, seed) if tex_size else {}
+    return Scene([Mesh(name=f"sphere_{k}", vertices=base, base_color=(1.0, 1.0, 1.0, 1.0), textures=tex)
+                  for k in range(count)])
+
+
+def random_soup(n_tri: int, seed: int = 1, extent: float = 1.0, tri_size: float = 0.2, stride: int = 12,
+                textures: dict | None = None, name: str = "soup_0") -> Scene:
+    """Random triangle soup with random normals/tangents/uvs: stresses every branch of the setup
+    (all three projection axes, both windings, all longest-edge cases)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0, extent, (n_tri, 1, 3))
+    size = tri_size * rng.uniform(0.02, 1.0, (n_tri, 1, 1)) ** 2
+    p = c + rng.uniform(-1, 1, (n_tri, 3, 3)) * size
+    nrm = rng.normal(size=(n_tri, 3, 3))
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    tng = rng.normal(size=(n_tri, 3, 3))
+    tng /= np.linalg.norm(tng, axis=-1, keepdims=True)
+    v = np.zeros((n_tri, 3, stride), np.float32)
+    v[..., 0:3] = p
+    v[..., 3:6] = nrm
+    v[..., 6:9] = tng
+    v[..., 9] = rng.choice([-1.0, 1.0], (n_tri, 3))
+    v[..., 10:12] = rng.uniform(-0.5, 2.5, (n_tri, 3, 2))
+    m = Mesh(name=name, vertices=v.reshape(-1, stride), base_color=(0.8, 0.6, 0.4, 0.9), textures=dict(textures or {}))
+    return Scene([m])

@@ -1,0 +1,94 @@
+/*
+ * m2s_oracle.h — CPU ORACLE for the mesh -> 3DGS conversion pass.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (mesh2splat_amd/) never
+ * links, imports or calls anything under oracle/.
+ *
+ * It is a plain-C, fp32 restatement of the reference's conversion pass:
+ *   src/shaders/conversion/converterGS.glsl:326-443   (per-triangle setup)
+ *   src/shaders/conversion/converterFS.glsl:44-104    (per-fragment shading + record)
+ *   src/renderer/renderPasses/ConversionPass.cpp:9-117 (driver: cap, per-mesh uniforms)
+ *   src/utils/glUtils.cpp:292-313                      (sampler state)
+ *   src/parsers/parsers.cpp:232-514, src/utils/utils.cpp:45-49, utils.hpp:270 (PLY export)
+ * plus the OpenGL 4.6 fixed-function behaviour the shaders rely on (viewport transform,
+ * pixel-centre rasterisation, screen-linear attribute interpolation, trilinear REPEAT
+ * sampling, GenerateMipmap), pinned as written in DESIGN.md section "Pinned semantics".
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or sample assets for this
+ * path and its implementation (GLSL on an OpenGL 4.6 driver inside a Windows GUI app) can
+ * be neither built nor run in this environment.  The oracle is therefore anchored on
+ * hand-derived known-answer tests (tests/test_oracle_kat.py) and, for the one sub-function
+ * with compilable third-party provenance (quat_cast == glm::quat_cast), on glm itself
+ * (oracle/ref_glm_check.cpp -> oracle/_ref/).
+ */
+#ifndef M2S_ORACLE_H
+#define M2S_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    const uint8_t* rgba8; /* tightly packed RGBA8, row 0 first; NULL = absent */
+    uint32_t width, height;
+} orc_texture;
+
+typedef struct {
+    const float* vertices;   /* de-indexed: 3 vertices per triangle                     */
+    uint32_t n_vertices;     /* multiple of 3                                            */
+    uint32_t stride_floats;  /* >= 12: pos3 normal3 tangent4 uv2 [normalizedUv2 scale3]  */
+    float bbox_min[3], bbox_max[3]; /* the mesh's u_bboxMin/u_bboxMax uniforms           */
+    float base_color[4];     /* u_materialFactor                                         */
+    orc_texture tex[3];      /* 0 albedo, 1 normal, 2 metallic-roughness                 */
+} orc_mesh;
+
+/* 24 floats per record == utils::GaussianDataSSBO (utils.hpp:145-152):
+ * position(4) color(4) scale(4) normal(4) rotation(4) pbr(4). */
+#define ORC_RECORD_FLOATS 24
+
+/* Reference cap formula, ConversionPass.cpp:21-24 (32-bit unsigned arithmetic). */
+uint32_t orc_reference_cap(uint32_t R, uint32_t n_meshes);
+
+/*
+ * Convert.  Records are produced in canonical order (mesh, triangle, pixel row y, pixel x).
+ *   tri_first/tri_count : restrict to a range of the flattened (mesh-major) triangle list;
+ *                         tri_count == UINT64_MAX means "to the end".
+ *   cap                 : records with canonical index >= cap are not stored (cap 0 = unlimited)
+ *   out / out_capacity  : may be NULL / 0 to only count
+ *   keys                : optional, one u64 per stored record: (global_tri << 24) | (y << 12) | x
+ *   n_threads           : >1 uses OpenMP over triangles (two-pass count/emit), results identical
+ * Returns the total number of fragments (like the reference's atomic counter, NOT clamped).
+ */
+uint64_t orc_convert(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R,
+                     uint64_t tri_first, uint64_t tri_count, uint64_t cap,
+                     float* out, uint64_t out_capacity, uint64_t* keys, int n_threads);
+
+/* Per-triangle fragment counts only (for shard balancing tests). counts has n_triangles entries. */
+uint64_t orc_count_per_triangle(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R,
+                                uint32_t* counts);
+
+/* Mip chain, levels 0..min(4, floor(log2(max(w,h)))), 2x2 box filter, round-half-up.
+ * Returns number of levels; level_offsets (in texels) gets n_levels entries; dst must hold
+ * orc_mip_total_texels(w,h) * 4 bytes. */
+uint32_t orc_mip_levels(uint32_t w, uint32_t h);
+uint64_t orc_mip_total_texels(uint32_t w, uint32_t h);
+uint32_t orc_build_mips(const uint8_t* rgba8, uint32_t w, uint32_t h, uint8_t* dst,
+                        uint64_t* level_offsets);
+
+/* Trilinear REPEAT sample with explicit lod lambda (exposed for tests). out = 4 floats. */
+void orc_sample(const uint8_t* mipchain, uint32_t w, uint32_t h, float u, float v,
+                float lambda, float* out);
+
+/* PLY writers, byte-for-byte restatement of parsers.cpp:232-514.
+ * format 0 standard 3DGS (62 floats), 1 PBR (19 floats), 2 compressed PBR (48 bytes).
+ * Returns 0 on success.  records are NOT modified. */
+int orc_write_ply(const char* path, const float* records, uint64_t n, unsigned format,
+                  float scale_multiplier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

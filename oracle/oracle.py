@@ -1,0 +1,163 @@
+"""ctypes front-end of the CPU ORACLE (oracle/m2s_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under mesh2splat_amd/ may import this module.
+PARITY UNPINNED: see oracle/m2s_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libm2s_oracle.so")
+_lib = None
+
+TEX_KEYS = ("baseColorTexture", "normalTexture", "metallicRoughnessTexture")
+
+
+class _Tex(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("n_vertices", C.c_uint32), ("stride_floats", C.c_uint32),
+                ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("base_color", C.c_float * 4),
+                ("tex", _Tex * 3)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "m2s_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_reference_cap.restype = C.c_uint32
+        L.orc_reference_cap.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_convert.restype = C.c_uint64
+        L.orc_convert.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_count_per_triangle.restype = C.c_uint64
+        L.orc_count_per_triangle.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_mip_levels.restype = C.c_uint32
+        L.orc_mip_levels.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_mip_total_texels.restype = C.c_uint64
+        L.orc_mip_total_texels.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_build_mips.restype = C.c_uint32
+        L.orc_build_mips.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_sample.restype = None
+        L.orc_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_write_ply.restype = C.c_int
+        L.orc_write_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_float]
+        L.orc_quat_cast.restype = None
+        L.orc_quat_cast.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _c_meshes(scene):
+    """scene: anything with .meshes, each having vertices/base_color/textures/bbox_min/bbox_max."""
+    arr = (_Mesh * max(1, len(scene.meshes)))()
+    keep = []
+    for i, m in enumerate(scene.meshes):
+        v = np.ascontiguousarray(m.vertices, np.float32)
+        keep.append(v)
+        arr[i].vertices = v.ctypes.data
+        arr[i].n_vertices = v.shape[0]
+        arr[i].stride_floats = v.shape[1]
+        for k in range(3):
+            arr[i].bbox_min[k] = float(m.bbox_min[k])
+            arr[i].bbox_max[k] = float(m.bbox_max[k])
+        for k in range(4):
+            arr[i].base_color[k] = float(m.base_color[k])
+        for k, key in enumerate(TEX_KEYS):
+            t = m.textures.get(key)
+            if t is None:
+                continue
+            t = np.ascontiguousarray(t, np.uint8)
+            keep.append(t)
+            arr[i].tex[k].rgba8 = t.ctypes.data
+            arr[i].tex[k].width = t.shape[1]
+            arr[i].tex[k].height = t.shape[0]
+    return arr, keep
+
+
+def reference_cap(R: int, n_meshes: int) -> int:
+    return int(lib().orc_reference_cap(R, n_meshes))
+
+
+def convert(scene, R: int, cap: int | None = None, tri_first: int = 0, tri_count: int | None = None,
+            want_keys: bool = False, n_threads: int = 1, count_only: bool = False):
+    """Returns (total, records[(n_stored, 24) float32], keys or None).
+    cap=None -> reference formula; cap=0 -> unlimited."""
+    L = lib()
+    arr, keep = _c_meshes(scene)
+    nm = len(scene.meshes)
+    if cap is None:
+        cap = reference_cap(R, nm)
+    tc = (1 << 64) - 1 if tri_count is None else int(tri_count)
+    total = L.orc_convert(arr, nm, R, tri_first, tc, cap, None, 0, None, n_threads)
+    if count_only:
+        return int(total), None, None
+    n_store = min(total, cap) if cap else total
+    out = np.zeros((n_store, 24), np.float32)
+    keys = np.zeros(n_store, np.uint64) if want_keys else None
+    t2 = L.orc_convert(arr, nm, R, tri_first, tc, cap, out.ctypes.data, n_store,
+                       keys.ctypes.data if want_keys else None, n_threads)
+    assert t2 == total
+    del keep
+    return int(total), out, keys
+
+
+def count_per_triangle(scene, R: int) -> np.ndarray:
+    arr, keep = _c_meshes(scene)
+    T = sum(m.vertices.shape[0] // 3 for m in scene.meshes)
+    counts = np.zeros(T, np.uint32)
+    lib().orc_count_per_triangle(arr, len(scene.meshes), R, counts.ctypes.data)
+    del keep
+    return counts
+
+
+def build_mips(tex: np.ndarray):
+    """tex (H,W,4) uint8 -> (chain bytes as uint8[total,4], level offsets in texels, n_levels)."""
+    L = lib()
+    t = np.ascontiguousarray(tex, np.uint8)
+    h, w = t.shape[:2]
+    tot = L.orc_mip_total_texels(w, h)
+    dst = np.zeros((tot, 4), np.uint8)
+    offs = np.zeros(5, np.uint64)
+    n = L.orc_build_mips(t.ctypes.data, w, h, dst.ctypes.data, offs.ctypes.data)
+    return dst, offs[:n].copy(), int(n)
+
+
+def sample(tex: np.ndarray, u: float, v: float, lam: float) -> np.ndarray:
+    chain, _, _ = build_mips(tex)
+    out = np.zeros(4, np.float32)
+    lib().orc_sample(chain.ctypes.data, tex.shape[1], tex.shape[0], u, v, lam, out.ctypes.data)
+    return out
+
+
+def write_ply(path: str, records: np.ndarray, fmt: int, scale_multiplier: float) -> None:
+    r = np.ascontiguousarray(records, np.float32)
+    rc = lib().orc_write_ply(os.fsencode(path), r.ctypes.data, r.shape[0], fmt, scale_multiplier)
+    if rc:
+        raise IOError(f"orc_write_ply failed ({rc})")
+
+
+def quat_cast(m_cols: np.ndarray) -> np.ndarray:
+    """m_cols: (3,3) array whose rows are the matrix COLUMNS (GLSL m[c][r]). Returns (x,y,z,w)."""
+    m = np.ascontiguousarray(m_cols, np.float32)
+    q = np.zeros(4, np.float32)
+    lib().orc_quat_cast(m.ctypes.data, q.ctypes.data)
+    return q

@@ -1,0 +1,135 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from mesh2splat_amd import synth
+from mesh2splat_amd.converter import Converter
+from mesh2splat_amd.scene import Mesh, Scene
+from parity import assert_records_match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def conv(hiplib):
+    c = Converter(0)
+    yield c
+    c.close()
+
+
+def run_both(conv, oracle, scene, R, cap=None):
+    conv.set_triangle_range(0, None)
+    conv.upload_scene(scene)
+    conv.set_max_gaussians(-1 if cap is None else cap)
+    total = conv.convert(R)
+    rec = conv.download()
+    ototal, orec, _ = oracle.convert(scene, R, cap=cap)
+    return total, rec, ototal, orec
+
+
+def test_unit_quad_c1(conv, oracle):
+    """BASELINE config C1 / KAT K-1: unit quad, no textures, R=64 -> exactly 4096 Gaussians."""
+    total, rec, ototal, orec = run_both(conv, oracle, synth.unit_quad(), 64)
+    assert total == ototal == 4096
+    assert_records_match(rec, orec, "quad R=64")
+    assert np.all(rec[:, 8:11] == np.float32([1, 1, 1e-7]))
+
+
+@pytest.mark.parametrize("R", [16, 64, 333, 1024])
+def test_unit_quad_textured(conv, oracle, R):
+    """Large triangles (wave-cooperative rasteriser) + all three maps, mag and min filtering."""
+    scene = synth.unit_quad(synth.procedural_textures(256))
+    total, rec, ototal, orec = run_both(conv, oracle, scene, R)
+    assert total == ototal == R * R
+    assert_records_match(rec, orec, f"textured quad R={R}")
+
+
+@pytest.mark.parametrize("n,R,tex", [(8, 64, 0), (24, 256, 128), (76, 512, 512)])
+def test_cube_sphere(conv, oracle, n, R, tex):
+    scene = synth.cube_sphere(n, tex_size=tex)
+    total, rec, ototal, orec = run_both(conv, oracle, scene, R)
+    assert total == ototal
+    assert_records_match(rec, orec, f"sphere n={n} R={R}")
+
+
+@pytest.mark.parametrize("seed,R", [(1, 64), (2, 257), (3, 1024)])
+def test_random_soup(conv, oracle, seed, R):
+    """All projection axes, both windings, all longest-edge cases, uv outside [0,1] (REPEAT)."""
+    scene = synth.random_soup(3000, seed=seed, textures=synth.procedural_textures(64, seed))
+    total, rec, ototal, orec = run_both(conv, oracle, scene, R, cap=0)
+    assert total == ototal
+    assert_records_match(rec, orec, f"soup seed={seed} R={R}")
+
+
+def test_multi_mesh_cumulative_bbox(conv, oracle):
+    """I-4 style scene: 8 meshes, distinct materials; mesh k's bbox is the AABB of meshes 0..k."""
+    scene = synth.sphere_grid(2, n=6, tex_size=64)
+    total, rec, ototal, orec = run_both(conv, oracle, scene, 128, cap=0)
+    assert total == ototal
+    assert_records_match(rec, orec, "sphere grid")
+
+
+def test_cap_semantics(conv, oracle):
+    """Counter keeps counting past the cap (ConversionPass.cpp:56-59); only cap records are stored."""
+    scene = synth.cube_sphere(8)
+    total, rec, ototal, orec = run_both(conv, oracle, scene, 64, cap=1000)
+    assert total == ototal > 1000
+    assert rec.shape[0] == 1000 == conv.num_stored
+    assert_records_match(rec, orec, "cap")
+
+
+def test_reference_cap_formula(conv, oracle):
+    conv.upload_scene(synth.unit_quad())
+    conv.set_max_gaussians(-1)
+    assert conv.convert(16) == 256
+    assert oracle.reference_cap(16, 1) == 16 * 16 * 6
+
+
+def test_empty_and_degenerate(conv, oracle):
+    """Empty mesh list entry, zero-area and collinear triangles, flat bbox (range 0 -> NaN uv)."""
+    v = np.zeros((9, 12), np.float32)
+    v[0:3, 0:3] = [[0, 0, 0], [0, 0, 0], [0, 0, 0]]           # zero area
+    v[3:6, 0:3] = [[0, 0, 0], [1, 1, 0], [2, 2, 0]]           # collinear
+    v[6:9, 0:3] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]           # a real one
+    v[:, 3:6] = [0, 0, 1]
+    v[:, 6:10] = [1, 0, 0, 1]
+    empty = Mesh("empty", np.zeros((0, 12), np.float32))
+    scene = Scene([empty, Mesh("m", v)])
+    total, rec, ototal, orec = run_both(conv, oracle, scene, 32)
+    assert total == ototal > 0
+    assert_records_match(rec, orec, "degenerate")
+    flat = Mesh("flat", v[6:9].copy(), bbox_min=np.zeros(3, np.float32), bbox_max=np.zeros(3, np.float32))
+    total, rec, ototal, orec = run_both(conv, oracle, Scene([flat]), 32)
+    assert total == ototal == 0 and rec.shape[0] == 0
+
+
+def test_triangle_range_shards_concatenate(conv, oracle):
+    """Multi-GPU contract: converting triangle ranges independently and concatenating in rank order
+    reproduces the unsharded result exactly."""
+    scene = synth.sphere_grid(2, n=5, tex_size=32)
+    conv.set_triangle_range(0, None)
+    conv.upload_scene(scene)
+    conv.set_max_gaussians(0)
+    conv.convert(96)
+    full = conv.download()
+    T = scene.n_triangles
+    cuts = [0, T // 3, T // 3 + 7, T]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        conv.set_triangle_range(a, b - a)
+        conv.upload_scene(scene)
+        conv.convert(96)
+        parts.append(conv.download())
+    conv.set_triangle_range(0, None)
+    cat = np.concatenate(parts, 0)
+    assert cat.shape == full.shape
+    assert np.array_equal(cat.view(np.uint32), full.view(np.uint32))
+
+
+def test_triangle_counts_match_oracle(conv, oracle):
+    scene = synth.random_soup(5000, seed=9)
+    conv.set_triangle_range(0, None)
+    conv.upload_scene(scene)
+    conv.set_max_gaussians(0)
+    conv.convert(512)
+    assert np.array_equal(conv.download_triangle_counts(), oracle.count_per_triangle(scene, 512))
