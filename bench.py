@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py — Gaussians/sec of the mesh -> 3DGS conversion pass on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one execution of the conversion pass (== ConversionPass::execute: count, scan,
+offsets, emit, counter read-back) on geometry and textures already resident in HBM.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): I-3 = cube-sphere n=289
+(1 002 252 triangles), three procedural 2048^2 RGBA8 maps, density R = 1024.
+N > 1 is WEAK scaling: the scene holds N such meshes (co-located, so every mesh has the same
+cumulative bbox and the same fragment count), sharded by triangle range one mesh per rank; the
+only collective in the timed step is the all-gather of the per-rank counters that gives every
+rank its offset in the virtual concatenated splat buffer.  The full record all-gather over xGMI
+(north-star) is measured separately after the timed region and reported under "gather".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (cube-sphere n, texture size, R)
+    "c3": (289, 2048, 1024),   # BASELINE configs[2] — default
+    "c2": (76, 2048, 512),     # SciFiHelmet stand-in (I-2)
+    "small": (24, 256, 256),   # CI-sized
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_one_mesh, R, budget_s):
+    """Oracle (CPU port of the reference path) on the host cores, same workload, bounded time."""
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    import numpy as np  # noqa: F401
+    best = None
+    t_start = time.perf_counter()
+    reps = 0
+    total = 0
+    while reps < 3 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        total, rec, _ = oracle.convert(scene_one_mesh, R, n_threads=cores)
+        dt = time.perf_counter() - t0
+        del rec
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return {"value": total / best, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"full workload ({total} Gaussians), OpenMP over triangles, count+emit incl. mip build, "
+                      f"best of {reps}", "ms_per_mesh": best * 1e3}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+
+    import torch  # first, so that the HIP runtime torch ships is the one the process uses
+    import torch.distributed as dist
+    import numpy as np
+    from mesh2splat_amd import synth
+    from mesh2splat_amd.converter import Converter
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, tex, R = WORKLOADS[a.workload]
+    scene = synth.colocated_spheres(world, n, tex)
+    tri_per_mesh = scene.meshes[0].n_triangles
+
+    conv = Converter(local_rank)
+    conv.set_triangle_range(rank * tri_per_mesh, tri_per_mesh)
+    conv.upload_scene(scene)
+    # N == 1: the reference's own cap formula.  N > 1: the merged scene exceeds the reference's
+    # 7 M envelope, so the cap is lifted and each rank writes into its own buffer.
+    conv.set_max_gaussians(-1 if world == 1 else 0)
+    T_local = conv.num_triangles
+
+    stream = torch.cuda.current_stream().cuda_stream
+    out = None
+    counts = torch.zeros(world, dtype=torch.int64, device="cuda")
+    mine = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def step():
+        if world == 1:
+            return conv.convert(R)
+        nonlocal out
+        total = conv.convert_into(R, out.data_ptr(), out.shape[0], stream)
+        mine.fill_(total)
+        dist.all_gather_into_tensor(counts, mine)   # offsets of every rank in the merged buffer
+        return total
+
+    if world > 1:
+        # size the per-rank record buffer once (like the SSBO (re)allocation, outside the timed region)
+        probe = torch.empty((1, 24), dtype=torch.float32, device="cuda")
+        need = conv.convert_into(R, probe.data_ptr(), 1, stream)
+        out = torch.empty((need, 24), dtype=torch.float32, device="cuda")
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    conv.set_profiling(True)   # HIP events around every kernel, on the stream the kernels run on
+    kms = {k: 0.0 for k in ("count", "scan", "offsets", "emit")}
+    sync()
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(a.steps):
+        total = step()
+        for k, v in conv.last_kernel_ms().items():
+            kms[k] += v
+    sync()
+    dt = time.perf_counter() - t0
+    conv.set_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    n_all = int(ntot.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = n_all / (dt / a.steps)
+
+    # optional: the north-star record all-gather (xGMI-bound), measured outside the timed region
+    gather = None
+    if world > 1 and not a.no_gather:
+        nmax = int(counts.max().item())
+        send = torch.zeros((nmax, 24), dtype=torch.float32, device="cuda")
+        send[: out.shape[0]] = out
+        recv = torch.empty((world * nmax, 24), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            dist.all_gather_into_tensor(recv, send)
+        sync()
+        g0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            step()
+            send[: out.shape[0]] = out
+            dist.all_gather_into_tensor(recv, send)
+        sync()
+        gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+        gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
+                  "what": "convert + padded RCCL all-gather of all records to every rank"}
+
+    if rank == 0:
+        emit_ms = kms["emit"] / a.steps
+        # algorithmic bytes of one emit launch: 96 B per Gaussian written + 144 B per triangle read
+        # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
+        b_alg = 96.0 * total + 144.0 * T_local
+        achieved = b_alg / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
+        res = {
+            "metric": "Gaussians/sec emitted (mesh->3DGS conversion pass, density 1024^2)" if R == 1024 else
+                      f"Gaussians/sec emitted (mesh->3DGS conversion pass, density {R}^2)",
+            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
+                                   f"3 procedural {tex}^2 RGBA8 maps, R={R}",
+                       "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
+                       "cap": "reference formula" if world == 1 else "unlimited (merged scene exceeds the 7M envelope)"},
+            "kernel_ms": {k: v / a.steps for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_emit",
+                         "algorithmic_bytes": b_alg,
+                         "write_only_frac": (96.0 * total / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
+        }
+        tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tr):
+            try:
+                with open(tr) as f:
+                    t = json.load(f)
+                if t.get("workload") == a.workload:
+                    res["roofline"]["traffic"] = t.get("k_emit_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if gather:
+            res["gather"] = gather
+        if not a.no_cpu_baseline and world == 1:
+            one = synth.colocated_spheres(1, n, tex)
+            res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
