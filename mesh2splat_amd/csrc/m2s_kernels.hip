@@ -640,15 +640,21 @@ __global__ void __launch_bounds__(kBlock) k_emit(SceneDev sc, uint32_t R, const 
 
     const unsigned long long total = *total_p;
     const unsigned long long nw = total < limit ? total : limit;  // records actually stored
-    const unsigned long long base64 = (unsigned long long)blockIdx.x * kEmitF;
-    if (base64 >= nw) return;
+    // XCD-aware mapping: hardware places workgroup b on XCD b % 8 and each XCD has a private 4 MiB L2.
+    // Give every XCD one CONTIGUOUS slice of the output (hence of the mesh surface and of texture
+    // space) instead of every 8th block, so texture / vertex lines are fetched by one L2, not eight.
+    const uint32_t nblk = (uint32_t)((nw + kEmitF - 1) / kEmitF);
+    const uint32_t per_xcd = (nblk + 7) / 8;
+    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || lblock >= nblk) return;
+    const unsigned long long base64 = (unsigned long long)lblock * kEmitF;
     const uint32_t base = (uint32_t)base64;
     const uint32_t end = (uint32_t)(nw - base64 < (unsigned long long)kEmitF ? nw : base64 + kEmitF);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t T = sc.n_tri;
 
     // ---- phase A: expand triangles into (triangle, pixel) entries, in canonical order ----
-    const uint32_t t_first = start[blockIdx.x];
+    const uint32_t t_first = start[lblock];
     const uint32_t m0 = find_mesh(sc, sc.tri_first + t_first);
     uint32_t t_last_seen = t_first;
     for (uint32_t tc = t_first;; tc += kBlock) {
@@ -735,6 +741,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(SceneDev sc, uint32_t R, const 
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st) {
     if (!n_blocks || !sc.n_tri) return;
+    n_blocks = (n_blocks + 7u) & ~7u;  // the XCD swizzle needs whole groups of 8
     hipLaunchKernelGGL(k_emit, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total,
                        (unsigned long long)limit, out);
 }
