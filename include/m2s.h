@@ -135,12 +135,20 @@ m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t
  * (SceneManager.cpp:668). */
 m2s_status m2s_export_ply(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std);
 
+/* ---- pipeline selection ------------------------------------------------------------------------ */
+/* AUTO (default): the single-pass fused kernel (k_fused); if the scene holds triangles larger than its
+ * in-workgroup budget (> 32 pixel rows or > 2048 fragments) the call re-runs the multi-pass pipeline,
+ * which balances work by output range and handles any triangle size.  MULTIPASS forces the latter.
+ * Both produce bit-identical output. */
+enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1 };
+m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
-enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_N = 4 };
+enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_FUSED = 4, M2S_K_N = 5 };
 /* When enabled every convert brackets each kernel with hipEvents on its stream. */
 m2s_status m2s_set_profiling(m2s_ctx* ctx, int enabled);
 /* Kernel durations (ms) of the last profiled convert, indexed by M2S_K_*. */
-m2s_status m2s_last_kernel_ms(const m2s_ctx* ctx, float out_ms[4]);
+m2s_status m2s_last_kernel_ms(const m2s_ctx* ctx, float out_ms[M2S_K_N]);
 /* Scene facts for roofline accounting: triangles in range, meshes. */
 uint64_t m2s_num_triangles(const m2s_ctx* ctx);
 

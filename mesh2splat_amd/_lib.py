@@ -12,19 +12,19 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "_build", "libm2s_hip.so")
+LIB_PATH = os.environ.get("M2S_LIB_PATH") or os.path.join(_HERE, "_build", "libm2s_hip.so")  # env override: A/B builds
 
 M2S_OK = 0
 STATUS_NAMES = {0: "M2S_OK", 1: "M2S_ERR_INVALID", 2: "M2S_ERR_NO_DEVICE", 3: "M2S_ERR_HIP", 4: "M2S_ERR_OOM",
                 5: "M2S_ERR_CAPACITY", 6: "M2S_ERR_IO", 7: "M2S_ERR_STATE"}
-KERNEL_NAMES = ("count", "scan", "offsets", "emit")  # M2S_K_*
+KERNEL_NAMES = ("count", "scan", "offsets", "emit", "fused")  # M2S_K_*
 
 # every symbol include/m2s.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "m2s_abi_version", "m2s_create", "m2s_destroy", "m2s_last_error", "m2s_set_triangle_range", "m2s_upload_scene",
     "m2s_set_max_gaussians", "m2s_convert", "m2s_convert_into", "m2s_num_stored", "m2s_device_records", "m2s_download",
     "m2s_download_triangle_counts", "m2s_write_ply", "m2s_export_ply", "m2s_set_profiling", "m2s_last_kernel_ms",
-    "m2s_num_triangles",
+    "m2s_num_triangles", "m2s_set_pipeline",
 )
 
 
@@ -87,6 +87,7 @@ def load():
         "m2s_set_profiling": (C.c_int, [vp, C.c_int]),
         "m2s_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "m2s_num_triangles": (u64, [vp]),
+        "m2s_set_pipeline": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

@@ -132,12 +132,16 @@ class Converter:
     def export_ply(self, path: str, fmt: int = 0, gaussian_std: float = 0.65):
         self._check(self._L.m2s_export_ply(self._h, os.fsencode(path), int(fmt), float(gaussian_std)))
 
+    def set_pipeline(self, name: str):
+        """'auto' (fused single-pass kernel, multi-pass fallback for big triangles) or 'multipass'."""
+        self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1}[name]))
+
     # -- measurement --------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._check(self._L.m2s_set_profiling(self._h, 1 if on else 0))
 
     def last_kernel_ms(self) -> dict:
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * len(_lib.KERNEL_NAMES))()
         self._check(self._L.m2s_last_kernel_ms(self._h, ms))
         return {k: float(ms[i]) for i, k in enumerate(_lib.KERNEL_NAMES)}
 

@@ -18,7 +18,7 @@ namespace {
 thread_local std::string g_create_error = "";
 
 constexpr uint32_t kMaxGaussiansToSort = 7000000u;  // RenderPass.hpp:9
-constexpr uint64_t kMaxTriangles = 0x7FFFFFFFull;   // triangle indices are 32-bit on the device
+constexpr uint64_t kMaxTriangles = (1ull << 28) - 1;  // 32-bit byte offsets into the 16 B/triangle planes
 constexpr size_t kStagingBytes = 256ull << 20;      // H2D staging for the AoS -> SoA repack
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -46,7 +46,11 @@ struct m2s_ctx {
     uint32_t* d_start = nullptr;
     size_t start_cap = 0;
     unsigned long long* d_total = nullptr;
-    unsigned long long* h_total = nullptr;  // pinned
+    unsigned long long* h_total = nullptr;  // pinned: [0] = fragment counter, [1] = status words of the fused kernel
+    unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per workgroup
+    uint32_t* d_status = nullptr;           // [0] deferred (big) triangles, [1] look-back error
+    int pipeline = M2S_PIPELINE_AUTO;
+    uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
 
     // output
     void* d_records = nullptr;
@@ -58,7 +62,7 @@ struct m2s_ctx {
 
     // measurement
     bool profiling = false;
-    hipEvent_t ev[M2S_K_N + 1] = {};
+    hipEvent_t ev[8] = {};
     float last_ms[M2S_K_N] = {};
 };
 
@@ -84,6 +88,9 @@ static void free_scene(m2s_ctx* c) {
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_chain) (void)hipFree(c->d_chain);
+    c->d_chain = nullptr;
+    c->sized_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
     c->d_cnt = c->d_off = c->d_partials = nullptr;
@@ -119,7 +126,8 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->h_total, sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->h_total, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -135,6 +143,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
     if (c->d_total) (void)hipFree(c->d_total);
+    if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -172,7 +181,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
                 return fail(c, M2S_ERR_INVALID, "texture dimensions must be in [1, 32768]");
         mesh_first[i] = (uint32_t)T;
         T += m.n_vertices / 3;
-        if (T > kMaxTriangles) return fail(c, M2S_ERR_INVALID, "more than 2^31-1 triangles");
+        if (T > kMaxTriangles) return fail(c, M2S_ERR_INVALID, "more than 2^28-1 triangles in one scene (shard it with m2s_set_triangle_range per context)");
     }
     mesh_first[n_meshes] = (uint32_t)T;
     const uint64_t first = std::min<uint64_t>(c->range_first, T);
@@ -265,6 +274,35 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
             dedup[key] = d;
         }
     }
+    // ---- combo textures (interleaved albedo/normal/MR, see ComboDesc) ----------------------------------
+    {
+        std::map<std::tuple<const uint32_t*, const uint32_t*, const uint32_t*>, ComboDesc> cdedup;
+        for (uint32_t i = 0; i < n_meshes; ++i) {
+            MeshParams& p = mp[i];
+            const TexDesc &ta = p.tex[0], &tn = p.tex[1], &tm = p.tex[2];
+            if (!ta.texels || !tn.texels || !tm.texels) continue;
+            if (ta.w != tn.w || ta.w != tm.w || ta.h != tn.h || ta.h != tm.h) continue;
+            auto key = std::make_tuple(ta.texels, tn.texels, tm.texels);
+            auto it = cdedup.find(key);
+            if (it != cdedup.end()) { p.combo = it->second; continue; }
+            ComboDesc cd{};
+            size_t tot = 0;
+            for (uint32_t l = 0; l < ta.n_levels; ++l) {
+                cd.coff[l] = (uint32_t)tot;
+                tot += (size_t)(std::max(1u, ta.w >> l) + 1) * std::max(1u, ta.h >> l) * 3;
+            }
+            if (tot > 0xFFFFFFFFull) continue;  // 32-bit dword offsets
+            void* mem = nullptr;
+            HIPCHK(c, hipMalloc(&mem, tot * 4));
+            c->tex_mem.push_back(mem);
+            cd.texels = (const uint32_t*)mem;
+            for (uint32_t l = 0; l < ta.n_levels; ++l)
+                launch_combo_level(ta.texels + ta.off[l], tn.texels + tn.off[l], tm.texels + tm.off[l], std::max(1u, ta.w >> l),
+                                   std::max(1u, ta.h >> l), (uint32_t*)mem + cd.coff[l], c->stream);
+            p.combo = cd;
+            cdedup[key] = cd;
+        }
+    }
     HIPCHK(c, hipMalloc((void**)&c->d_meshes, mp.size() * sizeof(MeshParams)));
     HIPCHK(c, hipMemcpyAsync(c->d_meshes, mp.data(), mp.size() * sizeof(MeshParams), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMalloc((void**)&c->d_mesh_first, mesh_first.size() * sizeof(uint32_t)));
@@ -277,6 +315,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     HIPCHK(c, hipMalloc((void**)&c->d_cnt, np * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_off, (np + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_partials, std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_chain, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long)));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries
     c->has_scene = true;
     c->last_total = c->last_stored = 0;
@@ -293,9 +332,38 @@ static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     return std::min(mx, kMaxGaussiansToSort);
 }
 
+// Multi-pass pipeline (count -> scan -> offsets -> emit): handles every triangle size, output-balanced.
+static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, hipStream_t st) {
+    const SceneDev& sc = c->scene;
+    const bool prof = c->profiling;
+    if (!counted) {
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count(sc, R, c->d_cnt, c->d_partials, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+        launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    }
+    const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
+    if (c->start_cap < n_blocks) {
+        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_start, std::max<size_t>(n_blocks, 1) * sizeof(uint32_t)));
+        c->start_cap = n_blocks;
+    }
+    launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    if (prof)
+        for (int k = counted ? 2 : 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+    return M2S_OK;
+}
+
 static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total) {
     if (!c->has_scene) return fail(c, M2S_ERR_STATE, "m2s_upload_scene has not been called");
-    if (R == 0 || R > 8192) return fail(c, M2S_ERR_INVALID, "R must be in [1, 8192]");
+    if (R == 0 || R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [1, 4096]");
     HIPCHK(c, hipSetDevice(c->device));
     const SceneDev& sc = c->scene;
     const uint64_t cap = resolve_cap(c, R);
@@ -310,14 +378,8 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         return M2S_OK;
     }
 
-    // K1 + scan: fragment counter (== the atomic counter of converterFS.glsl:46, but exact and ordered)
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    launch_count(sc, R, c->d_cnt, c->d_partials, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-    launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-
-    // where do the records go, and how many may be stored?
+    // ---- where do the records go, and how many may be stored? ------------------------------------
+    bool counted = false;  // k_count + k_scan already ran in this call
     uint64_t limit;
     float4* d_out;
     if (d_user) {
@@ -325,10 +387,22 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         d_out = (float4*)d_user;
     } else {
         uint64_t want = cap;
-        if (!cap) {  // unlimited: size the SSBO from the counter (one extra host round trip)
+        if (!cap && (c->sized_R != R || !c->d_records)) {
+            // unlimited policy: size the SSBO from an exact count (once per (scene, R))
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+            launch_count(sc, R, c->d_cnt, c->d_partials, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
             HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            want = std::max<uint64_t>(*c->h_total, 1);
+            if (prof)
+                for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+            counted = true;
+            want = std::max<uint64_t>(c->h_total[0], 1);
+            c->sized_R = R;
+        } else if (!cap) {
+            want = c->records_cap;
         }
         // ConversionPass.cpp:25-33: (re)allocate when the size differs (grow-only for the unlimited policy)
         if ((cap && c->records_cap != want) || (!cap && c->records_cap < want)) {
@@ -340,30 +414,34 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         d_out = (float4*)c->d_records;
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
-    const uint64_t n_blocks64 = (limit + kEmitF - 1) / kEmitF;
-    const uint32_t n_blocks = (uint32_t)n_blocks64;
-    if (c->start_cap < n_blocks) {
-        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
-        HIPCHK(c, hipMalloc((void**)&c->d_start, std::max<size_t>(n_blocks, 1) * sizeof(uint32_t)));
-        c->start_cap = n_blocks;
+
+    // ---- run ---------------------------------------------------------------------------------------
+    bool done = false;
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !counted) {
+        // single-pass kernel; triangles too large for its in-workgroup budget are only counted
+        HIPCHK(c, hipMemsetAsync(c->d_chain, 0, (size_t)n_fused_waves(sc.n_tri) * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint32_t), st));
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
+        launch_fused(sc, R, c->d_chain, limit, d_out, c->d_total, c->d_status, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&c->h_total[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(&c->h_total[1], c->d_status, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+        if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
+        const uint32_t n_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
+        if (err) return fail(c, M2S_ERR_HIP, "fused kernel: look-back chain timed out");
+        done = (n_big == 0);
     }
-
-    launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
-    launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-    HIPCHK(c, hipGetLastError());
-
-    // glFinish + counter read-back (ConversionPass.cpp:54-59)
-    HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const uint64_t total = *c->h_total;
+    if (!done) {
+        m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
+        if (s != M2S_OK) return s;
+    }
+    const uint64_t total = c->h_total[0];
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, limit);
     c->last_records = d_out;
-    if (prof)
-        for (int k = 0; k < M2S_K_N; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
     if (out_total) *out_total = total;
     return M2S_OK;
 }
@@ -401,7 +479,11 @@ m2s_status m2s_download_triangle_counts(m2s_ctx* c, uint32_t* dst, uint64_t n) {
     if (n < c->scene.n_tri) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer entries than triangles in range");
     if (!c->scene.n_tri) return M2S_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(dst, c->d_cnt, (size_t)c->scene.n_tri * 4, hipMemcpyDeviceToHost));
+    // the fused pipeline keeps counts in registers only: (re)run the counting kernel for the last R
+    launch_count(c->scene, c->last_R, c->d_cnt, c->d_partials, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_cnt, (size_t)c->scene.n_tri * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return M2S_OK;
 }
 
@@ -425,7 +507,14 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
     return M2S_OK;
 }
 
-m2s_status m2s_last_kernel_ms(const m2s_ctx* c, float out_ms[4]) {
+m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
+    if (!c) return M2S_ERR_INVALID;
+    if (pipeline != M2S_PIPELINE_AUTO && pipeline != M2S_PIPELINE_MULTIPASS) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    c->pipeline = pipeline;
+    return M2S_OK;
+}
+
+m2s_status m2s_last_kernel_ms(const m2s_ctx* c, float out_ms[M2S_K_N]) {
     if (!c || !out_ms) return M2S_ERR_INVALID;
     memcpy(out_ms, c->last_ms, sizeof c->last_ms);
     return M2S_OK;

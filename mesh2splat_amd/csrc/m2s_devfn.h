@@ -1,0 +1,626 @@
+// m2s_devfn.h — device functions shared by the conversion kernels (gfx950).  Restates
+// converterGS.glsl:326-443 (geo_setup / geo_flat), the pinned rasteriser (raster_setup / row_span)
+// and converterFS.glsl:44-104 with software trilinear sampling (shade_from_tri).
+#pragma once
+#include "m2s_device.h"
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+// ============================================================================================
+// small helpers
+// ============================================================================================
+__device__ __forceinline__ float len3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving
+    // LDS accesses across the point and drains outstanding LDS traffic.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// exact floor(num/den), den > 0, |num| < 2^52: fp64 quotient + one integer correction step
+__device__ __forceinline__ long long floordiv_pos(long long num, long long den) {
+    long long q = (long long)floor((double)num / (double)den);
+    long long r = num - q * den;
+    if (r < 0) q -= 1;
+    else if (r >= den) q += 1;
+    return q;
+}
+
+// ============================================================================================
+// geometry-shader restatement (converterGS.glsl:326-443)
+// ============================================================================================
+struct Geo {
+    float xx, xy, xz;  // xAxis = normalised longest edge  (GS:345, 401)
+    float nx, ny, nz;  // face normal                      (GS:347)
+    float ou[3], ov[3];  // bbox-normalised orthogonal UVs  (GS:353-399)
+};
+
+__device__ __forceinline__ void geo_setup(const float p[9], const float* __restrict__ bmin,
+                                          const float* __restrict__ bmax, Geo& g) {
+    float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+    float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+    float e3x = p[6] - p[3], e3y = p[7] - p[4], e3z = p[8] - p[5];
+    float l1 = len3(e1x, e1y, e1z), l2 = len3(e2x, e2y, e2z), l3 = len3(e3x, e3y, e3z);
+    // GS:333-342: strict >, else-if; second branch leaves edge2 untouched
+    if (l2 > l1 && l2 > l3) {
+        float tx = e1x, ty = e1y, tz = e1z;
+        e1x = e2x; e1y = e2y; e1z = e2z;
+        e2x = tx; e2y = ty; e2z = tz;
+    } else if (l3 > l1 && l3 > l2) {
+        e1x = e3x; e1y = e3y; e1z = e3z;
+    }
+    float inv = 1.0f / len3(e1x, e1y, e1z);
+    g.xx = e1x * inv; g.xy = e1y * inv; g.xz = e1z * inv;
+    float cx = g.xy * e2z - g.xz * e2y, cy = g.xz * e2x - g.xx * e2z, cz = g.xx * e2y - g.xy * e2x;
+    inv = 1.0f / len3(cx, cy, cz);
+    g.nx = cx * inv; g.ny = cy * inv; g.nz = cz * inv;
+    float ax = fabsf(g.nx), ay = fabsf(g.ny), az = fabsf(g.nz);
+    // GS:360-396: (y,z) | (x,z) | (x,y) with strict compares and fall-through on ties
+    const bool first = (ax > ay) && (ax > az);
+    const bool second = !first && (ay > az);
+    const bool useY_asA = first;             // A = 1 (y) only in the first branch, else 0 (x)
+    const bool useY_asB = !first && !second; // B = 1 (y) only in the third branch, else 2 (z)
+    float bminA = useY_asA ? bmin[1] : bmin[0], bmaxA = useY_asA ? bmax[1] : bmax[0];
+    float bminB = useY_asB ? bmin[1] : bmin[2], bmaxB = useY_asB ? bmax[1] : bmax[2];
+    float range = fmaxf(bmaxA - bminA, bmaxB - bminB);
+    float invRange = 1.0f / range;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float pa = useY_asA ? p[3 * i + 1] : p[3 * i + 0];
+        float pb = useY_asB ? p[3 * i + 1] : p[3 * i + 2];
+        g.ou[i] = (pa - bminA) * invRange;
+        g.ov[i] = (pb - bminB) * invRange;
+    }
+}
+
+// ---- value arithmetic helpers -------------------------------------------------------------------
+// Two classes of arithmetic (DESIGN.md "Pinned semantics"):
+//  * DECISION arithmetic — everything that selects triangles, axes, pixels (geo_setup, raster_setup,
+//    coverage): exact IEEE fp32, one rounding per operation, bit-identical to the CPU oracle.
+//  * VALUE arithmetic — continuous outputs only (Scale, Quaternion magnitude, barycentrics, attribute
+//    interpolation, texture filtering, normal mapping): FMA contraction and the hardware
+//    reciprocal / rsqrt / sqrt / log2 (<= 1 ulp each); agrees with the oracle to ~1e-6 relative,
+//    tolerance 1e-4.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// flat outputs of the GS: Scale (GS:409-430) and Quaternion (GS:401-407, quat_cast GS:131-183)
+__device__ __forceinline__ void geo_flat(const float p[9], const Geo& g, float& sx, float& sy, float4& rot) {
+    // yAxis = normalize(cross(normal, xAxis)): exact, because the quat_cast branch below is a decision
+    float cx = g.ny * g.xz - g.nz * g.xy, cy = g.nz * g.xx - g.nx * g.xz, cz = g.nx * g.xy - g.ny * g.xx;
+    float inv = 1.0f / len3(cx, cy, cz);
+    float yx = cx * inv, yy = cy * inv, yz = cz * inv;
+    // m[c][r]: columns x, y, n
+    const float m00 = g.xx, m01 = g.xy, m02 = g.xz;
+    const float m10 = yx, m11 = yy, m12 = yz;
+    const float m20 = g.nx, m21 = g.ny, m22 = g.nz;
+    float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
+    int bi = 0;
+    float fb = fw;
+    if (fx > fb) { fb = fx; bi = 1; }
+    if (fy > fb) { fb = fy; bi = 2; }
+    if (fz > fb) { fb = fz; bi = 3; }
+    {
+#pragma clang fp contract(fast)
+        const float bv = fast_sqrt(fb + 1.0f) * 0.5f;
+        const float mult = 0.25f * fast_rcp(bv);
+        // off-diagonal sums/differences selected without divergent branches
+        const float d0 = m12 - m21, d1 = m20 - m02, d2 = m01 - m10;
+        const float s0 = m01 + m10, s1 = m20 + m02, s2 = m12 + m21;
+        float qw, qx, qy, qz;
+        if (bi == 0) { qw = bv; qx = d0 * mult; qy = d1 * mult; qz = d2 * mult; }
+        else if (bi == 1) { qw = d0 * mult; qx = bv; qy = s0 * mult; qz = s1 * mult; }
+        else if (bi == 2) { qw = d1 * mult; qx = s0 * mult; qy = bv; qz = s2 * mult; }
+        else { qw = d2 * mult; qx = s1 * mult; qy = s2 * mult; qz = bv; }
+        rot = make_float4(qw, qx, qy, qz);  // GS:407 stores (w,x,y,z)
+        // Jacobian: UVMatrix[col][row], inverse2x2 (GS:206-220), multiplyMat2x3WithMat2x2 (GS:222-235)
+        const float U00 = g.ou[1] - g.ou[0], U10 = g.ou[2] - g.ou[0];
+        const float U01 = g.ov[1] - g.ov[0], U11 = g.ov[2] - g.ov[0];
+        const float det = U00 * U11 - U01 * U10;
+        const float invDet = det != 0.0f ? fast_rcp(det) : 0.0f;   // inverse2x2 returns mat2(0) for det == 0
+        const float I00 = U11 * invDet, I10 = -U10 * invDet, I01 = -U01 * invDet, I11 = U00 * invDet;
+        const float v0x = p[3] - p[0], v0y = p[4] - p[1], v0z = p[5] - p[2];
+        const float v1x = p[6] - p[0], v1y = p[7] - p[1], v1z = p[8] - p[2];
+        const float jux = v0x * I00 + v1x * I01, juy = v0y * I00 + v1y * I01, juz = v0z * I00 + v1z * I01;
+        const float jvx = v0x * I10 + v1x * I11, jvy = v0y * I10 + v1y * I11, jvz = v0z * I10 + v1z * I11;
+        sx = fast_sqrt(jux * jux + juy * juy + juz * juz);
+        sy = fast_sqrt(jvx * jvx + jvy * jvy + jvz * jvz);
+    }
+}
+
+// ============================================================================================
+// pinned rasteriser: viewport transform, 24.8 snap (RNE), int64 edge functions, top-left rule
+// ============================================================================================
+struct Raster {
+    int a[3], b[3];      // E_i(Px,Py) = a*Px + b*Py + c, interior positive; edge i opposite vertex i
+    long long c[3];
+    long long area2;
+    int bias;            // bit i: boundary of edge i is inside
+    int x0, x1, y0, y1;  // inclusive pixel bbox, clamped to the viewport
+    int ext;             // max sub-pixel extent of the (unclamped) triangle bbox
+};
+
+constexpr float kGuardPx = 16384.0f;
+
+__device__ __forceinline__ bool raster_setup(const Geo& g, uint32_t R, Raster& s) {
+    const float half = (float)R * 0.5f;
+    int X[3], Y[3];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float ndx = g.ou[i] * 2.0f - 1.0f, ndy = g.ov[i] * 2.0f - 1.0f;  // GS:439
+        float xw = half * ndx + half, yw = half * ndy + half;            // glViewport(0,0,R,R)
+        ok = ok && (fabsf(xw) < kGuardPx) && (fabsf(yw) < kGuardPx);     // false for NaN
+        X[i] = (int)rintf(xw * 256.0f);
+        Y[i] = (int)rintf(yw * 256.0f);
+    }
+    if (!ok) return false;
+    long long area2 = (long long)(X[1] - X[0]) * (Y[2] - Y[0]) - (long long)(Y[1] - Y[0]) * (X[2] - X[0]);
+    if (area2 == 0) return false;
+    const int sgn = area2 < 0 ? -1 : 1;  // no culling (ConversionPass.cpp:48)
+    s.area2 = area2 < 0 ? -area2 : area2;
+    s.bias = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int ia = (i + 1) % 3, ib = (i + 2) % 3;
+        int dy = Y[ib] - Y[ia], dx = X[ib] - X[ia];
+        s.a[i] = -dy * sgn;
+        s.b[i] = dx * sgn;
+        s.c[i] = ((long long)dy * X[ia] - (long long)dx * Y[ia]) * sgn;
+        if (s.a[i] > 0 || (s.a[i] == 0 && s.b[i] > 0)) s.bias |= 1 << i;
+    }
+    int xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
+    int ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+    s.ext = max(xmax - xmin, ymax - ymin);
+    s.x0 = max((xmin - 128 + 255) >> 8, 0);
+    s.x1 = min((xmax - 128) >> 8, (int)R - 1);
+    s.y0 = max((ymin - 128 + 255) >> 8, 0);
+    s.y1 = min((ymax - 128) >> 8, (int)R - 1);
+    return s.x0 <= s.x1 && s.y0 <= s.y1;
+}
+
+// covered pixels of row y form one interval [xa, xb] (empty if xa > xb): exact closed form
+__device__ __forceinline__ void row_span(const Raster& s, int y, int& xa, int& xb) {
+    const long long Py = 256ll * y + 128;
+    long long lo = s.x0, hi = s.x1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const long long alpha = 256ll * s.a[i];
+        // pixel x is inside edge i  <=>  alpha*x + beta >= 1   (E > 0, or E >= 0 on an owned boundary)
+        const long long beta = 128ll * s.a[i] + (long long)s.b[i] * Py + s.c[i] + ((s.bias >> i) & 1);
+        if (alpha > 0) {
+            long long q = floordiv_pos(alpha - beta, alpha);  // ceil((1-beta)/alpha)
+            lo = q > lo ? q : lo;
+        } else if (alpha < 0) {
+            long long q = floordiv_pos(beta - 1, -alpha);
+            hi = q < hi ? q : hi;
+        } else if (beta < 1) {
+            hi = lo - 1;
+        }
+    }
+    if (hi < lo) { xa = 0; xb = -1; }
+    else { xa = (int)lo; xb = (int)hi; }
+}
+
+__device__ __forceinline__ Raster shfl_raster(const Raster& s, int src) {
+    Raster r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        r.a[i] = __shfl(s.a[i], src);
+        r.b[i] = __shfl(s.b[i], src);
+        r.c[i] = __shfl(s.c[i], src);
+    }
+    r.area2 = 0;
+    r.bias = __shfl(s.bias, src);
+    r.ext = 0;
+    r.x0 = __shfl(s.x0, src); r.x1 = __shfl(s.x1, src);
+    r.y0 = __shfl(s.y0, src); r.y1 = __shfl(s.y1, src);
+    return r;
+}
+
+// ============================================================================================
+// scene access
+// ============================================================================================
+__device__ __forceinline__ void load_positions(const TriPlanes& tp, uint32_t t, float p[9]) {
+    float4 a0 = tp.A0[t], a1 = tp.A1[t];
+    float a2 = tp.A2[t];
+    p[0] = a0.x; p[1] = a0.y; p[2] = a0.z; p[3] = a0.w;
+    p[4] = a1.x; p[5] = a1.y; p[6] = a1.z; p[7] = a1.w;
+    p[8] = a2;
+}
+
+// mesh of GLOBAL triangle gt: last m with mesh_first[m] <= gt
+__device__ __forceinline__ uint32_t find_mesh(const SceneDev& sc, uint32_t gt) {
+    uint32_t lo = 0, hi = sc.n_meshes;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sc.mesh_first[mid] <= gt) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool setup_raster_for(const SceneDev& sc, uint32_t t, uint32_t mesh_hint, bool uniform_mesh,
+                                                 uint32_t R, Raster& rs) {
+    float p[9];
+    load_positions(sc.tri, t, p);
+    uint32_t m = uniform_mesh ? mesh_hint : find_mesh(sc, sc.tri_first + t);
+    const MeshParams* mp = sc.meshes + m;
+    Geo g;
+    geo_setup(p, mp->bmin, mp->bmax, g);
+    return raster_setup(g, R, rs);
+}
+
+// ============================================================================================
+// fragment-shader restatement (converterFS.glsl:44-104) with software trilinear sampling
+// (sampler state glUtils.cpp:292-313: REPEAT, LINEAR_MIPMAP_LINEAR / LINEAR, levels 0..4).
+// VALUE arithmetic throughout (see geo_flat).
+// ============================================================================================
+constexpr float kUnorm8 = 0.003921568859368563f;  // fp32 nearest to 1/255
+
+// Per-triangle constants of the fragment stage: computed once per triangle (fused kernel: in the
+// triangle phase, kept in LDS; multi-pass emit: recomputed per fragment).  64 bytes = four float4.
+struct TriShade {
+    int a1, b1, a2, b2;      // edge functions opposite vertex 1 / 2 ...
+    long long e1, e2;        // ... and their exact values at the bbox origin pixel (x0,y0)
+    float inva, sx, sy, lod0;  // 1/area2 (IEEE), Scale.xy (GS:423-430), LOD lambda of map 0
+    float4 rot;              // Quaternion (w,x,y,z)
+    float lod1, lod2;        // LOD lambda of maps 1, 2 (constant per triangle: UV is affine in the window)
+    uint32_t org;            // y0 << 12 | x0
+    uint32_t mesh;           // mesh index (read by waves that straddle a mesh boundary)
+};
+static_assert(sizeof(TriShade) == 80, "TriShade must be five float4");
+
+__device__ __forceinline__ float lod_from_grad(float fw, float fh, float dudx, float dvdx, float dudy, float dvdy) {
+#pragma clang fp contract(fast)
+    const float sx = dudx * fw, tx = dvdx * fh, sy = dudy * fw, ty = dvdy * fh;
+    const float r2 = fmaxf(sx * sx + tx * tx, sy * sy + ty * ty);
+    return 0.5f * fast_log2(r2);   // log2(sqrt(r2))
+}
+
+// p: positions; b0/b1: uv planes of the triangle.  Needs a valid Raster.
+__device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, const MeshParams* __restrict__ mp,
+                                                float4 b0, float2 b1, TriShade& ts) {
+#pragma clang fp contract(fast)
+    // The barycentrics feed the texture coordinates, where any rounding difference is amplified by the
+    // texture size and contrast: they follow the oracle's exact operation sequence
+    // lambda_i = float(E_i) * (1 / float(area2)) with exact integer E_i (DECISION-class arithmetic).
+    {
+#pragma clang fp contract(off)
+        ts.inva = 1.0f / (float)rs.area2;
+    }
+    const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+    ts.a1 = rs.a[1]; ts.b1 = rs.b[1]; ts.a2 = rs.a[2]; ts.b2 = rs.b[2];
+    ts.e1 = (long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1];
+    ts.e2 = (long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2];
+    ts.org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;
+    ts.mesh = 0;
+    const float A1 = (float)rs.a[1] * 256.0f * ts.inva, B1 = (float)rs.b[1] * 256.0f * ts.inva;
+    const float A2 = (float)rs.a[2] * 256.0f * ts.inva, B2 = (float)rs.b[2] * 256.0f * ts.inva;
+    geo_flat(p, g, ts.sx, ts.sy, ts.rot);
+    ts.lod0 = ts.lod1 = ts.lod2 = 0.0f;
+    const TexDesc* __restrict__ ta = &mp->tex[0];
+    const TexDesc* __restrict__ tn = &mp->tex[1];
+    const TexDesc* __restrict__ tm = &mp->tex[2];
+    const bool hasA = ta->texels != nullptr, hasN = tn->texels != nullptr, hasM = tm->texels != nullptr;
+    if (hasA || hasN || hasM) {
+        // UV is affine in window space (all w = 1, GS:439): d(lambda_i)/dx = A_i, d/dy = B_i per pixel
+        const float du1 = b0.z - b0.x, du2 = b1.x - b0.x, dv1 = b0.w - b0.y, dv2 = b1.y - b0.y;
+        const float dudx = A1 * du1 + A2 * du2, dvdx = A1 * dv1 + A2 * dv2;
+        const float dudy = B1 * du1 + B2 * du2, dvdy = B1 * dv1 + B2 * dv2;
+        if (hasA) ts.lod0 = lod_from_grad((float)ta->w, (float)ta->h, dudx, dvdx, dudy, dvdy);
+        if (hasN) ts.lod1 = (hasA && tn->w == ta->w && tn->h == ta->h) ? ts.lod0
+                          : lod_from_grad((float)tn->w, (float)tn->h, dudx, dvdx, dudy, dvdy);
+        if (hasM) ts.lod2 = (hasA && tm->w == ta->w && tm->h == ta->h) ? ts.lod0
+                          : (hasN && tm->w == tn->w && tm->h == tn->h) ? ts.lod1
+                          : lod_from_grad((float)tm->w, (float)tm->h, dudx, dvdx, dudy, dvdy);
+    }
+}
+
+// Texel addresses (in texels from the start of the mip chain) and bilinear weights of one level.
+struct TexTap {
+    uint32_t o00, o10, o01, o11;
+    float w00, w10, w01, w11;
+};
+
+// uf, vf in [0,1] (REPEAT already applied).  W,H,level_off describe the level.
+__device__ __forceinline__ void tex_tap(uint32_t W, uint32_t H, uint32_t level_off, float uf, float vf, TexTap& t) {
+    float up, vp;
+    {   // texel coordinates and fractional weights: exact oracle sequence (no FMA)
+#pragma clang fp contract(off)
+        up = uf * (float)W - 0.5f;
+        vp = vf * (float)H - 0.5f;
+    }
+    const float fi = floorf(up), fj = floorf(vp);
+    const float a = up - fi, b = vp - fj;
+    int i0 = (int)fi, j0 = (int)fj;  // in [-1, W-1]
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = i0 < 0 ? i0 + (int)W : i0;
+    j0 = j0 < 0 ? j0 + (int)H : j0;
+    i1 = i1 >= (int)W ? i1 - (int)W : i1;
+    j1 = j1 >= (int)H ? j1 - (int)H : j1;
+    const uint32_t r0 = level_off + (uint32_t)j0 * W, r1 = level_off + (uint32_t)j1 * W;
+    t.o00 = r0 + (uint32_t)i0; t.o10 = r0 + (uint32_t)i1;
+    t.o01 = r1 + (uint32_t)i0; t.o11 = r1 + (uint32_t)i1;
+    const float na = 1.0f - a, nb = 1.0f - b;
+    t.w00 = na * nb; t.w10 = a * nb; t.w01 = na * b; t.w11 = a * b;
+}
+
+// The LOD-dependent sampling state shared by every map of the same size: one or two levels.
+struct TexState {
+    TexTap lo, hi;
+    float f;     // weight of `hi` (0 = single level)
+};
+
+__device__ __forceinline__ void tex_state(const TexDesc* __restrict__ t, float uf, float vf, float lambda, TexState& st) {
+    const uint32_t nl = t->n_levels, w = t->w, h = t->h;
+    const float q = (float)(nl - 1);
+    float d = 0.0f, f = 0.0f;
+    if (lambda > 0.0f) {   // false for NaN: magnification
+        if (lambda >= q) d = q;
+        else { d = floorf(lambda); f = lambda - d; }
+    }
+    const uint32_t l0 = (uint32_t)d, l1 = min(l0 + 1u, nl - 1u);
+    // level offsets are wave-uniform scalars; pick per lane
+    const uint32_t o1 = t->off[1], o2 = t->off[2], o3 = t->off[3], o4 = t->off[4];
+    const uint32_t off0 = l0 == 0 ? 0u : l0 == 1 ? o1 : l0 == 2 ? o2 : l0 == 3 ? o3 : o4;
+    const uint32_t off1 = l1 == 0 ? 0u : l1 == 1 ? o1 : l1 == 2 ? o2 : l1 == 3 ? o3 : o4;
+    tex_tap(max(1u, w >> l0), max(1u, h >> l0), off0, uf, vf, st.lo);
+    st.f = f;
+    if (__ballot(f != 0.0f) != 0ull) tex_tap(max(1u, w >> l1), max(1u, h >> l1), off1, uf, vf, st.hi);
+    else st.hi = st.lo;
+}
+
+template <int NCH>  // number of leading channels wanted (RGBA byte order)
+__device__ __forceinline__ void tap_fetch(const uint32_t* __restrict__ texels, const TexTap& t, float out[NCH]) {
+#pragma clang fp contract(fast)
+    const uint32_t t00 = texels[t.o00], t10 = texels[t.o10], t01 = texels[t.o01], t11 = texels[t.o11];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const float c00 = (float)((t00 >> (8 * ch)) & 255u), c10 = (float)((t10 >> (8 * ch)) & 255u);
+        const float c01 = (float)((t01 >> (8 * ch)) & 255u), c11 = (float)((t11 >> (8 * ch)) & 255u);
+        out[ch] = t.w00 * c00 + t.w10 * c10 + t.w01 * c01 + t.w11 * c11;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, const TexState& st, float out[NCH]) {
+#pragma clang fp contract(fast)
+    float lo[NCH];
+    tap_fetch<NCH>(texels, st.lo, lo);
+    if (__ballot(st.f != 0.0f) != 0ull) {
+        float hi[NCH];
+        tap_fetch<NCH>(texels, st.hi, hi);
+        const float f = st.f, nf = 1.0f - st.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) out[ch] = (nf * lo[ch] + f * hi[ch]) * kUnorm8;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) out[ch] = lo[ch] * kUnorm8;
+    }
+}
+
+// ---- combo path -----------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) ComboPair { uint32_t v[6]; };  // {A,N,M} of texel i and of texel i+1
+
+// un-normalised bilinear sums of one level for the nine channels we need:
+// albedo rgba (0-3), normal rgb (4-6), roughness = MR.g (7), metallic = MR.b (8)
+__device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, uint32_t W, uint32_t H, float uf, float vf, float out[9]) {
+#pragma clang fp contract(fast)
+    float up, vp;
+    {   // exact oracle sequence (no FMA), as in tex_tap
+#pragma clang fp contract(off)
+        up = uf * (float)W - 0.5f;
+        vp = vf * (float)H - 0.5f;
+    }
+    const float fi = floorf(up), fj = floorf(vp);
+    const float a = up - fi, b = vp - fj;
+    int i0 = (int)fi, j0 = (int)fj;  // in [-1, W-1]
+    int j1 = j0 + 1;
+    i0 = i0 < 0 ? i0 + (int)W : i0;  // i0 == W-1 reads the wrapped extra column as its right neighbour
+    j0 = j0 < 0 ? j0 + (int)H : j0;
+    j1 = j1 >= (int)H ? j1 - (int)H : j1;
+    const uint32_t stride = W + 1;
+    const ComboPair r0 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u);
+    const ComboPair r1 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u);
+    const float na = 1.0f - a, nb = 1.0f - b;
+    const float w00 = na * nb, w10 = a * nb, w01 = na * b, w11 = a * b;
+#define M2S_CH(word, sh) (w00 * (float)((r0.v[word] >> (sh)) & 255u) + w10 * (float)((r0.v[(word) + 3] >> (sh)) & 255u) + \
+                          w01 * (float)((r1.v[word] >> (sh)) & 255u) + w11 * (float)((r1.v[(word) + 3] >> (sh)) & 255u))
+    out[0] = M2S_CH(0, 0); out[1] = M2S_CH(0, 8); out[2] = M2S_CH(0, 16); out[3] = M2S_CH(0, 24);
+    out[4] = M2S_CH(1, 0); out[5] = M2S_CH(1, 8); out[6] = M2S_CH(1, 16);
+    out[7] = M2S_CH(2, 8); out[8] = M2S_CH(2, 16);
+#undef M2S_CH
+}
+
+__device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, const TexDesc* __restrict__ t, float uf, float vf,
+                                             float lambda, float out[9]) {
+#pragma clang fp contract(fast)
+    const uint32_t nl = t->n_levels, w = t->w, h = t->h;
+    const float q = (float)(nl - 1);
+    float d = 0.0f, f = 0.0f;
+    if (lambda > 0.0f) {   // false for NaN: magnification
+        if (lambda >= q) d = q;
+        else { d = floorf(lambda); f = lambda - d; }
+    }
+    const uint32_t l0 = (uint32_t)d, l1 = min(l0 + 1u, nl - 1u);
+    const uint32_t c1 = mp->combo.coff[1], c2 = mp->combo.coff[2], c3 = mp->combo.coff[3], c4 = mp->combo.coff[4];
+    const uint32_t off0 = l0 == 0 ? 0u : l0 == 1 ? c1 : l0 == 2 ? c2 : l0 == 3 ? c3 : c4;
+    const uint32_t off1 = l1 == 0 ? 0u : l1 == 1 ? c1 : l1 == 2 ? c2 : l1 == 3 ? c3 : c4;
+    const uint32_t* __restrict__ base = mp->combo.texels;
+    float lo[9];
+    combo_level(base + off0, max(1u, w >> l0), max(1u, h >> l0), uf, vf, lo);
+    if (__ballot(f != 0.0f) != 0ull) {
+        float hi[9];
+        combo_level(base + off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, hi);
+        const float nf = 1.0f - f;
+#pragma unroll
+        for (int ch = 0; ch < 9; ch++) out[ch] = (nf * lo[ch] + f * hi[ch]) * kUnorm8;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] * kUnorm8;
+    }
+}
+
+__device__ __forceinline__ float frac_repeat(float u) {
+    float f = u - floorf(u);
+    f = (f >= 0.0f) ? f : 0.0f;   // NaN -> 0
+    return fminf(f, 1.0f);
+}
+
+template <typename T>
+__device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
+    // 32-bit byte offset from a wave-uniform base: lets the backend use the saddr + voffset form
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(t * (uint32_t)sizeof(T)));
+}
+
+// The per-fragment part of rasteriser + FS (converterFS.glsl:44-104) for pixel (x,y) of triangle t.
+// `mp` should be wave-uniform (scalar) for speed; correctness does not depend on it.
+__device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, const MeshParams* __restrict__ mp,
+                                               const TriShade& ts, float4 rec[6]) {
+#pragma clang fp contract(fast)
+    // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
+    // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
+    const int dx256 = (x - (int)(ts.org & 0xFFFu)) * 256, dy256 = (y - (int)(ts.org >> 12)) * 256;
+    const long long E1 = ts.e1 + (long long)ts.a1 * dx256 + (long long)ts.b1 * dy256;
+    const long long E2 = ts.e2 + (long long)ts.a2 * dx256 + (long long)ts.b2 * dy256;
+    float l1, l2;
+    {
+#pragma clang fp contract(off)
+        l1 = (float)E1 * ts.inva;
+        l2 = (float)E2 * ts.inva;
+    }
+
+    // smooth varyings (converterGS.glsl:432-441): Position, Normal, Tangent, UV
+#ifdef M2S_SKIP_ATTR
+    const float4 a0 = make_float4(ts.inva, 1, 2, 3), a1 = a0, b0 = make_float4(0.1f, 0.2f, 0.3f, ts.inva), c0 = a0, c1 = a0, d0 = a0, d1 = a0, d2 = a0;
+    const float a2 = 1, c2 = 2; const float2 b1 = make_float2(0.5f, 0.7f);
+#else
+    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
+    const float a2 = ld_plane(tp.A2, t);
+    const float4 b0 = ld_plane(tp.B0, t);
+    const float2 b1 = ld_plane(tp.B1, t);
+    const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
+    const float c2 = ld_plane(tp.C2, t);
+    const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
+#endif
+#define M2S_LERP(f0, f1, f2) ((f0) + l1 * ((f1) - (f0)) + l2 * ((f2) - (f0)))
+    const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
+    const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
+    float U, V;
+    {   // texture coordinates: exact oracle sequence (no FMA), see tri_shade_setup
+#pragma clang fp contract(off)
+        U = (b0.x + l1 * (b0.z - b0.x)) + l2 * (b1.x - b0.x);
+        V = (b0.y + l1 * (b0.w - b0.y)) + l2 * (b1.y - b0.y);
+    }
+
+    const TexDesc* __restrict__ ta = &mp->tex[0];
+    const TexDesc* __restrict__ tn = &mp->tex[1];
+    const TexDesc* __restrict__ tm = &mp->tex[2];
+    const uint32_t* xa = ta->texels;   // (non-const only for the debug ablation switch below)
+    const uint32_t* xn = tn->texels;
+    const uint32_t* xm = tm->texels;
+    // the tangent is only consumed by the normal-map branch; interpolate it now so that the twelve
+    // raw tangent registers die here instead of living across the albedo fetch
+    float Tx = 0.0f, Ty = 0.0f, Tz = 0.0f, Tw = 0.0f;
+    if (xn != nullptr) {
+        Tx = M2S_LERP(d0.x, d1.x, d2.x); Ty = M2S_LERP(d0.y, d1.y, d2.y); Tz = M2S_LERP(d0.z, d1.z, d2.z);
+        Tw = M2S_LERP(d0.w, d1.w, d2.w);
+    }
+    const float uf = frac_repeat(U), vf = frac_repeat(V);
+    float col[4] = { 1.0f, 1.0f, 1.0f, 1.0f };   // FS:53-62
+    float nrm[3] = { 0.0f, 0.0f, 1.0f };
+    float metal = 0.1f, rough = 0.5f;            // FS:87-95 defaults
+    const uint32_t* __restrict__ cmb = mp->combo.texels;
+#ifdef M2S_SKIP_TEX
+    cmb = nullptr; xa = nullptr; xn = nullptr; xm = nullptr;
+#endif
+    if (cmb != nullptr) {
+        // all three maps, same size: one LOD state, interleaved texels, 2 x 24-byte row reads per level
+        float acc[9];
+        combo_sample(mp, ta, uf, vf, ts.lod0, acc);
+        col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2]; col[3] = acc[3];
+        nrm[0] = acc[4]; nrm[1] = acc[5]; nrm[2] = acc[6];
+        rough = acc[7]; metal = acc[8];
+    } else {
+        TexState st;
+        if (xa != nullptr) {
+            tex_state(ta, uf, vf, ts.lod0, st);
+            tex_sample<4>(xa, st, col);
+        }
+        if (xn != nullptr) {
+            if (!(xa != nullptr && tn->w == ta->w && tn->h == ta->h)) tex_state(tn, uf, vf, ts.lod1, st);
+            tex_sample<3>(xn, st, nrm);
+        }
+        if (xm != nullptr) {
+            const bool sameA = xa != nullptr && tm->w == ta->w && tm->h == ta->h;
+            const bool sameN = xn != nullptr && tm->w == tn->w && tm->h == tn->h;
+            // `st` currently describes the normal map if present (possibly shared with albedo), else albedo
+            const bool reuse = (xn != nullptr) ? (sameN) : sameA;
+            if (!reuse) tex_state(tm, uf, vf, ts.lod2, st);
+            float s[3];
+            tex_sample<3>(xm, st, s);
+            metal = s[2]; rough = s[1];
+        }
+    }
+    // FS:66-81
+    float ox = Nx, oy = Ny, oz = Nz;
+    if (xn != nullptr) {
+        float rx = nrm[0] * 2.0f - 1.0f, ry = nrm[1] * 2.0f - 1.0f, rz = nrm[2] * 2.0f - 1.0f;
+        float inv = fast_rsq(rx * rx + ry * ry + rz * rz);
+        rx *= inv; ry *= inv; rz *= inv;
+        float bx = Ny * Tz - Nz * Ty, by = Nz * Tx - Nx * Tz, bz = Nx * Ty - Ny * Tx;  // cross(Normal, Tangent.xyz)
+        inv = fast_rsq(bx * bx + by * by + bz * bz) * Tw;
+        bx *= inv; by *= inv; bz *= inv;
+        inv = fast_rsq(Nx * Nx + Ny * Ny + Nz * Nz);
+        const float nnx = Nx * inv, nny = Ny * inv, nnz = Nz * inv;
+        const float wx = Tx * rx + bx * ry + nnx * rz, wy = Ty * rx + by * ry + nny * rz, wz = Tz * rx + bz * ry + nnz * rz;
+        inv = fast_rsq(wx * wx + wy * wy + wz * wz);
+        ox = wx * inv; oy = wy * inv; oz = wz * inv;
+    }
+#undef M2S_LERP
+    // FS:98-103
+    rec[0] = make_float4(Pxw, Pyw, Pzw, 1.0f);
+    rec[1] = make_float4(col[0] * mp->color[0], col[1] * mp->color[1], col[2] * mp->color[2], col[3] * mp->color[3]);
+    rec[2] = make_float4(ts.sx, ts.sy, 1e-7f, 0.0f);
+    rec[3] = make_float4(ox, oy, oz, 0.0f);
+    rec[4] = ts.rot;
+    rec[5] = make_float4(metal, rough, 0.0f, 1.0f);
+}
+
+// Everything the GS + rasteriser + FS produce for ONE fragment (multi-pass emit: per-triangle part recomputed).
+__device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, int x, int y, uint32_t mesh_hint,
+                                               bool uniform_mesh, uint32_t R, float4 rec[6]) {
+    const TriPlanes& tp = sc.tri;
+    float p[9];
+    load_positions(tp, t, p);
+    const uint32_t m = uniform_mesh ? mesh_hint : find_mesh(sc, sc.tri_first + t);
+    const MeshParams* __restrict__ mp = sc.meshes + m;
+    Geo g;
+    geo_setup(p, mp->bmin, mp->bmax, g);
+    Raster rs;
+    raster_setup(g, R, rs);
+    TriShade ts;
+    tri_shade_setup(p, g, rs, mp, tp.B0[t], tp.B1[t], ts);
+    shade_from_tri(tp, t, x, y, mp, ts, rec);
+}
+
+}  // namespace m2s

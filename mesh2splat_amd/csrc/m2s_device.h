@@ -36,11 +36,22 @@ struct TexDesc {
 };
 
 // per-mesh "uniforms" (ConversionPass.cpp:77-112)
+// "Combo" texture: when the three maps of a material exist and have identical dimensions their texels
+// are interleaved — texel (i,j) of level l is the 12-byte triple {albedo, normal, metallic-roughness}
+// at combo + coff[l] + (j*(W_l+1) + i)*3 dwords, and every row carries one extra wrapped texel
+// (column W_l == column 0).  A bilinear footprint of ALL THREE maps is then two contiguous 24-byte
+// row reads instead of twelve scattered 4-byte gathers.
+struct ComboDesc {
+    const uint32_t* texels;  // nullptr = not available (fallback: the separate maps)
+    uint32_t coff[5];        // level offsets in dwords
+};
+
 struct MeshParams {
     float bmin[3];
     float bmax[3];
     float color[4];
     TexDesc tex[3];
+    ComboDesc combo;
 };
 
 struct SceneDev {
@@ -57,6 +68,8 @@ void launch_repack(const float* d_aos, uint32_t stride_floats, uint32_t n_tri_sr
                    uint32_t n, uint32_t dst_first, TriPlanes dst /*non-const view*/, hipStream_t st);
 void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh,
                       hipStream_t st);
+void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m, uint32_t w, uint32_t h, uint32_t* dst,
+                        hipStream_t st);
 void launch_count(const SceneDev& sc, uint32_t R, uint32_t* cnt, uint32_t* partials, hipStream_t st);
 void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long long* total, hipStream_t st);
 void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
@@ -64,6 +77,11 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
 
+void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
+                  unsigned long long* total, uint32_t* status /* [0]=n_big [1]=error */, hipStream_t st);
+
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
+inline uint32_t n_fused_blocks(uint32_t n_tri) { return (n_tri + kBlock - 1) / kBlock; }
+inline uint32_t n_fused_waves(uint32_t n_tri) { return (n_tri + 63) / 64; }
 
 }  // namespace m2s

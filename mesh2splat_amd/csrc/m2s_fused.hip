@@ -1,0 +1,386 @@
+// m2s_fused.hip — single-pass conversion kernel (gfx950).
+//
+// One launch does what the reference's VS+GS+rasteriser+FS draw does (converterGS.glsl:326-443,
+// converterFS.glsl:44-104, ConversionPass.cpp:114-116) for triangles whose fragments fit the
+// in-workgroup budget:
+//
+//   triangle phase  (1 thread / triangle, 256 triangles / workgroup)
+//       coalesced 36 B position load -> GS setup -> exact coverage:
+//         * bbox <= 8x8 px : 64-bit coverage mask from incremental int32 edge functions
+//         * <= 32 rows     : closed-form row spans
+//         * larger         : counted wave-cooperatively, emission deferred ("big" triangles)
+//       per-triangle fragment constants (edge functions, 1/area, Scale, Quaternion, LODs) -> LDS
+//   ordering        workgroup scan of the counts + decoupled look-back over a chain of 64-bit
+//                   {flag,value} words: the workgroup learns the index of its first record in the
+//                   global, canonically ordered output WITHOUT a second pass and without atomics
+//                   on a shared cursor (the reference: one atomicCounterIncrement per fragment,
+//                   converterFS.glsl:46).
+//   fragment phase  (1 thread / Gaussian) expansion masks/spans -> LDS entry list, shading from the
+//                   LDS triangle record, records staged per wave in LDS and written as contiguous
+//                   6 KiB runs with 16 B/lane stores.
+//
+// Inter-workgroup protocol (MI355X_MICROARCH.md "R2 granule"): each chain word is written by ONE
+// relaxed agent-scope 8-byte atomic store and read by relaxed agent-scope 8-byte atomic loads; the
+// word carries both the flag and the payload, so no fence is needed.  Workgroup b only ever waits for
+// workgroups < b (hardware dispatches a grid in increasing workgroup order per XCD); every spin is
+// bounded and sets an error flag instead of hanging.
+#include "m2s_devfn.h"
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+constexpr uint32_t kBigCount = 2048;       // triangles with more fragments are deferred
+constexpr uint32_t kSpinLimit = 1u << 22;  // look-back polls before giving up (~ seconds)
+
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPrefix = 2ull << 62, kValMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned long long chain_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+enum : int { kNone = 0, kSmall = 1, kMedium = 2, kBig = 3 };
+
+// Rare path, deliberately NOT inlined: its closed-form span code (fp64 divisions) would otherwise add ~30
+// VGPRs of pressure to the fragment loop of every wave.  Re-derives the raster setup from global memory.
+__device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, const float* A2, const MeshParams* mp,
+                                           uint32_t t, uint32_t R, uint32_t lane, uint32_t cto, uint32_t win, uint32_t wend,
+                                           uint32_t* entries) {
+    const float4 a0 = A0[t], a1 = A1[t];
+    const float p[9] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, A2[t] };
+    Geo g;
+    geo_setup(p, mp->bmin, mp->bmax, g);
+    Raster r2;
+    if (!raster_setup(g, R, r2)) return;
+    uint32_t ci = cto;
+    for (int y = r2.y0; y <= r2.y1 && ci < wend; ++y) {
+        int xa, xb;
+        row_span(r2, y, xa, xb);
+        for (int x = xa; x <= xb; ++x, ++ci)
+            if (ci >= win && ci < wend) entries[ci - win] = (lane << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+    }
+}
+
+// Decoupled look-back: sum of the totals of all waves before `wid`.  256 chain words per poll (lane l
+// inspects predecessors wid-1-4l .. wid-4-4l, nearest first).  Not inlined: runs once per wave.
+__device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t* status) {
+    unsigned long long base = 0;
+    long long idx = (long long)wid - 1 - 4 * lane;
+    uint32_t spins = 0;
+    for (;;) {
+        unsigned long long part = 0;   // sum of this lane's entries up to and including its first prefix
+        bool has_prefix = false, invalid = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long ij = idx - j;
+            const unsigned long long v = ij >= 0 ? chain_load(&chain[ij]) : kFlagPrefix;
+            const unsigned flag = (unsigned)(v >> 62);
+            if (!has_prefix) {
+                if (flag == 0) invalid = true;
+                part += v & kValMask;
+                has_prefix = (flag == 2);
+            }
+        }
+        const unsigned long long pm = __ballot(has_prefix), im = __ballot(invalid);
+        if (pm) {
+            const int pl = __ffsll((long long)pm) - 1;  // lane holding the nearest inclusive prefix
+            if ((im & ((2ull << pl) - 1ull)) == 0) {     // every nearer entry is published
+                base += wave_sum64(lane <= pl ? part : 0ull);
+                break;
+            }
+        } else if (im == 0) {  // 256 aggregates: take them all and look further back
+            base += wave_sum64(part);
+            idx -= 256;
+            continue;
+        }
+        if (++spins > kSpinLimit) {
+            if (lane == 0) atomicExch(&status[1], 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+           __builtin_amdgcn_readfirstlane((uint32_t)base);
+}
+
+#ifdef M2S_TIMING
+// debug build only: per-wave phase timestamps (s_memtime), read back by tools/fused_timing.py
+constexpr int kTimingSlots = 12, kTimingWaves = 16384;
+__device__ unsigned long long g_timing[kTimingSlots * kTimingWaves];
+#define M2S_STAMP(i) do { if (lane == 0 && wid < kTimingWaves) g_timing[(i) * kTimingWaves + wid] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define M2S_STAMP(i) do {} while (0)
+#endif
+
+constexpr int kWaveEntryCap = 192;  // per-wave LDS entry-list window (fragments)
+
+// Everything one wave needs in LDS: exactly 10 KiB -> 40 KiB per 256-thread workgroup, 4 workgroups per CU.
+struct WaveLds {
+    float4 tri[64 * 5];                 // TriShade of the wave's 64 triangles
+    uint32_t tskip[64];                 // fragments of deferred (big) triangles preceding each triangle
+    uint4 park[64];                     // per-triangle expansion state {mask.lo, mask.hi, ctoff | cnt<<18 | kind<<30, origin
+                                        // pixel}: parked here so it is not live in VGPRs during the fragment loop
+    uint32_t entries[kWaveEntryCap];    // slot<<24 | y<<12 | x
+    float4 stage[32 * 6];               // half-wave record staging
+};
+
+// Each WAVE owns 64 consecutive triangles from load to store; waves never synchronise with each
+// other inside the workgroup (no __syncthreads), so a stalled wave never holds back its neighbours.
+#ifndef M2S_FUSED_WAVES
+#define M2S_FUSED_WAVES 3
+#endif
+__global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+                                                  unsigned long long limit, float4* __restrict__ out,
+                                                  unsigned long long* __restrict__ total_out,
+                                                  uint32_t* __restrict__ status /* [0]=n_big, [1]=error */) {
+    __shared__ WaveLds lds_all[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    WaveLds& L = lds_all[threadIdx.x >> 6];
+    // global wave id == chain index (made scalar explicitly: the compiler cannot prove threadIdx.x>>6 uniform)
+    const uint32_t wid = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = (sc.n_tri + 63u) / 64u;
+    if (wid >= n_waves) return;
+    const uint32_t t0 = wid * 64u;
+    const uint32_t t = t0 + lane;
+    const bool valid = t < sc.n_tri;
+    const uint32_t lastT = min(t0 + 64u, sc.n_tri) - 1;
+    const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
+    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+
+    M2S_STAMP(0);
+    // ---------------- triangle phase ----------------
+    float p[9];
+    Geo g;
+    Raster rs;
+    rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
+    bool ok = false;
+    uint32_t m = m0;
+    if (valid) {
+        load_positions(sc.tri, t, p);
+        if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
+        geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+        ok = raster_setup(g, R, rs);
+    }
+    M2S_STAMP(1);  // positions loaded + GS/raster setup
+    const int w = rs.x1 - rs.x0 + 1, rows = rs.y1 - rs.y0 + 1;
+    int kind = kNone;
+    unsigned long long mask = 0;
+    uint32_t cnt = 0;
+    if (ok) {
+        if (w <= 8 && rows <= 8 && rs.ext <= 2304) {
+            // small: every quantity fits int32 relative to the bbox origin pixel (|E| < 2^24)
+            kind = kSmall;
+            const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+            int e0 = (int)((long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0]) + ((rs.bias >> 0) & 1) - 1;
+            int e1 = (int)((long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1]) + ((rs.bias >> 1) & 1) - 1;
+            int e2 = (int)((long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2]) + ((rs.bias >> 2) & 1) - 1;
+            const int ax0 = rs.a[0] * 256, ax1 = rs.a[1] * 256, ax2 = rs.a[2] * 256;
+            const int by0 = rs.b[0] * 256, by1 = rs.b[1] * 256, by2 = rs.b[2] * 256;
+            for (int dy = 0; dy < rows; ++dy) {
+                int r0 = e0, r1 = e1, r2 = e2;
+                for (int dx = 0; dx < w; ++dx) {
+                    if ((r0 | r1 | r2) >= 0) mask |= 1ull << (dy * 8 + dx);  // all three >= 0
+                    r0 += ax0; r1 += ax1; r2 += ax2;
+                }
+                e0 += by0; e1 += by1; e2 += by2;
+            }
+            cnt = (uint32_t)__popcll(mask);
+        } else if (rows <= kRowsThread) {
+            kind = kMedium;
+            for (int y = rs.y0; y <= rs.y1; ++y) {
+                int xa, xb;
+                row_span(rs, y, xa, xb);
+                cnt += (uint32_t)max(xb - xa + 1, 0);
+            }
+            if (cnt > kBigCount) kind = kBig;
+        } else {
+            kind = kBig;
+        }
+    }
+    {   // big triangles spanning many rows: counted by the whole wave, one row per lane
+        unsigned long long bigm = __ballot(kind == kBig && rows > kRowsThread);
+        while (bigm) {
+            const int src = __ffsll((long long)bigm) - 1;
+            bigm &= bigm - 1;
+            const Raster br = shfl_raster(rs, src);
+            uint32_t part = 0;
+            for (int y = br.y0 + lane; y <= br.y1; y += 64) {
+                int xa, xb;
+                row_span(br, y, xa, xb);
+                part += (uint32_t)max(xb - xa + 1, 0);
+            }
+            part = wave_sum(part);
+            if (lane == src) cnt = part;
+        }
+    }
+    if (cnt == 0) kind = kNone;
+    const uint32_t cntc = (kind == kSmall || kind == kMedium) ? cnt : 0;  // emitted by this kernel
+    const uint32_t org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;       // bbox origin pixel
+    const bool anybig = __ballot(kind == kBig) != 0ull;
+
+    M2S_STAMP(2);  // coverage counted
+    // ---------------- ordering: wave scan + decoupled look-back ----------------
+    const unsigned long long incl = wave_incl_scan64(cnt, lane);
+    const uint32_t inclc = wave_incl_scan(cntc, lane);
+    const uint32_t tw_lo = __builtin_amdgcn_readlane((uint32_t)incl, 63), tw_hi = __builtin_amdgcn_readlane((uint32_t)(incl >> 32), 63);
+    const unsigned long long total_w = ((unsigned long long)tw_hi << 32) | tw_lo;  // wave-uniform, in SGPRs
+    const uint32_t total_c = __builtin_amdgcn_readlane(inclc, 63);
+    const unsigned long long toff = incl - cnt;  // wave-local index of the first fragment (all kinds)
+    const uint32_t ctoff = inclc - cntc;         // same, counting only fragments emitted here
+
+    if (lane == 0) chain_store(&chain[wid], (wid == 0 ? kFlagPrefix : kFlagAgg) | total_w);
+    // The look-back itself is deferred to the first store: shading does not need the global offset, so
+    // the chain latency overlaps with the first strip's work.
+    unsigned long long base = 0;
+    bool have_base = (wid == 0);
+    auto resolve_base = [&]() {
+        base = lookback(chain, wid, lane, status);
+        if (lane == 0) {
+            chain_store(&chain[wid], kFlagPrefix | ((base + total_w) & kValMask));
+            if (wid == n_waves - 1) *total_out = base + total_w;
+        }
+        have_base = true;
+    };
+    if (wid == 0 && lane == 0 && n_waves == 1) *total_out = total_w;
+    if (total_c == 0 && !have_base) resolve_base();  // nothing to shade: settle the chain now
+
+    M2S_STAMP(3);  // scanned + aggregate published
+    // ---------------- per-triangle fragment constants -> LDS ----------------
+    if (cntc) {
+        TriShade ts;
+        tri_shade_setup(p, g, rs, sc.meshes + m, sc.tri.B0[t], sc.tri.B1[t], ts);
+        ts.mesh = m;
+        const float4* src = reinterpret_cast<const float4*>(&ts);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) L.tri[lane * 5 + k] = src[k];
+        L.tskip[lane] = (uint32_t)(toff - ctoff);
+    }
+    L.park[lane] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), ctoff | (cntc << 18) | ((uint32_t)kind << 30), org);
+    if (kind == kBig) atomicAdd(&status[0], 1u);
+
+    M2S_STAMP(4);  // TriShade in LDS
+    // ---------------- fragment phase, in windows of kWaveEntryCap ----------------
+#ifndef M2S_ABLATE_NOFRAG
+    for (uint32_t win = 0; win < total_c; win += kWaveEntryCap) {
+        const uint32_t wend = win + kWaveEntryCap;
+        {
+            const uint4 pk = L.park[lane];
+            const uint32_t kd = pk.z >> 30, cn = (pk.z >> 18) & 0xFFFu, cto = pk.z & 0x3FFFFu;
+            if (kd == kSmall && cto < wend && cto + cn > win) {
+                unsigned long long mm = ((unsigned long long)pk.y << 32) | pk.x;
+                const uint32_t tag = ((uint32_t)lane << 24) | pk.w;
+                uint32_t ci = cto;
+                while (mm) {
+                    const int bit = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    if (ci >= win && ci < wend) L.entries[ci - win] = tag + (((uint32_t)(bit >> 3) << 12) | (uint32_t)(bit & 7));
+                    ++ci;
+                }
+            } else if (kd == kMedium && cto < wend && cto + cn > win) {
+                expand_medium(sc.tri.A0, sc.tri.A1, sc.tri.A2, sc.meshes + reinterpret_cast<const uint32_t*>(&L.tri[lane * 5 + 4])[3], t0 + lane, R, (uint32_t)lane, cto, win, wend, L.entries);
+            }
+        }
+        wave_lds_sync();  // entries + tri visible to the whole wave
+        if (win == 0) M2S_STAMP(5);  // first window expanded
+        const uint32_t nwin = min((uint32_t)kWaveEntryCap, total_c - win);
+        for (uint32_t e0 = 0; e0 < nwin; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool have = e < nwin;
+            float4 rec[6];
+            uint32_t skipped = 0;  // fragments of deferred (big) triangles preceding this fragment's triangle
+            uint32_t en = 0, slot = 0, mymesh = m0;
+            if (have) {
+                en = L.entries[e];
+                slot = en >> 24;
+                if (!uniform_mesh) mymesh = reinterpret_cast<const uint32_t*>(&L.tri[slot * 5 + 4])[3];
+                if (anybig) skipped = L.tskip[slot];
+            }
+            if (have) {
+                TriShade ts;
+                float4* dst = reinterpret_cast<float4*>(&ts);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dst[k] = L.tri[slot * 5 + k];
+                // wave inside one mesh (the common case): descriptors are wave-uniform -> SGPRs, scalar loads.
+                // wave straddling a mesh boundary: per-lane descriptor pointer.
+                const MeshParams* mp = uniform_mesh ? sc.meshes + m0 : sc.meshes + mymesh;
+                shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), mp, ts, rec);
+            }
+            if (win == 0 && e0 == 0) M2S_STAMP(6);  // first strip shaded
+            if (!have_base) resolve_base();
+            if (win == 0 && e0 == 0) M2S_STAMP(7);  // base resolved
+            const unsigned long long oidx = base + skipped + win + e;
+            if (!anybig) {
+                // the strip's records are consecutive in the output: stage half a wave at a time, then
+                // 16 B/lane fully coalesced stores (3 KiB contiguous per half)
+                const unsigned long long o0 = base + win + e0;
+                uint32_t nvalid = min(64u, nwin - e0);
+                if (o0 >= limit) nvalid = 0;
+                else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    if (have && (lane >> 5) == half) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) L.stage[(lane & 31) * 6 + k] = rec[k];
+                    }
+                    wave_lds_sync();
+                    float4* __restrict__ dsto = out + (o0 + 32u * half) * 6;
+                    const uint32_t nv = nvalid > 32u * half ? min(32u, nvalid - 32u * half) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const uint32_t q = (uint32_t)lane + 64u * j;
+                        const uint32_t r = q / 6u;
+#ifndef M2S_SKIP_STORE
+                        if (r < nv) dsto[q] = L.stage[q];
+#else
+                        if (r < nv && L.stage[q].x == 123.456f) dsto[q] = L.stage[q];
+#endif
+                    }
+                    wave_lds_sync();
+                }
+            } else if (have && oidx < limit) {
+                float4* __restrict__ dsto = out + oidx * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dsto[k] = rec[k];
+            }
+        }
+        wave_lds_sync();  // the next window overwrites entries
+    }
+#endif
+    M2S_STAMP(8);  // done
+#ifdef M2S_TIMING
+    if (lane == 0 && wid < kTimingWaves) { g_timing[9 * kTimingWaves + wid] = total_c; g_timing[10 * kTimingWaves + wid] = __builtin_amdgcn_s_getreg(6164) /*XCC_ID*/; }
+#endif
+}
+
+void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
+                  unsigned long long* total, uint32_t* status, hipStream_t st) {
+    const uint32_t nb = n_fused_blocks(sc.n_tri);
+    if (!nb) return;
+    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status);
+}
+
+#ifdef M2S_TIMING
+extern "C" int m2s_debug_read_timing(unsigned long long* dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_timing), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+}  // namespace m2s

@@ -16,248 +16,11 @@
 // Arithmetic is fp32 with one rounding per operation (compiled with -ffp-contract=off; HIP's
 // default correctly-rounded fp32 divide/sqrt), integer rasterisation on a 24.8 grid with int64
 // edge functions: see DESIGN.md "Pinned semantics".  No MFMA: nothing here is a contraction.
-#include "m2s_device.h"
+#include "m2s_devfn.h"
 
 #pragma clang fp contract(off)
 
 namespace m2s {
-
-// ============================================================================================
-// small helpers
-// ============================================================================================
-__device__ __forceinline__ float len3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t n = __shfl_up(v, d);
-        if (lane >= d) v += n;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave execute in order; this only stops the compiler from moving
-    // LDS accesses across the point and drains outstanding LDS traffic.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// exact floor(num/den), den > 0, |num| < 2^52: fp64 quotient + one integer correction step
-__device__ __forceinline__ long long floordiv_pos(long long num, long long den) {
-    long long q = (long long)floor((double)num / (double)den);
-    long long r = num - q * den;
-    if (r < 0) q -= 1;
-    else if (r >= den) q += 1;
-    return q;
-}
-
-// ============================================================================================
-// geometry-shader restatement (converterGS.glsl:326-443)
-// ============================================================================================
-struct Geo {
-    float xx, xy, xz;  // xAxis = normalised longest edge  (GS:345, 401)
-    float nx, ny, nz;  // face normal                      (GS:347)
-    float ou[3], ov[3];  // bbox-normalised orthogonal UVs  (GS:353-399)
-};
-
-__device__ __forceinline__ void geo_setup(const float p[9], const float* __restrict__ bmin,
-                                          const float* __restrict__ bmax, Geo& g) {
-    float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
-    float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
-    float e3x = p[6] - p[3], e3y = p[7] - p[4], e3z = p[8] - p[5];
-    float l1 = len3(e1x, e1y, e1z), l2 = len3(e2x, e2y, e2z), l3 = len3(e3x, e3y, e3z);
-    // GS:333-342: strict >, else-if; second branch leaves edge2 untouched
-    if (l2 > l1 && l2 > l3) {
-        float tx = e1x, ty = e1y, tz = e1z;
-        e1x = e2x; e1y = e2y; e1z = e2z;
-        e2x = tx; e2y = ty; e2z = tz;
-    } else if (l3 > l1 && l3 > l2) {
-        e1x = e3x; e1y = e3y; e1z = e3z;
-    }
-    float inv = 1.0f / len3(e1x, e1y, e1z);
-    g.xx = e1x * inv; g.xy = e1y * inv; g.xz = e1z * inv;
-    float cx = g.xy * e2z - g.xz * e2y, cy = g.xz * e2x - g.xx * e2z, cz = g.xx * e2y - g.xy * e2x;
-    inv = 1.0f / len3(cx, cy, cz);
-    g.nx = cx * inv; g.ny = cy * inv; g.nz = cz * inv;
-    float ax = fabsf(g.nx), ay = fabsf(g.ny), az = fabsf(g.nz);
-    // GS:360-396: (y,z) | (x,z) | (x,y) with strict compares and fall-through on ties
-    const bool first = (ax > ay) && (ax > az);
-    const bool second = !first && (ay > az);
-    const bool useY_asA = first;             // A = 1 (y) only in the first branch, else 0 (x)
-    const bool useY_asB = !first && !second; // B = 1 (y) only in the third branch, else 2 (z)
-    float bminA = useY_asA ? bmin[1] : bmin[0], bmaxA = useY_asA ? bmax[1] : bmax[0];
-    float bminB = useY_asB ? bmin[1] : bmin[2], bmaxB = useY_asB ? bmax[1] : bmax[2];
-    float range = fmaxf(bmaxA - bminA, bmaxB - bminB);
-    float invRange = 1.0f / range;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        float pa = useY_asA ? p[3 * i + 1] : p[3 * i + 0];
-        float pb = useY_asB ? p[3 * i + 1] : p[3 * i + 2];
-        g.ou[i] = (pa - bminA) * invRange;
-        g.ov[i] = (pb - bminB) * invRange;
-    }
-}
-
-// flat outputs of the GS: Scale (GS:409-430) and Quaternion (GS:401-407, quat_cast GS:131-183)
-__device__ __forceinline__ void geo_flat(const float p[9], const Geo& g, float& sx, float& sy, float4& rot) {
-    // yAxis = normalize(cross(normal, xAxis))
-    float cx = g.ny * g.xz - g.nz * g.xy, cy = g.nz * g.xx - g.nx * g.xz, cz = g.nx * g.xy - g.ny * g.xx;
-    float inv = 1.0f / len3(cx, cy, cz);
-    float yx = cx * inv, yy = cy * inv, yz = cz * inv;
-    // m[c][r]: columns x, y, n
-    const float m00 = g.xx, m01 = g.xy, m02 = g.xz;
-    const float m10 = yx, m11 = yy, m12 = yz;
-    const float m20 = g.nx, m21 = g.ny, m22 = g.nz;
-    float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
-    int bi = 0;
-    float fb = fw;
-    if (fx > fb) { fb = fx; bi = 1; }
-    if (fy > fb) { fb = fy; bi = 2; }
-    if (fz > fb) { fb = fz; bi = 3; }
-    float bv = sqrtf(fb + 1.0f) * 0.5f;
-    float mult = 0.25f / bv;
-    float qx, qy, qz, qw;
-    if (bi == 0) {
-        qw = bv; qx = (m12 - m21) * mult; qy = (m20 - m02) * mult; qz = (m01 - m10) * mult;
-    } else if (bi == 1) {
-        qw = (m12 - m21) * mult; qx = bv; qy = (m01 + m10) * mult; qz = (m20 + m02) * mult;
-    } else if (bi == 2) {
-        qw = (m20 - m02) * mult; qx = (m01 + m10) * mult; qy = bv; qz = (m12 + m21) * mult;
-    } else {
-        qw = (m01 - m10) * mult; qx = (m20 + m02) * mult; qy = (m12 + m21) * mult; qz = bv;
-    }
-    rot = make_float4(qw, qx, qy, qz);  // GS:407 stores (w,x,y,z)
-    // Jacobian: UVMatrix[col][row], inverse2x2 (GS:206-220), multiplyMat2x3WithMat2x2 (GS:222-235)
-    float U00 = g.ou[1] - g.ou[0], U10 = g.ou[2] - g.ou[0];
-    float U01 = g.ov[1] - g.ov[0], U11 = g.ov[2] - g.ov[0];
-    float det = U00 * U11 - U01 * U10;
-    float I00 = 0.0f, I10 = 0.0f, I01 = 0.0f, I11 = 0.0f;
-    if (det != 0.0f) {
-        float invDet = 1.0f / det;
-        I00 = U11 * invDet;
-        I10 = -U10 * invDet;
-        I01 = -U01 * invDet;
-        I11 = U00 * invDet;
-    }
-    float v0x = p[3] - p[0], v0y = p[4] - p[1], v0z = p[5] - p[2];
-    float v1x = p[6] - p[0], v1y = p[7] - p[1], v1z = p[8] - p[2];
-    sx = len3(v0x * I00 + v1x * I01, v0y * I00 + v1y * I01, v0z * I00 + v1z * I01);
-    sy = len3(v0x * I10 + v1x * I11, v0y * I10 + v1y * I11, v0z * I10 + v1z * I11);
-}
-
-// ============================================================================================
-// pinned rasteriser: viewport transform, 24.8 snap (RNE), int64 edge functions, top-left rule
-// ============================================================================================
-struct Raster {
-    int a[3], b[3];      // E_i(Px,Py) = a*Px + b*Py + c, interior positive; edge i opposite vertex i
-    long long c[3];
-    long long area2;
-    int bias;            // bit i: boundary of edge i is inside
-    int x0, x1, y0, y1;  // inclusive pixel bbox, clamped to the viewport
-};
-
-constexpr float kGuardPx = 16384.0f;
-
-__device__ __forceinline__ bool raster_setup(const Geo& g, uint32_t R, Raster& s) {
-    const float half = (float)R * 0.5f;
-    int X[3], Y[3];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        float ndx = g.ou[i] * 2.0f - 1.0f, ndy = g.ov[i] * 2.0f - 1.0f;  // GS:439
-        float xw = half * ndx + half, yw = half * ndy + half;            // glViewport(0,0,R,R)
-        ok = ok && (fabsf(xw) < kGuardPx) && (fabsf(yw) < kGuardPx);     // false for NaN
-        X[i] = (int)rintf(xw * 256.0f);
-        Y[i] = (int)rintf(yw * 256.0f);
-    }
-    if (!ok) return false;
-    long long area2 = (long long)(X[1] - X[0]) * (Y[2] - Y[0]) - (long long)(Y[1] - Y[0]) * (X[2] - X[0]);
-    if (area2 == 0) return false;
-    const int sgn = area2 < 0 ? -1 : 1;  // no culling (ConversionPass.cpp:48)
-    s.area2 = area2 < 0 ? -area2 : area2;
-    s.bias = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int ia = (i + 1) % 3, ib = (i + 2) % 3;
-        int dy = Y[ib] - Y[ia], dx = X[ib] - X[ia];
-        s.a[i] = -dy * sgn;
-        s.b[i] = dx * sgn;
-        s.c[i] = ((long long)dy * X[ia] - (long long)dx * Y[ia]) * sgn;
-        if (s.a[i] > 0 || (s.a[i] == 0 && s.b[i] > 0)) s.bias |= 1 << i;
-    }
-    int xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
-    int ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
-    s.x0 = max((xmin - 128 + 255) >> 8, 0);
-    s.x1 = min((xmax - 128) >> 8, (int)R - 1);
-    s.y0 = max((ymin - 128 + 255) >> 8, 0);
-    s.y1 = min((ymax - 128) >> 8, (int)R - 1);
-    return s.x0 <= s.x1 && s.y0 <= s.y1;
-}
-
-// covered pixels of row y form one interval [xa, xb] (empty if xa > xb): exact closed form
-__device__ __forceinline__ void row_span(const Raster& s, int y, int& xa, int& xb) {
-    const long long Py = 256ll * y + 128;
-    long long lo = s.x0, hi = s.x1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const long long alpha = 256ll * s.a[i];
-        // pixel x is inside edge i  <=>  alpha*x + beta >= 1   (E > 0, or E >= 0 on an owned boundary)
-        const long long beta = 128ll * s.a[i] + (long long)s.b[i] * Py + s.c[i] + ((s.bias >> i) & 1);
-        if (alpha > 0) {
-            long long q = floordiv_pos(alpha - beta, alpha);  // ceil((1-beta)/alpha)
-            lo = q > lo ? q : lo;
-        } else if (alpha < 0) {
-            long long q = floordiv_pos(beta - 1, -alpha);
-            hi = q < hi ? q : hi;
-        } else if (beta < 1) {
-            hi = lo - 1;
-        }
-    }
-    if (hi < lo) { xa = 0; xb = -1; }
-    else { xa = (int)lo; xb = (int)hi; }
-}
-
-__device__ __forceinline__ Raster shfl_raster(const Raster& s, int src) {
-    Raster r;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        r.a[i] = __shfl(s.a[i], src);
-        r.b[i] = __shfl(s.b[i], src);
-        r.c[i] = __shfl(s.c[i], src);
-    }
-    r.area2 = 0;
-    r.bias = __shfl(s.bias, src);
-    r.x0 = __shfl(s.x0, src); r.x1 = __shfl(s.x1, src);
-    r.y0 = __shfl(s.y0, src); r.y1 = __shfl(s.y1, src);
-    return r;
-}
-
-// ============================================================================================
-// scene access
-// ============================================================================================
-__device__ __forceinline__ void load_positions(const TriPlanes& tp, uint32_t t, float p[9]) {
-    float4 a0 = tp.A0[t], a1 = tp.A1[t];
-    float a2 = tp.A2[t];
-    p[0] = a0.x; p[1] = a0.y; p[2] = a0.z; p[3] = a0.w;
-    p[4] = a1.x; p[5] = a1.y; p[6] = a1.z; p[7] = a1.w;
-    p[8] = a2;
-}
-
-// mesh of GLOBAL triangle gt: last m with mesh_first[m] <= gt
-__device__ __forceinline__ uint32_t find_mesh(const SceneDev& sc, uint32_t gt) {
-    uint32_t lo = 0, hi = sc.n_meshes;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (sc.mesh_first[mid] <= gt) lo = mid; else hi = mid;
-    }
-    return lo;
-}
 
 // ============================================================================================
 // upload-time kernels (== SceneManager::setupMeshBuffers / glGenerateMipmap; not in the timed pass)
@@ -321,6 +84,25 @@ __global__ void __launch_bounds__(kBlock) k_mip(const uint32_t* __restrict__ src
     dst[i] = o;
 }
 
+// interleave one mip level of the three maps into the combo layout (see ComboDesc)
+__global__ void __launch_bounds__(kBlock) k_combo(const uint32_t* __restrict__ a, const uint32_t* __restrict__ n,
+                                                  const uint32_t* __restrict__ m, uint32_t w, uint32_t h,
+                                                  uint32_t* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (w + 1) * h) return;
+    const uint32_t x = i % (w + 1), y = i / (w + 1);
+    const uint32_t src = y * w + (x == w ? 0u : x);
+    dst[3 * i + 0] = a[src];
+    dst[3 * i + 1] = n[src];
+    dst[3 * i + 2] = m[src];
+}
+
+void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m, uint32_t w, uint32_t h, uint32_t* dst,
+                        hipStream_t st) {
+    const uint32_t cnt = (w + 1) * h;
+    hipLaunchKernelGGL(k_combo, dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a, n, m, w, h, dst);
+}
+
 void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh,
                       hipStream_t st) {
     uint32_t n = dw * dh;
@@ -330,17 +112,6 @@ void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* d
 // ============================================================================================
 // K1: per-triangle fragment count
 // ============================================================================================
-__device__ __forceinline__ bool setup_raster_for(const SceneDev& sc, uint32_t t, uint32_t mesh_hint, bool uniform_mesh,
-                                                 uint32_t R, Raster& rs) {
-    float p[9];
-    load_positions(sc.tri, t, p);
-    uint32_t m = uniform_mesh ? mesh_hint : find_mesh(sc, sc.tri_first + t);
-    const MeshParams* mp = sc.meshes + m;
-    Geo g;
-    geo_setup(p, mp->bmin, mp->bmax, g);
-    return raster_setup(g, R, rs);
-}
-
 __global__ void __launch_bounds__(kBlock) k_count(SceneDev sc, uint32_t R, uint32_t* __restrict__ cnt,
                                                   uint32_t* __restrict__ partials) {
     __shared__ uint32_t red[kBlock / 64];
@@ -466,164 +237,6 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
     if (!n_tri) return;
     hipLaunchKernelGGL(k_offsets, dim3(n_count_blocks(n_tri)), dim3(kBlock), 0, st, cnt, partials, n_tri, off, start,
                        n_start);
-}
-
-// ============================================================================================
-// fragment-shader restatement (converterFS.glsl:44-104) with software trilinear sampling
-// (sampler state glUtils.cpp:292-313: REPEAT, LINEAR_MIPMAP_LINEAR / LINEAR, levels 0..4)
-// ============================================================================================
-constexpr float kUnorm8 = 0.003921568859368563f;  // fp32 nearest to 1/255
-
-__device__ __forceinline__ float frac_repeat(float u) {
-    float f = u - floorf(u);
-    if (!(f >= 0.0f)) f = 0.0f;
-    if (f > 1.0f) f = 1.0f;
-    return f;
-}
-
-// un-normalised bilinear sum of raw byte values on one level
-__device__ __forceinline__ void bilinear(const TexDesc* __restrict__ t, uint32_t level, float uf, float vf, float out[4]) {
-    const uint32_t W = max(1u, t->w >> level), H = max(1u, t->h >> level);
-    const uint32_t* __restrict__ img = t->texels + t->off[level];
-    const float up = uf * (float)W - 0.5f, vp = vf * (float)H - 0.5f;
-    const float fi = floorf(up), fj = floorf(vp);
-    const float a = up - fi, b = vp - fj;
-    int i0 = (int)fi, j0 = (int)fj;
-    int i1 = i0 + 1, j1 = j0 + 1;
-    if (i0 < 0) i0 += (int)W;
-    if (j0 < 0) j0 += (int)H;
-    if (i0 >= (int)W) i0 -= (int)W;
-    if (j0 >= (int)H) j0 -= (int)H;
-    if (i1 >= (int)W) i1 -= (int)W;
-    if (j1 >= (int)H) j1 -= (int)H;
-    if (i1 >= (int)W) i1 -= (int)W;
-    if (j1 >= (int)H) j1 -= (int)H;
-    const uint32_t t00 = img[(size_t)j0 * W + i0], t10 = img[(size_t)j0 * W + i1];
-    const uint32_t t01 = img[(size_t)j1 * W + i0], t11 = img[(size_t)j1 * W + i1];
-    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++) {
-        const float c00 = (float)((t00 >> (8 * ch)) & 255u), c10 = (float)((t10 >> (8 * ch)) & 255u);
-        const float c01 = (float)((t01 >> (8 * ch)) & 255u), c11 = (float)((t11 >> (8 * ch)) & 255u);
-        out[ch] = ((w00 * c00 + w10 * c10) + w01 * c01) + w11 * c11;
-    }
-}
-
-__device__ __forceinline__ float lod_lambda(const TexDesc* __restrict__ t, float dudx, float dvdx, float dudy, float dvdy) {
-    const float fw = (float)t->w, fh = (float)t->h;
-    const float sx = dudx * fw, tx = dvdx * fh, sy = dudy * fw, ty = dvdy * fh;
-    const float rx = sqrtf(sx * sx + tx * tx), ry = sqrtf(sy * sy + ty * ty);
-    return log2f(fmaxf(rx, ry));
-}
-
-__device__ __forceinline__ void sample_lod(const TexDesc* __restrict__ t, float u, float v, float lambda, float out[4]) {
-    const float uf = frac_repeat(u), vf = frac_repeat(v);
-    const uint32_t nl = t->n_levels;
-    float t1[4];
-    if (!(lambda > 0.0f)) {
-        bilinear(t, 0, uf, vf, t1);
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) out[ch] = t1[ch] * kUnorm8;
-        return;
-    }
-    if (lambda >= (float)(nl - 1)) {
-        bilinear(t, nl - 1, uf, vf, t1);
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) out[ch] = t1[ch] * kUnorm8;
-        return;
-    }
-    const float d = floorf(lambda), f = lambda - d;
-    float t2[4];
-    bilinear(t, (uint32_t)d, uf, vf, t1);
-    bilinear(t, (uint32_t)d + 1, uf, vf, t2);
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++) out[ch] = ((1.0f - f) * t1[ch] + f * t2[ch]) * kUnorm8;
-}
-
-// Everything the GS + rasteriser + FS produce for ONE fragment (triangle t, pixel x,y).
-__device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, int x, int y, uint32_t mesh_hint,
-                                               bool uniform_mesh, uint32_t R, float4 rec[6]) {
-    const TriPlanes& tp = sc.tri;
-    float p[9];
-    load_positions(tp, t, p);
-    const uint32_t m = uniform_mesh ? mesh_hint : find_mesh(sc, sc.tri_first + t);
-    const MeshParams* __restrict__ mp = sc.meshes + m;
-    Geo g;
-    geo_setup(p, mp->bmin, mp->bmax, g);
-    Raster rs;
-    raster_setup(g, R, rs);
-    float sx, sy;
-    float4 rot;
-    geo_flat(p, g, sx, sy, rot);
-
-    // screen-linear barycentrics from the exact integer edge functions
-    const long long Px = 256ll * x + 128, Py = 256ll * y + 128;
-    const long long E1 = (long long)rs.a[1] * Px + (long long)rs.b[1] * Py + rs.c[1];
-    const long long E2 = (long long)rs.a[2] * Px + (long long)rs.b[2] * Py + rs.c[2];
-    const float inva = 1.0f / (float)rs.area2;
-    const float l1 = (float)E1 * inva, l2 = (float)E2 * inva;
-
-    // smooth varyings (converterGS.glsl:432-441): Position, Normal, Tangent, UV
-    const float4 b0 = tp.B0[t];
-    const float2 b1 = tp.B1[t];
-    const float4 c0 = tp.C0[t], c1 = tp.C1[t];
-    const float c2 = tp.C2[t];
-    const float4 d0 = tp.D0[t], d1 = tp.D1[t], d2 = tp.D2[t];
-#define M2S_LERP(f0, f1, f2) (((f0) + l1 * ((f1) - (f0))) + l2 * ((f2) - (f0)))
-    const float Pxw = M2S_LERP(p[0], p[3], p[6]), Pyw = M2S_LERP(p[1], p[4], p[7]), Pzw = M2S_LERP(p[2], p[5], p[8]);
-    const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
-    const float Tx = M2S_LERP(d0.x, d1.x, d2.x), Ty = M2S_LERP(d0.y, d1.y, d2.y), Tz = M2S_LERP(d0.z, d1.z, d2.z);
-    const float Tw = M2S_LERP(d0.w, d1.w, d2.w);
-    const float U = M2S_LERP(b0.x, b0.z, b1.x), V = M2S_LERP(b0.y, b0.w, b1.y);
-#undef M2S_LERP
-
-    const TexDesc* __restrict__ ta = &mp->tex[0];
-    const TexDesc* __restrict__ tn = &mp->tex[1];
-    const TexDesc* __restrict__ tm = &mp->tex[2];
-    const bool hasA = ta->texels != nullptr, hasN = tn->texels != nullptr, hasM = tm->texels != nullptr;
-    float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
-    if (hasA || hasN || hasM) {
-        // UV is affine in window space (all w = 1, GS:439), so the derivatives are per-triangle constants
-        const float g1x = (float)((long long)rs.a[1] * 256) * inva, g2x = (float)((long long)rs.a[2] * 256) * inva;
-        const float g1y = (float)((long long)rs.b[1] * 256) * inva, g2y = (float)((long long)rs.b[2] * 256) * inva;
-        const float du1 = b0.z - b0.x, du2 = b1.x - b0.x, dv1 = b0.w - b0.y, dv2 = b1.y - b0.y;
-        dudx = g1x * du1 + g2x * du2; dvdx = g1x * dv1 + g2x * dv2;
-        dudy = g1y * du1 + g2y * du2; dvdy = g1y * dv1 + g2y * dv2;
-    }
-    // FS:53-62
-    float col[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-    if (hasA) sample_lod(ta, U, V, lod_lambda(ta, dudx, dvdx, dudy, dvdy), col);
-    // FS:66-81
-    float ox = Nx, oy = Ny, oz = Nz;
-    if (hasN) {
-        float s[4];
-        sample_lod(tn, U, V, lod_lambda(tn, dudx, dvdx, dudy, dvdy), s);
-        float rx = s[0] * 2.0f - 1.0f, ry = s[1] * 2.0f - 1.0f, rz = s[2] * 2.0f - 1.0f;
-        float inv = 1.0f / len3(rx, ry, rz);
-        rx *= inv; ry *= inv; rz *= inv;
-        float bx = Ny * Tz - Nz * Ty, by = Nz * Tx - Nx * Tz, bz = Nx * Ty - Ny * Tx;  // cross(Normal, Tangent.xyz)
-        inv = 1.0f / len3(bx, by, bz);
-        bx = (bx * inv) * Tw; by = (by * inv) * Tw; bz = (bz * inv) * Tw;
-        inv = 1.0f / len3(Nx, Ny, Nz);
-        const float nnx = Nx * inv, nny = Ny * inv, nnz = Nz * inv;
-        float wx = (Tx * rx + bx * ry) + nnx * rz, wy = (Ty * rx + by * ry) + nny * rz, wz = (Tz * rx + bz * ry) + nnz * rz;
-        inv = 1.0f / len3(wx, wy, wz);
-        ox = wx * inv; oy = wy * inv; oz = wz * inv;
-    }
-    // FS:87-95
-    float metal = 0.1f, rough = 0.5f;
-    if (hasM) {
-        float s[4];
-        sample_lod(tm, U, V, lod_lambda(tm, dudx, dvdx, dudy, dvdy), s);
-        metal = s[2]; rough = s[1];
-    }
-    // FS:98-103
-    rec[0] = make_float4(Pxw, Pyw, Pzw, 1.0f);
-    rec[1] = make_float4(col[0] * mp->color[0], col[1] * mp->color[1], col[2] * mp->color[2], col[3] * mp->color[3]);
-    rec[2] = make_float4(sx, sy, 1e-7f, 0.0f);
-    rec[3] = make_float4(ox, oy, oz, 0.0f);
-    rec[4] = rot;
-    rec[5] = make_float4(metal, rough, 0.0f, 1.0f);
 }
 
 // ============================================================================================

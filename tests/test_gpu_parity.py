@@ -10,11 +10,31 @@ from parity import assert_records_match
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def conv(hiplib):
+@pytest.fixture(scope="module", params=["auto", "multipass"])
+def conv(hiplib, request):
+    """Every parity test runs through both pipelines: the fused single-pass kernel (with its multi-pass
+    fallback for big triangles) and the forced multi-pass pipeline."""
     c = Converter(0)
+    c.set_pipeline(request.param)
     yield c
     c.close()
+
+
+def test_pipelines_bit_identical(hiplib):
+    """fused and multi-pass pipelines must produce the same bytes (they share the per-fragment code)."""
+    a, b = Converter(0), Converter(0)
+    b.set_pipeline("multipass")
+    for scene, R in [(synth.cube_sphere(30, tex_size=64), 256), (synth.random_soup(4000, seed=4), 300),
+                     (synth.sphere_grid(2, n=7, tex_size=32), 200)]:
+        outs = []
+        for c in (a, b):
+            c.upload_scene(scene)
+            c.set_max_gaussians(0)
+            n = c.convert(R)
+            outs.append((n, c.download()))
+        assert outs[0][0] == outs[1][0]
+        assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    a.close(); b.close()
 
 
 def run_both(conv, oracle, scene, R, cap=None):
