@@ -48,9 +48,9 @@ struct m2s_ctx {
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;  // pinned: [0] = fragment counter, [1] = status words of the fused kernel
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per workgroup
-    uint32_t* d_status = nullptr;           // [0] deferred (big) triangles, [1] look-back error
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
+    uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
 
     // output
     void* d_records = nullptr;
@@ -126,7 +126,6 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void**)&c->d_status, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->h_total, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
@@ -143,7 +142,6 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
     if (c->d_total) (void)hipFree(c->d_total);
-    if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -316,6 +314,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     HIPCHK(c, hipMalloc((void**)&c->d_off, (np + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_partials, std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_chain, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->d_chain, 0, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries
     c->has_scene = true;
     c->last_total = c->last_stored = 0;
@@ -418,20 +417,20 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
     if (c->pipeline != M2S_PIPELINE_MULTIPASS && !counted) {
-        // single-pass kernel; triangles too large for its in-workgroup budget are only counted
-        HIPCHK(c, hipMemsetAsync(c->d_chain, 0, (size_t)n_fused_waves(sc.n_tri) * sizeof(unsigned long long), st));
-        HIPCHK(c, hipMemsetAsync(c->d_status, 0, 2 * sizeof(uint32_t), st));
+        // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
+        // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
+        // counter and its two status words straight into pinned host memory.
+        c->h_total[0] = 0;
+        c->h_total[1] = 0;
         if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-        launch_fused(sc, R, c->d_chain, limit, d_out, c->d_total, c->d_status, st);
+        launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch, st);
         if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&c->h_total[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(&c->h_total[1], c->d_status, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
         if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
-        const uint32_t n_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
+        const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
         if (err) return fail(c, M2S_ERR_HIP, "fused kernel: look-back chain timed out");
-        done = (n_big == 0);
+        done = (any_big == 0);
     }
     if (!done) {
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);

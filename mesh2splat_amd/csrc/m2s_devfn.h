@@ -439,8 +439,17 @@ __device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, ui
     j0 = j0 < 0 ? j0 + (int)H : j0;
     j1 = j1 >= (int)H ? j1 - (int)H : j1;
     const uint32_t stride = W + 1;
+#ifdef M2S_ABL_X4ONLY   // debug ablation: one 16-byte access per row instead of 24 bytes (x4 + x2 to the same line)
+    struct __attribute__((packed, aligned(4))) U4 { uint32_t v[4]; };
+    const U4 q0 = *reinterpret_cast<const U4*>(lvl + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u);
+    const U4 q1 = *reinterpret_cast<const U4*>(lvl + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u);
+    ComboPair r0, r1;
+    r0.v[0] = q0.v[0]; r0.v[1] = q0.v[1]; r0.v[2] = q0.v[2]; r0.v[3] = q0.v[3]; r0.v[4] = q0.v[1]; r0.v[5] = q0.v[2];
+    r1.v[0] = q1.v[0]; r1.v[1] = q1.v[1]; r1.v[2] = q1.v[2]; r1.v[3] = q1.v[3]; r1.v[4] = q1.v[1]; r1.v[5] = q1.v[2];
+#else
     const ComboPair r0 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u);
     const ComboPair r1 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u);
+#endif
     const float na = 1.0f - a, nb = 1.0f - b;
     const float w00 = na * nb, w10 = a * nb, w01 = na * b, w11 = a * b;
 #define M2S_CH(word, sh) (w00 * (float)((r0.v[word] >> (sh)) & 255u) + w10 * (float)((r0.v[(word) + 3] >> (sh)) & 255u) + \
@@ -509,28 +518,29 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         l2 = (float)E2 * ts.inva;
     }
 
-    // smooth varyings (converterGS.glsl:432-441): Position, Normal, Tangent, UV
+    // smooth varyings (converterGS.glsl:432-441): Position, Normal, Tangent, UV.
+    // The UV planes are requested FIRST: vector-memory results return in issue order, so the texture
+    // coordinates (and with them the dependent texel fetches) need to wait only for these two loads while
+    // the other nine attribute loads are still in flight.
 #ifdef M2S_SKIP_ATTR
     const float4 a0 = make_float4(ts.inva, 1, 2, 3), a1 = a0, b0 = make_float4(0.1f, 0.2f, 0.3f, ts.inva), c0 = a0, c1 = a0, d0 = a0, d1 = a0, d2 = a0;
     const float a2 = 1, c2 = 2; const float2 b1 = make_float2(0.5f, 0.7f);
 #else
-    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
-    const float a2 = ld_plane(tp.A2, t);
     const float4 b0 = ld_plane(tp.B0, t);
     const float2 b1 = ld_plane(tp.B1, t);
+    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
+    const float a2 = ld_plane(tp.A2, t);
     const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
     const float c2 = ld_plane(tp.C2, t);
     const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
 #endif
-#define M2S_LERP(f0, f1, f2) ((f0) + l1 * ((f1) - (f0)) + l2 * ((f2) - (f0)))
-    const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
-    const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
     float U, V;
     {   // texture coordinates: exact oracle sequence (no FMA), see tri_shade_setup
 #pragma clang fp contract(off)
         U = (b0.x + l1 * (b0.z - b0.x)) + l2 * (b1.x - b0.x);
         V = (b0.y + l1 * (b0.w - b0.y)) + l2 * (b1.y - b0.y);
     }
+#define M2S_LERP(f0, f1, f2) ((f0) + l1 * ((f1) - (f0)) + l2 * ((f2) - (f0)))
 
     const TexDesc* __restrict__ ta = &mp->tex[0];
     const TexDesc* __restrict__ tn = &mp->tex[1];
@@ -538,13 +548,6 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     const uint32_t* xa = ta->texels;   // (non-const only for the debug ablation switch below)
     const uint32_t* xn = tn->texels;
     const uint32_t* xm = tm->texels;
-    // the tangent is only consumed by the normal-map branch; interpolate it now so that the twelve
-    // raw tangent registers die here instead of living across the albedo fetch
-    float Tx = 0.0f, Ty = 0.0f, Tz = 0.0f, Tw = 0.0f;
-    if (xn != nullptr) {
-        Tx = M2S_LERP(d0.x, d1.x, d2.x); Ty = M2S_LERP(d0.y, d1.y, d2.y); Tz = M2S_LERP(d0.z, d1.z, d2.z);
-        Tw = M2S_LERP(d0.w, d1.w, d2.w);
-    }
     const float uf = frac_repeat(U), vf = frac_repeat(V);
     float col[4] = { 1.0f, 1.0f, 1.0f, 1.0f };   // FS:53-62
     float nrm[3] = { 0.0f, 0.0f, 1.0f };
@@ -581,9 +584,14 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
             metal = s[2]; rough = s[1];
         }
     }
+    // the remaining varyings: by now their loads have had the whole texture fetch to arrive
+    const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
+    const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
     // FS:66-81
     float ox = Nx, oy = Ny, oz = Nz;
     if (xn != nullptr) {
+        const float Tx = M2S_LERP(d0.x, d1.x, d2.x), Ty = M2S_LERP(d0.y, d1.y, d2.y), Tz = M2S_LERP(d0.z, d1.z, d2.z);
+        const float Tw = M2S_LERP(d0.w, d1.w, d2.w);
         float rx = nrm[0] * 2.0f - 1.0f, ry = nrm[1] * 2.0f - 1.0f, rz = nrm[2] * 2.0f - 1.0f;
         float inv = fast_rsq(rx * rx + ry * ry + rz * rz);
         rx *= inv; ry *= inv; rz *= inv;

@@ -78,7 +78,7 @@ void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
 
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                  unsigned long long* total, uint32_t* status /* [0]=n_big [1]=error */, hipStream_t st);
+                  unsigned long long* total, uint32_t* status /* [0]=n_big [1]=error */, uint32_t epoch, hipStream_t st);
 
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
 inline uint32_t n_fused_blocks(uint32_t n_tri) { return (n_tri + kBlock - 1) / kBlock; }

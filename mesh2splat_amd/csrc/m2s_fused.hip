@@ -33,7 +33,13 @@ namespace m2s {
 constexpr uint32_t kBigCount = 2048;       // triangles with more fragments are deferred
 constexpr uint32_t kSpinLimit = 1u << 22;  // look-back polls before giving up (~ seconds)
 
-constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPrefix = 2ull << 62, kValMask = (1ull << 62) - 1;
+// chain word = flag(2) | epoch(16) | value(46).  The epoch changes with every launch, so words left over
+// from the previous launch read as "not published" and the chain needs no per-launch memset.
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPrefix = 2ull << 62, kValMask = (1ull << 46) - 1;
+constexpr int kEpochShift = 46;
+__device__ __forceinline__ unsigned chain_flag(unsigned long long v, uint32_t epoch) {
+    return (((v >> kEpochShift) & 0xFFFFu) == epoch) ? (unsigned)(v >> 62) : 0u;
+}
 
 __device__ __forceinline__ unsigned long long chain_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,6 +63,11 @@ __device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long lon
 
 enum : int { kNone = 0, kSmall = 1, kMedium = 2, kBig = 3 };
 
+__device__ __forceinline__ void nt_store(float4* p, float4 v) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // merged into one dwordx4 nt
+}
+
 // Rare path, deliberately NOT inlined: its closed-form span code (fp64 divisions) would otherwise add ~30
 // VGPRs of pressure to the fragment loop of every wave.  Re-derives the raster setup from global memory.
 __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, const float* A2, const MeshParams* mp,
@@ -79,7 +90,9 @@ __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, c
 
 // Decoupled look-back: sum of the totals of all waves before `wid`.  256 chain words per poll (lane l
 // inspects predecessors wid-1-4l .. wid-4-4l, nearest first).  Not inlined: runs once per wave.
-__device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t* status) {
+__device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t epoch,
+                                                    uint32_t* status) {
+    const unsigned long long virt_prefix = kFlagPrefix | ((unsigned long long)epoch << kEpochShift);
     unsigned long long base = 0;
     long long idx = (long long)wid - 1 - 4 * lane;
     uint32_t spins = 0;
@@ -89,8 +102,8 @@ __device__ __noinline__ unsigned long long lookback(const unsigned long long* ch
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long ij = idx - j;
-            const unsigned long long v = ij >= 0 ? chain_load(&chain[ij]) : kFlagPrefix;
-            const unsigned flag = (unsigned)(v >> 62);
+            const unsigned long long v = ij >= 0 ? chain_load(&chain[ij]) : virt_prefix;
+            const unsigned flag = chain_flag(v, epoch);
             if (!has_prefix) {
                 if (flag == 0) invalid = true;
                 part += v & kValMask;
@@ -110,7 +123,7 @@ __device__ __noinline__ unsigned long long lookback(const unsigned long long* ch
             continue;
         }
         if (++spins > kSpinLimit) {
-            if (lane == 0) atomicExch(&status[1], 1u);
+            if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -128,6 +141,10 @@ __device__ unsigned long long g_timing[kTimingSlots * kTimingWaves];
 #define M2S_STAMP(i) do {} while (0)
 #endif
 
+#ifndef M2S_XCD_RUN
+#define M2S_XCD_RUN 1
+#endif
+constexpr uint32_t kXcdRun = M2S_XCD_RUN;  // logical workgroups per XCD run (1 = plain round-robin)
 constexpr int kWaveEntryCap = 192;  // per-wave LDS entry-list window (fragments)
 
 // Everything one wave needs in LDS: exactly 10 KiB -> 40 KiB per 256-thread workgroup, 4 workgroups per CU.
@@ -148,12 +165,20 @@ struct WaveLds {
 __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                   unsigned long long limit, float4* __restrict__ out,
                                                   unsigned long long* __restrict__ total_out,
-                                                  uint32_t* __restrict__ status /* [0]=n_big, [1]=error */) {
+                                                  uint32_t* __restrict__ status /* [0]=n_big, [1]=error */, uint32_t epoch) {
     __shared__ WaveLds lds_all[kBlock / 64];
     const int lane = threadIdx.x & 63;
     WaveLds& L = lds_all[threadIdx.x >> 6];
+    // Optional XCD-aware placement (kXcdRun > 1): hardware workgroup b runs on XCD b % 8 (private L2 each);
+    // runs of kXcdRun consecutive LOGICAL workgroups (= consecutive triangles = neighbouring texture
+    // regions) go to one XCD.  It cuts L2->fabric fetches, but MEASURED SLOWER on the C3 workload
+    // (k_fused 0.237 ms at run 1, 0.249 at 4, 0.262 at 16, 0.287 at 64): the look-back chain follows the
+    // logical order, and a wave's predecessors are then dispatched up to kXcdRun rounds later, which
+    // lengthens every wave's wait for its base offset.  Default 1 = plain round-robin.
+    const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
+    const uint32_t lb = ((round / kXcdRun) * 8u + xcd) * kXcdRun + (round % kXcdRun);
     // global wave id == chain index (made scalar explicitly: the compiler cannot prove threadIdx.x>>6 uniform)
-    const uint32_t wid = blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wid = lb * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = (sc.n_tri + 63u) / 64u;
     if (wid >= n_waves) return;
     const uint32_t t0 = wid * 64u;
@@ -173,8 +198,12 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
     bool ok = false;
     uint32_t m = m0;
+    float4 uvb0 = make_float4(0, 0, 0, 0);
+    float2 uvb1 = make_float2(0, 0);
     if (valid) {
         load_positions(sc.tri, t, p);
+        uvb0 = sc.tri.B0[t];   // only needed for the LODs of covered triangles, but requesting it here
+        uvb1 = sc.tri.B1[t];   // puts it in the same memory round trip as the positions
         if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
         geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
         ok = raster_setup(g, R, rs);
@@ -246,15 +275,16 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     const unsigned long long toff = incl - cnt;  // wave-local index of the first fragment (all kinds)
     const uint32_t ctoff = inclc - cntc;         // same, counting only fragments emitted here
 
-    if (lane == 0) chain_store(&chain[wid], (wid == 0 ? kFlagPrefix : kFlagAgg) | total_w);
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    if (lane == 0) chain_store(&chain[wid], (wid == 0 ? kFlagPrefix : kFlagAgg) | etag | (total_w & kValMask));
     // The look-back itself is deferred to the first store: shading does not need the global offset, so
     // the chain latency overlaps with the first strip's work.
     unsigned long long base = 0;
     bool have_base = (wid == 0);
     auto resolve_base = [&]() {
-        base = lookback(chain, wid, lane, status);
+        base = lookback(chain, wid, lane, epoch, status);
         if (lane == 0) {
-            chain_store(&chain[wid], kFlagPrefix | ((base + total_w) & kValMask));
+            chain_store(&chain[wid], kFlagPrefix | etag | ((base + total_w) & kValMask));
             if (wid == n_waves - 1) *total_out = base + total_w;
         }
         have_base = true;
@@ -266,7 +296,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     // ---------------- per-triangle fragment constants -> LDS ----------------
     if (cntc) {
         TriShade ts;
-        tri_shade_setup(p, g, rs, sc.meshes + m, sc.tri.B0[t], sc.tri.B1[t], ts);
+        tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
         ts.mesh = m;
         const float4* src = reinterpret_cast<const float4*>(&ts);
 #pragma unroll
@@ -274,7 +304,8 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         L.tskip[lane] = (uint32_t)(toff - ctoff);
     }
     L.park[lane] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), ctoff | (cntc << 18) | ((uint32_t)kind << 30), org);
-    if (kind == kBig) atomicAdd(&status[0], 1u);
+    // status lives in host-mapped memory: plain (idempotent) system-scope stores, no PCIe atomics needed
+    if (anybig && lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     M2S_STAMP(4);  // TriShade in LDS
     // ---------------- fragment phase, in windows of kWaveEntryCap ----------------
@@ -348,7 +379,9 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                         const uint32_t q = (uint32_t)lane + 64u * j;
                         const uint32_t r = q / 6u;
 #ifndef M2S_SKIP_STORE
-                        if (r < nv) dsto[q] = L.stage[q];
+                        // non-temporal: the records are never re-read by this kernel; keeping them out of the
+                        // 4 MiB L2 leaves it to the texture / vertex lines (measured: k_fused 0.236 -> 0.200 ms)
+                        if (r < nv) nt_store(&dsto[q], L.stage[q]);
 #else
                         if (r < nv && L.stage[q].x == 123.456f) dsto[q] = L.stage[q];
 #endif
@@ -358,7 +391,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
             } else if (have && oidx < limit) {
                 float4* __restrict__ dsto = out + oidx * 6;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) dsto[k] = rec[k];
+                for (int k = 0; k < 6; ++k) nt_store(&dsto[k], rec[k]);
             }
         }
         wave_lds_sync();  // the next window overwrites entries
@@ -371,10 +404,11 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
 }
 
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                  unsigned long long* total, uint32_t* status, hipStream_t st) {
-    const uint32_t nb = n_fused_blocks(sc.n_tri);
+                  unsigned long long* total, uint32_t* status, uint32_t epoch, hipStream_t st) {
+    uint32_t nb = n_fused_blocks(sc.n_tri);
     if (!nb) return;
-    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status);
+    nb = (nb + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);  // whole XCD runs; surplus workgroups exit at once
+    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status, epoch & 0xFFFFu);
 }
 
 #ifdef M2S_TIMING
