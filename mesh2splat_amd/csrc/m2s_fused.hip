@@ -88,45 +88,51 @@ __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, c
     }
 }
 
-// Decoupled look-back: sum of the totals of all waves before `wid`.  256 chain words per poll (lane l
-// inspects predecessors wid-1-4l .. wid-4-4l, nearest first).  Not inlined: runs once per wave.
+// Decoupled look-back: sum of the totals of all waves before `wid`.  Each poll inspects kLbWindows
+// windows of 64 consecutive chain words (lane l of window j reads word first-64j-l: coalesced 512-byte
+// reads, all issued before the first is consumed = one memory round trip for 512 predecessors).  All
+// resident waves reach this point at a similar age, so the nearest published PREFIX is typically several
+// hundred entries back; a 64- or 256-entry reach cost 3-4 sequential round trips per wave.
+// Not inlined: runs once per wave.
+constexpr int kLbWindows = 8;
 __device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t epoch,
                                                     uint32_t* status) {
     const unsigned long long virt_prefix = kFlagPrefix | ((unsigned long long)epoch << kEpochShift);
     unsigned long long base = 0;
-    long long idx = (long long)wid - 1 - 4 * lane;
+    long long first = (long long)wid - 1;   // nearest predecessor not yet accounted for
     uint32_t spins = 0;
     for (;;) {
-        unsigned long long part = 0;   // sum of this lane's entries up to and including its first prefix
-        bool has_prefix = false, invalid = false;
+        unsigned long long v[kLbWindows];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long ij = idx - j;
-            const unsigned long long v = ij >= 0 ? chain_load(&chain[ij]) : virt_prefix;
-            const unsigned flag = chain_flag(v, epoch);
-            if (!has_prefix) {
-                if (flag == 0) invalid = true;
-                part += v & kValMask;
-                has_prefix = (flag == 2);
-            }
+        for (int j = 0; j < kLbWindows; ++j) {
+            const long long ij = first - 64 * j - lane;
+            v[j] = ij >= 0 ? chain_load(&chain[ij]) : virt_prefix;
         }
-        const unsigned long long pm = __ballot(has_prefix), im = __ballot(invalid);
-        if (pm) {
-            const int pl = __ffsll((long long)pm) - 1;  // lane holding the nearest inclusive prefix
-            if ((im & ((2ull << pl) - 1ull)) == 0) {     // every nearer entry is published
-                base += wave_sum64(lane <= pl ? part : 0ull);
+        bool done = false, stalled = false;
+#pragma unroll
+        for (int j = 0; j < kLbWindows; ++j) {
+            if (done || stalled) continue;
+            const unsigned flag = chain_flag(v[j], epoch);
+            const unsigned long long pm = __ballot(flag == 2), im = __ballot(flag == 0);
+            if (pm) {
+                const int pl = __ffsll((long long)pm) - 1;        // nearest inclusive prefix in this window
+                if ((im & ((1ull << pl) - 1ull)) == 0) {           // every nearer entry is published
+                    base += wave_sum64(lane <= pl ? (v[j] & kValMask) : 0ull);
+                    done = true;
+                } else stalled = true;
+            } else if (im == 0) {                                  // 64 aggregates: take them, go further back
+                base += wave_sum64(v[j] & kValMask);
+                first -= 64;
+            } else stalled = true;
+        }
+        if (done) break;
+        if (stalled) {
+            if (++spins > kSpinLimit) {
+                if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-        } else if (im == 0) {  // 256 aggregates: take them all and look further back
-            base += wave_sum64(part);
-            idx -= 256;
-            continue;
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (++spins > kSpinLimit) {
-            if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(1);
     }
     return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
            __builtin_amdgcn_readfirstlane((uint32_t)base);
