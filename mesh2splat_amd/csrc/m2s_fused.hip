@@ -173,6 +173,10 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                                                   unsigned long long* __restrict__ total_out,
                                                   uint32_t* __restrict__ status /* [0]=n_big, [1]=error */, uint32_t epoch) {
     __shared__ WaveLds lds_all[kBlock / 64];
+#ifdef M2S_LDS_PAD   // debug: lower the occupancy artificially
+    __shared__ volatile uint32_t lds_pad[M2S_LDS_PAD / 4];
+    if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
+#endif
     const int lane = threadIdx.x & 63;
     WaveLds& L = lds_all[threadIdx.x >> 6];
     // Optional XCD-aware placement (kXcdRun > 1): hardware workgroup b runs on XCD b % 8 (private L2 each);
