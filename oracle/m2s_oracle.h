@@ -66,6 +66,14 @@ uint64_t orc_convert(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R,
                      uint64_t tri_first, uint64_t tri_count, uint64_t cap,
                      float* out, uint64_t out_capacity, uint64_t* keys, int n_threads);
 
+/* Same conversion on a prepared scene (mip chains built once, like the GPU upload): used by bench.py's
+ * cpu_baseline so that the timed region matches the GPU one (geometry + textures resident -> records). */
+typedef struct orc_scene orc_scene;
+orc_scene* orc_scene_create(const orc_mesh* meshes, uint32_t n_meshes);
+void orc_scene_destroy(orc_scene* sc);
+uint64_t orc_scene_convert(const orc_scene* sc, uint32_t R, uint64_t tri_first, uint64_t tri_count, uint64_t cap,
+                           float* out, uint64_t out_capacity, uint64_t* keys, int n_threads);
+
 /* Per-triangle fragment counts only (for shard balancing tests). counts has n_triangles entries. */
 uint64_t orc_count_per_triangle(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R,
                                 uint32_t* counts);

@@ -48,6 +48,13 @@ def lib():
         L.orc_convert.restype = C.c_uint64
         L.orc_convert.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
                                   C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(_Mesh), C.c_uint32]
+        L.orc_scene_destroy.restype = None
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_convert.restype = C.c_uint64
+        L.orc_scene_convert.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                        C.c_void_p, C.c_int]
         L.orc_count_per_triangle.restype = C.c_uint64
         L.orc_count_per_triangle.argtypes = [C.POINTER(_Mesh), C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_mip_levels.restype = C.c_uint32
@@ -118,6 +125,32 @@ def convert(scene, R: int, cap: int | None = None, tri_first: int = 0, tri_count
     assert t2 == total
     del keep
     return int(total), out, keys
+
+
+class PreparedScene:
+    """Scene with mip chains built once (== the state after the GPU upload); convert() is the timed region."""
+
+    def __init__(self, scene):
+        self._arr, self._keep = _c_meshes(scene)
+        self.n_meshes = len(scene.meshes)
+        self._h = lib().orc_scene_create(self._arr, self.n_meshes)
+
+    def convert(self, R: int, cap: int = 0, n_threads: int = 1, out: np.ndarray | None = None):
+        """Returns (total, records).  `out` may be a preallocated (n, 24) float32 array (like the SSBO)."""
+        L = lib()
+        if out is None:
+            total = L.orc_scene_convert(self._h, R, 0, (1 << 64) - 1, cap, None, 0, None, n_threads)
+            out = np.zeros((min(total, cap) if cap else total, 24), np.float32)
+        total = L.orc_scene_convert(self._h, R, 0, (1 << 64) - 1, cap, out.ctypes.data, out.shape[0], None, n_threads)
+        return int(total), out
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def count_per_triangle(scene, R: int) -> np.ndarray:
