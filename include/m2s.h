@@ -135,6 +135,26 @@ m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t
  * (SceneManager.cpp:668). */
 m2s_status m2s_export_ply(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std);
 
+/* ---- scene I/O == SceneManager::loadModel (minus GL) and parsers::loadPlyFile ------------------------ */
+/* Host-side scene loaded from a binary glTF file: scene-graph transforms applied, de-indexed 17-float
+ * vertex buffers, fallback normals/tangents, cumulative bboxes, RGBA8 textures (PNG) — exactly what
+ * SceneManager::parseGltfFile/setupMeshBuffers/loadTextures leave in RenderContext
+ * (SceneManager.cpp:195-649).  The returned m2s_mesh array can be passed to m2s_upload_scene and stays
+ * valid until m2s_free_host_scene. */
+typedef struct m2s_host_scene m2s_host_scene;
+m2s_status m2s_load_glb(const char* path, m2s_host_scene** out_scene);
+void m2s_free_host_scene(m2s_host_scene* scene);
+uint32_t m2s_host_scene_num_meshes(const m2s_host_scene* scene);
+const m2s_mesh* m2s_host_scene_meshes(const m2s_host_scene* scene);
+const char* m2s_host_scene_mesh_name(const m2s_host_scene* scene, uint32_t i);   /* "<mesh name>_<counter>" */
+const char* m2s_host_scene_warnings(const m2s_host_scene* scene);                 /* skipped primitives etc. */
+/* Reads a binary .ply written by format 0 or 1 back into records (parsers.cpp:516-629): scale = exp,
+ * alpha = sigmoid, colour = SH -> RGB, quaternion normalised.  Free with m2s_free_records. */
+m2s_status m2s_read_ply(const char* path, m2s_gaussian** out_records, uint64_t* out_n, int* out_has_pbr);
+void m2s_free_records(m2s_gaussian* records);
+/* Message of the last failed scene-I/O call on this thread. */
+const char* m2s_io_last_error(void);
+
 /* ---- pipeline selection ------------------------------------------------------------------------ */
 /* AUTO (default): the single-pass fused kernel (k_fused); if the scene holds triangles larger than its
  * in-workgroup budget (> 32 pixel rows or > 2048 fragments) the call re-runs the multi-pass pipeline,

@@ -24,7 +24,9 @@ EXPORTS = (
     "m2s_abi_version", "m2s_create", "m2s_destroy", "m2s_last_error", "m2s_set_triangle_range", "m2s_upload_scene",
     "m2s_set_max_gaussians", "m2s_convert", "m2s_convert_into", "m2s_num_stored", "m2s_device_records", "m2s_download",
     "m2s_download_triangle_counts", "m2s_write_ply", "m2s_export_ply", "m2s_set_profiling", "m2s_last_kernel_ms",
-    "m2s_num_triangles", "m2s_set_pipeline",
+    "m2s_num_triangles", "m2s_set_pipeline", "m2s_load_glb", "m2s_free_host_scene", "m2s_host_scene_num_meshes",
+    "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
+    "m2s_io_last_error",
 )
 
 
@@ -88,6 +90,15 @@ def load():
         "m2s_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "m2s_num_triangles": (u64, [vp]),
         "m2s_set_pipeline": (C.c_int, [vp, C.c_int]),
+        "m2s_load_glb": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "m2s_free_host_scene": (None, [vp]),
+        "m2s_host_scene_num_meshes": (u32, [vp]),
+        "m2s_host_scene_meshes": (C.POINTER(MeshC), [vp]),
+        "m2s_host_scene_mesh_name": (C.c_char_p, [vp, u32]),
+        "m2s_host_scene_warnings": (C.c_char_p, [vp]),
+        "m2s_read_ply": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_int)]),
+        "m2s_free_records": (None, [vp]),
+        "m2s_io_last_error": (C.c_char_p, []),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

@@ -1,0 +1,409 @@
+// m2s_gltf.cpp — .glb scene loader: the host half of the reference's load path re-hosted without GL,
+// tiny_gltf or glm.  Follows SceneManager::loadModel (src/utils/SceneManager.cpp:22-35):
+//   parseGltfFile      :195-459  scene graph -> world matrices, de-indexing into faces, fallback
+//                                normals (:406-413) and UV-derived tangents (:421-451), material parse (:99-193)
+//   setupMeshBuffers   :468-576  17-float interleaved vertex buffer + CUMULATIVE bbox (:476-477,514-527)
+//   loadTextures       :578-649  albedo / normal / metallic-roughness RGBA8 images per mesh
+// Hardening beyond the reference: accessor byteStride and normalised-integer
+// TEXCOORD_0 are honoured (SceneManager::getBufferData :50-61 ignores both).
+#include "m2s_host.h"
+#include "m2s_json.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+
+namespace m2s_host {
+
+namespace {
+
+// ---- the small subset of glm the loader needs, with glm's operation order ------------------------
+struct V3 { float x, y, z; };
+struct M4 { float c[4][4]; };  // c[col][row]
+
+M4 identity() { M4 m{}; for (int i = 0; i < 4; ++i) m.c[i][i] = 1.0f; return m; }
+M4 mul(const M4& a, const M4& b) {  // glm: result[j] = a[0]*b[j][0] + a[1]*b[j][1] + a[2]*b[j][2] + a[3]*b[j][3]
+    M4 r{};
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            r.c[j][i] = ((a.c[0][i] * b.c[j][0] + a.c[1][i] * b.c[j][1]) + a.c[2][i] * b.c[j][2]) + a.c[3][i] * b.c[j][3];
+    return r;
+}
+V3 xform_point(const M4& m, V3 p) {  // vec3(m * vec4(p, 1)); glm: (m0*x + m1*y) + (m2*z + m3*w)
+    V3 r;
+    r.x = (m.c[0][0] * p.x + m.c[1][0] * p.y) + (m.c[2][0] * p.z + m.c[3][0] * 1.0f);
+    r.y = (m.c[0][1] * p.x + m.c[1][1] * p.y) + (m.c[2][1] * p.z + m.c[3][1] * 1.0f);
+    r.z = (m.c[0][2] * p.x + m.c[1][2] * p.y) + (m.c[2][2] * p.z + m.c[3][2] * 1.0f);
+    return r;
+}
+struct M3 { float c[3][3]; };
+M3 upper3(const M4& m) { M3 r; for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) r.c[j][i] = m.c[j][i]; return r; }
+V3 mul(const M3& m, V3 v) {  // glm: m[0]*v.x + m[1]*v.y + m[2]*v.z
+    return { (m.c[0][0] * v.x + m.c[1][0] * v.y) + m.c[2][0] * v.z, (m.c[0][1] * v.x + m.c[1][1] * v.y) + m.c[2][1] * v.z,
+             (m.c[0][2] * v.x + m.c[1][2] * v.y) + m.c[2][2] * v.z };
+}
+M3 inverse_transpose(const M3& m) {  // glm::transpose(glm::inverse(m))
+    const float det = +m.c[0][0] * (m.c[1][1] * m.c[2][2] - m.c[2][1] * m.c[1][2]) - m.c[1][0] * (m.c[0][1] * m.c[2][2] - m.c[2][1] * m.c[0][2]) +
+                      m.c[2][0] * (m.c[0][1] * m.c[1][2] - m.c[1][1] * m.c[0][2]);
+    const float id = 1.0f / det;
+    M3 inv;
+    inv.c[0][0] = +(m.c[1][1] * m.c[2][2] - m.c[2][1] * m.c[1][2]) * id;
+    inv.c[1][0] = -(m.c[1][0] * m.c[2][2] - m.c[2][0] * m.c[1][2]) * id;
+    inv.c[2][0] = +(m.c[1][0] * m.c[2][1] - m.c[2][0] * m.c[1][1]) * id;
+    inv.c[0][1] = -(m.c[0][1] * m.c[2][2] - m.c[2][1] * m.c[0][2]) * id;
+    inv.c[1][1] = +(m.c[0][0] * m.c[2][2] - m.c[2][0] * m.c[0][2]) * id;
+    inv.c[2][1] = -(m.c[0][0] * m.c[2][1] - m.c[2][0] * m.c[0][1]) * id;
+    inv.c[0][2] = +(m.c[0][1] * m.c[1][2] - m.c[1][1] * m.c[0][2]) * id;
+    inv.c[1][2] = -(m.c[0][0] * m.c[1][2] - m.c[1][0] * m.c[0][2]) * id;
+    inv.c[2][2] = +(m.c[0][0] * m.c[1][1] - m.c[1][0] * m.c[0][1]) * id;
+    M3 t;
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) t.c[j][i] = inv.c[i][j];
+    return t;
+}
+V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+V3 cross(V3 a, V3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+V3 normalize(V3 v) { const float s = 1.0f / std::sqrt(dot(v, v)); return { v.x * s, v.y * s, v.z * s }; }  // v * inversesqrt(dot)
+V3 scale(V3 v, float s) { return { v.x * s, v.y * s, v.z * s }; }
+
+M4 node_local(const m2s_json::Value& node) {  // SceneManager.cpp:224-255
+    const auto& mat = node["matrix"];
+    if (mat.is_array() && mat.size() == 16) {
+        M4 m{};
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) m.c[c][r] = (float)mat[(size_t)(c * 4 + r)].number_or(0.0);
+        return m;
+    }
+    M4 T = identity(), R = identity(), S = identity();
+    const auto& t = node["translation"];
+    if (t.is_array() && t.size() == 3) for (int i = 0; i < 3; ++i) T.c[3][i] = (float)t[(size_t)i].number_or(0.0);
+    const auto& q = node["rotation"];
+    if (q.is_array() && q.size() == 4) {  // glm::mat4_cast(quat(w, x, y, z))
+        const float x = (float)q[(size_t)0].number_or(0), y = (float)q[(size_t)1].number_or(0), z = (float)q[(size_t)2].number_or(0),
+                    w = (float)q[(size_t)3].number_or(1);
+        const float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z, qwx = w * x, qwy = w * y, qwz = w * z;
+        R.c[0][0] = 1.0f - 2.0f * (qyy + qzz); R.c[0][1] = 2.0f * (qxy + qwz); R.c[0][2] = 2.0f * (qxz - qwy);
+        R.c[1][0] = 2.0f * (qxy - qwz); R.c[1][1] = 1.0f - 2.0f * (qxx + qzz); R.c[1][2] = 2.0f * (qyz + qwx);
+        R.c[2][0] = 2.0f * (qxz + qwy); R.c[2][1] = 2.0f * (qyz - qwx); R.c[2][2] = 1.0f - 2.0f * (qxx + qyy);
+    }
+    const auto& s = node["scale"];
+    if (s.is_array() && s.size() == 3) for (int i = 0; i < 3; ++i) S.c[i][i] = (float)s[(size_t)i].number_or(1.0);
+    return mul(mul(T, R), S);
+}
+
+struct Accessor {
+    const uint8_t* base = nullptr;
+    size_t count = 0, stride = 0;
+    int component = 0, ncomp = 0;
+    bool normalized = false;
+};
+
+struct Glb {
+    m2s_json::Value doc;
+    std::vector<uint8_t> file;
+    const uint8_t* bin = nullptr;
+    size_t bin_len = 0;
+};
+
+int comp_size(int t) { return t == 5120 || t == 5121 ? 1 : t == 5122 || t == 5123 ? 2 : t == 5125 || t == 5126 ? 4 : 0; }
+int type_ncomp(const std::string& t) {
+    return t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : t == "MAT4" ? 16 : 0;
+}
+
+bool get_accessor(const Glb& g, long long idx, Accessor& a, std::string& err) {
+    const auto& acc = g.doc["accessors"][(size_t)idx];
+    if (idx < 0 || !acc.is_object()) { err = "accessor index out of range"; return false; }
+    const long long bvi = acc["bufferView"].int_or(-1);
+    const auto& bv = g.doc["bufferViews"][(size_t)bvi];
+    if (bvi < 0 || !bv.is_object()) { err = "accessor without bufferView (sparse accessors are not supported)"; return false; }
+    if (bv["buffer"].int_or(0) != 0) { err = "only the GLB-embedded buffer 0 is supported"; return false; }
+    a.component = (int)acc["componentType"].int_or(0);
+    a.ncomp = type_ncomp(acc["type"].string_or(""));
+    a.count = (size_t)acc["count"].int_or(0);
+    a.normalized = acc["normalized"].kind == m2s_json::Value::Bool && acc["normalized"].b;
+    const size_t elem = (size_t)comp_size(a.component) * a.ncomp;
+    if (!elem) { err = "unsupported accessor type"; return false; }
+    a.stride = (size_t)bv["byteStride"].int_or(0);
+    if (!a.stride) a.stride = elem;
+    const size_t off = (size_t)bv["byteOffset"].int_or(0) + (size_t)acc["byteOffset"].int_or(0);
+    if (a.count && off + (a.count - 1) * a.stride + elem > g.bin_len) { err = "accessor exceeds the binary chunk"; return false; }
+    a.base = g.bin + off;
+    return true;
+}
+
+inline void read_floats(const Accessor& a, size_t i, int n, float* out) { std::memcpy(out, a.base + i * a.stride, sizeof(float) * n); }
+
+void read_uv(const Accessor& a, size_t i, float out[2]) {
+    const uint8_t* p = a.base + i * a.stride;
+    if (a.component == 5126) { std::memcpy(out, p, 8); return; }
+    if (a.component == 5121) { out[0] = p[0] / 255.0f; out[1] = p[1] / 255.0f; return; }
+    if (a.component == 5123) { uint16_t v[2]; std::memcpy(v, p, 4); out[0] = v[0] / 65535.0f; out[1] = v[1] / 65535.0f; return; }
+    out[0] = out[1] = 0.0f;
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (n < 0) { std::fclose(f); return false; }
+    out.resize((size_t)n);
+    const bool ok = n == 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok;
+}
+
+}  // namespace
+
+bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
+    Glb g;
+    if (!read_file(path, g.file)) { err = "cannot read " + path; return false; }
+    const std::vector<uint8_t>& f = g.file;
+    auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, &f[o], 4); return v; };
+    if (f.size() < 20 || u32(0) != 0x46546C67u) { err = "not a binary glTF (.glb) file"; return false; }
+    if (u32(4) != 2) { err = "unsupported glTF container version"; return false; }
+    size_t pos = 12;
+    const uint8_t* json = nullptr;
+    size_t json_len = 0;
+    while (pos + 8 <= f.size()) {
+        const uint32_t clen = u32(pos), ctype = u32(pos + 4);
+        if (pos + 8 + (size_t)clen > f.size()) { err = "truncated GLB chunk"; return false; }
+        if (ctype == 0x4E4F534Au && !json) { json = &f[pos + 8]; json_len = clen; }
+        else if (ctype == 0x004E4942u && !g.bin) { g.bin = &f[pos + 8]; g.bin_len = clen; }
+        pos += 8 + (size_t)clen;
+        pos = (pos + 3) & ~(size_t)3;
+    }
+    if (!json) { err = "GLB without JSON chunk"; return false; }
+    try { g.doc = m2s_json::parse((const char*)json, json_len); }
+    catch (const std::exception& e) { err = e.what(); return false; }
+    const auto& doc = g.doc;
+
+    // ---- scene graph -> (mesh, world matrix) instances: SceneManager.cpp:211-281 ---------------------
+    struct Inst { long long mesh; M4 world; };
+    std::vector<Inst> insts;
+    const auto& nodes = doc["nodes"];
+    std::function<void(long long, const M4&, int)> walk = [&](long long ni, const M4& parent, int depth) {
+        if (ni < 0 || (size_t)ni >= nodes.size() || depth > 256) return;
+        const auto& node = nodes[(size_t)ni];
+        const M4 world = mul(parent, node_local(node));
+        const long long mi = node["mesh"].int_or(-1);
+        if (mi >= 0 && (size_t)mi < doc["meshes"].size()) insts.push_back({ mi, world });
+        const auto& ch = node["children"];
+        for (size_t k = 0; k < ch.size(); ++k) walk(ch[k].int_or(-1), world, depth + 1);
+    };
+    if (doc["scenes"].size()) {
+        long long si = doc["scene"].int_or(-1);
+        if (si < 0 || (size_t)si >= doc["scenes"].size()) si = 0;
+        const auto& roots = doc["scenes"][(size_t)si]["nodes"];
+        for (size_t k = 0; k < roots.size(); ++k) walk(roots[k].int_or(-1), identity(), 0);
+    }
+    if (insts.empty())
+        for (size_t i = 0; i < doc["meshes"].size(); ++i) insts.push_back({ (long long)i, identity() });
+
+    // ---- images are decoded lazily, once per glTF image ------------------------------------------------
+    std::map<long long, int> image_slot;
+    auto load_image = [&](long long tex_index, int& out_slot) -> bool {
+        out_slot = -1;
+        const auto& tex = doc["textures"][(size_t)tex_index];
+        if (tex_index < 0 || !tex.is_object()) return true;               // SceneManager.cpp:68-70: silently absent
+        const long long src = tex["source"].int_or(-1);
+        const auto& im = doc["images"][(size_t)src];
+        if (src < 0 || !im.is_object()) return true;
+        auto it = image_slot.find(src);
+        if (it != image_slot.end()) { out_slot = it->second; return true; }
+        const long long bvi = im["bufferView"].int_or(-1);
+        const auto& bv = doc["bufferViews"][(size_t)bvi];
+        if (bvi < 0 || !bv.is_object()) { err = "image " + std::to_string(src) + " is not embedded (external URIs are not supported in .glb mode)"; return false; }
+        const size_t off = (size_t)bv["byteOffset"].int_or(0), len = (size_t)bv["byteLength"].int_or(0);
+        if (off + len > g.bin_len) { err = "image bufferView exceeds the binary chunk"; return false; }
+        Image img;
+        std::string perr;
+        if (!decode_png(g.bin + off, len, img, perr)) {
+            const std::string mime = im["mimeType"].string_or("?");
+            err = "image " + std::to_string(src) + " (" + mime + "): " + perr +
+                  (mime == "image/jpeg" ? " - JPEG decoding is not available in this build; re-export the asset with PNG textures" : "");
+            return false;
+        }
+        scene.images.push_back(std::move(img));
+        out_slot = image_slot[src] = (int)scene.images.size() - 1;
+        return true;
+    };
+
+    // ---- primitives -> meshes: SceneManager.cpp:283-457 ----------------------------------------------------
+    int mesh_counter = 0;
+    for (const Inst& inst : insts) {
+        const auto& mesh = doc["meshes"][(size_t)inst.mesh];
+        const M4& world = inst.world;
+        const M3 world3 = upper3(world);
+        const M3 normal_matrix = inverse_transpose(world3);
+        const auto& prims = mesh["primitives"];
+        for (size_t pi = 0; pi < prims.size(); ++pi) {
+            const auto& prim = prims[pi];
+            const long long mode = prim["mode"].int_or(-1);
+            if (mode != 4 && mode != -1) { scene.warnings.push_back("skipping non-triangle primitive (mode=" + std::to_string(mode) + ")"); continue; }
+            const auto& attrs = prim["attributes"];
+            if (!attrs.has("POSITION")) { scene.warnings.push_back("primitive without POSITION skipped"); continue; }
+            const std::string base = mesh["name"].string_or("").empty() ? "mesh" : mesh["name"].str;
+            HostMesh hm;
+            hm.name = base + "_" + std::to_string(mesh_counter++);
+
+            Accessor pos_a;
+            if (!get_accessor(g, attrs["POSITION"].int_or(-1), pos_a, err)) return false;
+            if (pos_a.component != 5126 || pos_a.ncomp != 3) { err = "POSITION must be float VEC3"; return false; }
+            // index list
+            std::vector<uint32_t> idx;
+            if (prim["indices"].is_number()) {
+                Accessor ia;
+                if (!get_accessor(g, prim["indices"].int_or(-1), ia, err)) return false;
+                if (ia.component != 5121 && ia.component != 5123 && ia.component != 5125) {
+                    scene.warnings.push_back("unsupported index component type, primitive skipped");
+                    continue;
+                }
+                idx.resize(ia.count);
+                for (size_t i = 0; i < ia.count; ++i) {
+                    const uint8_t* p = ia.base + i * ia.stride;
+                    if (ia.component == 5121) idx[i] = *p;
+                    else if (ia.component == 5123) { uint16_t v; std::memcpy(&v, p, 2); idx[i] = v; }
+                    else { uint32_t v; std::memcpy(&v, p, 4); idx[i] = v; }
+                }
+            } else {
+                idx.resize(pos_a.count);
+                for (size_t i = 0; i < pos_a.count; ++i) idx[i] = (uint32_t)i;
+            }
+            if (idx.size() < 3 || idx.size() % 3 != 0) { scene.warnings.push_back("invalid index count, primitive skipped"); continue; }
+            for (uint32_t v : idx) if (v >= pos_a.count) { err = "vertex index out of range in mesh " + hm.name; return false; }
+
+            Accessor nrm_a, uv_a, tan_a;
+            const bool has_n = attrs.has("NORMAL"), has_uv = attrs.has("TEXCOORD_0"), has_t = attrs.has("TANGENT");
+            if (has_n && (!get_accessor(g, attrs["NORMAL"].int_or(-1), nrm_a, err) || nrm_a.component != 5126 || nrm_a.ncomp != 3)) { if (err.empty()) err = "NORMAL must be float VEC3"; return false; }
+            if (has_uv && (!get_accessor(g, attrs["TEXCOORD_0"].int_or(-1), uv_a, err) || uv_a.ncomp != 2)) { if (err.empty()) err = "TEXCOORD_0 must be VEC2"; return false; }
+            if (has_t && (!get_accessor(g, attrs["TANGENT"].int_or(-1), tan_a, err) || tan_a.component != 5126 || tan_a.ncomp != 4)) { if (err.empty()) err = "TANGENT must be float VEC4"; return false; }
+            if ((has_n && nrm_a.count < pos_a.count) || (has_uv && uv_a.count < pos_a.count) || (has_t && tan_a.count < pos_a.count)) {
+                err = "attribute accessor shorter than POSITION in mesh " + hm.name; return false;
+            }
+
+            // material: SceneManager.cpp:99-193 (factors other than baseColorFactor are parsed but never used by the pass)
+            hm.base_color[0] = hm.base_color[1] = hm.base_color[2] = hm.base_color[3] = 1.0f;
+            const long long mat_i = prim["material"].int_or(-1);
+            const auto& mat = doc["materials"][(size_t)mat_i];
+            if (mat_i >= 0 && mat.is_object()) {
+                const auto& pbr = mat["pbrMetallicRoughness"];
+                const auto& bcf = pbr["baseColorFactor"];
+                if (bcf.is_array() && bcf.size() == 4) for (int k = 0; k < 4; ++k) hm.base_color[k] = (float)bcf[(size_t)k].number_or(1.0);
+                if (pbr["baseColorTexture"].is_object() && !load_image(pbr["baseColorTexture"]["index"].int_or(-1), hm.tex_image[0])) return false;
+                if (mat["normalTexture"].is_object() && !load_image(mat["normalTexture"]["index"].int_or(-1), hm.tex_image[1])) return false;
+                if (pbr["metallicRoughnessTexture"].is_object() && !load_image(pbr["metallicRoughnessTexture"]["index"].int_or(-1), hm.tex_image[2])) return false;
+            }
+
+            const size_t n_tri = idx.size() / 3;
+            hm.vertices.assign(n_tri * 3 * 17, 0.0f);
+            for (size_t t = 0; t < n_tri; ++t) {
+                V3 p[3], n[3];
+                float uv[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, tg[3][4];
+                for (int e = 0; e < 3; ++e) {
+                    const uint32_t vi = idx[3 * t + e];
+                    float raw[4];
+                    read_floats(pos_a, vi, 3, raw);
+                    p[e] = xform_point(world, { raw[0], raw[1], raw[2] });
+                    if (has_uv) read_uv(uv_a, vi, uv[e]);
+                    if (has_n) { read_floats(nrm_a, vi, 3, raw); n[e] = normalize(mul(normal_matrix, { raw[0], raw[1], raw[2] })); }
+                }
+                if (!has_n) {  // :406-413 flat face normal from the transformed positions
+                    const V3 fn = normalize(cross(sub(p[1], p[0]), sub(p[2], p[0])));
+                    n[0] = n[1] = n[2] = fn;
+                }
+                if (has_t) {
+                    for (int e = 0; e < 3; ++e) {
+                        float raw[4];
+                        read_floats(tan_a, idx[3 * t + e], 4, raw);
+                        const V3 tv = normalize(mul(world3, { raw[0], raw[1], raw[2] }));
+                        tg[e][0] = tv.x; tg[e][1] = tv.y; tg[e][2] = tv.z; tg[e][3] = raw[3];
+                    }
+                } else {  // :421-451 tangent from the UV parametrisation, one per face
+                    const V3 dp1 = sub(p[1], p[0]), dp2 = sub(p[2], p[0]);
+                    const float du1 = uv[1][0] - uv[0][0], dv1 = uv[1][1] - uv[0][1], du2 = uv[2][0] - uv[0][0], dv2 = uv[2][1] - uv[0][1];
+                    float det = du1 * dv2 - dv1 * du2;
+                    if (std::fabs(det) < 1e-8f) det = 1.0f;
+                    const float inv = 1.0f / det;
+                    V3 tangent = scale(sub(scale(dp1, dv2), scale(dp2, dv1)), inv);
+                    V3 bitangent = scale(sub(scale(dp2, du1), scale(dp1, du2)), inv);
+                    tangent = normalize(tangent);
+                    bitangent = normalize(bitangent);
+                    const V3 nn = normalize(cross(dp1, dp2));
+                    const float hand = dot(cross(nn, tangent), bitangent) < 0.0f ? -1.0f : 1.0f;
+                    for (int e = 0; e < 3; ++e) { tg[e][0] = tangent.x; tg[e][1] = tangent.y; tg[e][2] = tangent.z; tg[e][3] = hand; }
+                }
+                for (int e = 0; e < 3; ++e) {  // setupMeshBuffers :483-512
+                    float* v = &hm.vertices[(t * 3 + e) * 17];
+                    v[0] = p[e].x; v[1] = p[e].y; v[2] = p[e].z;
+                    v[3] = n[e].x; v[4] = n[e].y; v[5] = n[e].z;
+                    v[6] = tg[e][0]; v[7] = tg[e][1]; v[8] = tg[e][2]; v[9] = tg[e][3];
+                    v[10] = uv[e][0]; v[11] = uv[e][1];
+                }
+            }
+            scene.meshes.push_back(std::move(hm));
+        }
+    }
+
+    // ---- cumulative bbox (:476-477,514-527: minBB/maxBB live outside the mesh loop) + C view ----------------
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    scene.c_meshes.clear();
+    for (HostMesh& hm : scene.meshes) {
+        for (size_t v = 0; v < hm.vertices.size(); v += 17)
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hm.vertices[v + k]); mx[k] = std::max(mx[k], hm.vertices[v + k]); }
+        std::memcpy(hm.bbox_min, mn, 12);
+        std::memcpy(hm.bbox_max, mx, 12);
+    }
+    for (HostMesh& hm : scene.meshes) {
+        m2s_mesh cm{};
+        cm.vertices = hm.vertices.data();
+        cm.n_vertices = (uint32_t)(hm.vertices.size() / 17);
+        cm.stride_floats = 17;
+        std::memcpy(cm.bbox_min, hm.bbox_min, 12);
+        std::memcpy(cm.bbox_max, hm.bbox_max, 12);
+        std::memcpy(cm.base_color, hm.base_color, 16);
+        for (int k = 0; k < 3; ++k) {
+            if (hm.tex_image[k] < 0) continue;
+            const Image& im = scene.images[(size_t)hm.tex_image[k]];
+            cm.tex[k].rgba8 = im.rgba.data();
+            cm.tex[k].width = im.width;
+            cm.tex[k].height = im.height;
+        }
+        scene.c_meshes.push_back(cm);
+    }
+    return true;
+}
+
+}  // namespace m2s_host
+
+// Test hook (not part of include/m2s.h): the loader's TRS composition and vertex transforms for one node,
+// so that oracle/ref_glm_xform_check.cpp can compare them bit-for-bit with glm compiled from the
+// reference's vendored copy.  trs = translation(3) rotation xyzw(4) scale(3); out = world(16, column-major),
+// transformed point(3), transformed+normalised normal(3), transformed+normalised tangent(3).
+extern "C" void m2s_debug_node_xform(const float trs[10], const float p[3], const float n[3], const float t[3], float out[25]) {
+    using namespace m2s_host;
+    m2s_json::Value node;
+    node.kind = m2s_json::Value::Obj;
+    node.obj = std::make_shared<m2s_json::Object>();
+    auto arr = [](const float* v, int k) {
+        m2s_json::Value a;
+        a.kind = m2s_json::Value::Arr;
+        a.arr = std::make_shared<m2s_json::Array>();
+        for (int i = 0; i < k; ++i) { m2s_json::Value x; x.kind = m2s_json::Value::Number; x.num = v[i]; a.arr->push_back(x); }
+        return a;
+    };
+    (*node.obj)["translation"] = arr(trs, 3);
+    (*node.obj)["rotation"] = arr(trs + 3, 4);
+    (*node.obj)["scale"] = arr(trs + 7, 3);
+    const M4 w = mul(identity(), node_local(node));
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) out[c * 4 + r] = w.c[c][r];
+    const V3 q = xform_point(w, { p[0], p[1], p[2] });
+    out[16] = q.x; out[17] = q.y; out[18] = q.z;
+    const V3 nn = normalize(mul(inverse_transpose(upper3(w)), { n[0], n[1], n[2] }));
+    out[19] = nn.x; out[20] = nn.y; out[21] = nn.z;
+    const V3 tt = normalize(mul(upper3(w), { t[0], t[1], t[2] }));
+    out[22] = tt.x; out[23] = tt.y; out[24] = tt.z;
+}

@@ -1,0 +1,40 @@
+// m2s_host.h — internal host-side types of the scene I/O layer (.glb loader, PNG decoder, .ply reader).
+// The public boundary is include/m2s.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/m2s.h"
+
+namespace m2s_host {
+
+struct Image {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> rgba;  // RGBA8, row 0 first
+};
+
+// PNG -> RGBA8 (tiny_gltf/stb_image behaviour: always 4 components).  false + err on failure.
+bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err);
+
+// == utils::Mesh + its meshToTextureData entry after SceneManager::loadModel
+struct HostMesh {
+    std::string name;
+    std::vector<float> vertices;   // 17 floats per vertex, the VBO of SceneManager::setupMeshBuffers
+    float bbox_min[3], bbox_max[3];
+    float base_color[4];
+    int tex_image[3] = { -1, -1, -1 };  // index into HostScene::images (albedo, normal, MR)
+};
+
+struct HostScene {
+    std::vector<HostMesh> meshes;
+    std::vector<Image> images;         // decoded once, shared between materials
+    std::vector<m2s_mesh> c_meshes;    // view handed to m2s_upload_scene
+    std::vector<std::string> warnings;
+};
+
+// SceneManager::parseGltfFile + setupMeshBuffers + loadTextures for a .glb file.
+bool load_glb(const std::string& path, HostScene& scene, std::string& err);
+
+}  // namespace m2s_host
