@@ -135,6 +135,17 @@ m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t
  * (SceneManager.cpp:668). */
 m2s_status m2s_export_ply(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std);
 
+/* ---- depth sort == RadixSortPass::execute (RadixSortPass.cpp:8-90) ------------------------------------ */
+/* Sorts the records stored by the last m2s_convert by key = floatBitsToUint(view-space z), ascending on the
+ * raw bits (radixSortPrepass.glsl:23-33; z = row 2 of world_to_view * (P,1), world_to_view column-major like
+ * glm), stable, and gathers the 96-byte records into a second context-owned buffer (radixSortGather.glsl).
+ * *out_n = number of records sorted. */
+m2s_status m2s_sort_by_depth(m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n);
+const void* m2s_device_sorted_records(const m2s_ctx* ctx);
+m2s_status m2s_download_sorted(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacity_records);
+/* Duration (ms) of the last profiled sort (key build + radix sort + gather). */
+float m2s_last_sort_ms(const m2s_ctx* ctx);
+
 /* ---- scene I/O == SceneManager::loadModel (minus GL) and parsers::loadPlyFile ------------------------ */
 /* Host-side scene loaded from a binary glTF file: scene-graph transforms applied, de-indexed 17-float
  * vertex buffers, fallback normals/tangents, cumulative bboxes, RGBA8 textures (PNG) — exactly what

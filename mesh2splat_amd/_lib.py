@@ -26,7 +26,7 @@ EXPORTS = (
     "m2s_download_triangle_counts", "m2s_write_ply", "m2s_export_ply", "m2s_set_profiling", "m2s_last_kernel_ms",
     "m2s_num_triangles", "m2s_set_pipeline", "m2s_load_glb", "m2s_free_host_scene", "m2s_host_scene_num_meshes",
     "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
-    "m2s_io_last_error",
+    "m2s_io_last_error", "m2s_sort_by_depth", "m2s_device_sorted_records", "m2s_download_sorted", "m2s_last_sort_ms",
 )
 
 
@@ -99,6 +99,10 @@ def load():
         "m2s_read_ply": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u64), C.POINTER(C.c_int)]),
         "m2s_free_records": (None, [vp]),
         "m2s_io_last_error": (C.c_char_p, []),
+        "m2s_sort_by_depth": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(u64)]),
+        "m2s_device_sorted_records": (vp, [vp]),
+        "m2s_download_sorted": (C.c_int, [vp, vp, u64]),
+        "m2s_last_sort_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

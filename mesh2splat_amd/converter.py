@@ -132,6 +132,20 @@ class Converter:
     def export_ply(self, path: str, fmt: int = 0, gaussian_std: float = 0.65):
         self._check(self._L.m2s_export_ply(self._h, os.fsencode(path), int(fmt), float(gaussian_std)))
 
+    def sort_by_depth(self, world_to_view) -> np.ndarray:
+        """RadixSortPass: sort the last conversion's records by floatBitsToUint(view-space z); returns them.
+        world_to_view: 4x4, applied as M @ (P,1) (stored column-major for the ABI, like glm)."""
+        m = np.ascontiguousarray(np.asarray(world_to_view, np.float32).T.reshape(16))   # column-major
+        n = C.c_uint64()
+        self._check(self._L.m2s_sort_by_depth(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        out = np.empty((n.value, RECORD_FLOATS), np.float32)
+        self._check(self._L.m2s_download_sorted(self._h, out.ctypes.data, n.value))
+        return out
+
+    @property
+    def last_sort_ms(self) -> float:
+        return float(self._L.m2s_last_sort_ms(self._h))
+
     def set_pipeline(self, name: str):
         """'auto' (fused single-pass kernel, multi-pass fallback for big triangles) or 'multipass'."""
         self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1}[name]))

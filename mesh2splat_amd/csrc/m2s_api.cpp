@@ -60,6 +60,15 @@ struct m2s_ctx {
     uint64_t last_total = 0, last_stored = 0;
     uint32_t last_R = 0;
 
+    // depth sort (f-2)
+    void* d_sorted = nullptr;
+    uint64_t sorted_cap = 0, sorted_n = 0;
+    uint32_t* d_sort_u32 = nullptr;   // keys_in | vals_in | keys_out | vals_out
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_cap = 0;
+    uint64_t sort_u32_cap = 0;
+    float last_sort_ms = 0.0f;
+
     // measurement
     bool profiling = false;
     hipEvent_t ev[8] = {};
@@ -141,6 +150,9 @@ void m2s_destroy(m2s_ctx* c) {
     free_scene(c);
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
+    if (c->d_sorted) (void)hipFree(c->d_sorted);
+    if (c->d_sort_u32) (void)hipFree(c->d_sort_u32);
+    if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -499,6 +511,57 @@ m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float g
     if (s != M2S_OK) c->err = std::string("could not write ") + path;
     return s;
 }
+
+// RadixSortPass::execute (RadixSortPass.cpp:8-90) on the records of the last conversion.
+m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t* out_n) {
+    if (!c || !world_to_view) return M2S_ERR_INVALID;
+    if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->last_stored;
+    c->sorted_n = 0;
+    if (out_n) *out_n = n;
+    if (!n) return M2S_OK;
+    if (n > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 records");
+    if (c->sorted_cap < n) {
+        if (c->d_sorted) { (void)hipFree(c->d_sorted); c->d_sorted = nullptr; c->sorted_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_sorted, n * sizeof(m2s_gaussian)));
+        c->sorted_cap = n;
+    }
+    if (c->sort_u32_cap < n) {
+        if (c->d_sort_u32) { (void)hipFree(c->d_sort_u32); c->d_sort_u32 = nullptr; c->sort_u32_cap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_sort_u32, n * 4 * sizeof(uint32_t)));
+        c->sort_u32_cap = n;
+    }
+    const size_t tb = sort_temp_bytes((uint32_t)n);
+    if (c->sort_temp_cap < tb) {
+        if (c->d_sort_temp) { (void)hipFree(c->d_sort_temp); c->d_sort_temp = nullptr; c->sort_temp_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_sort_temp, std::max<size_t>(tb, 256)));
+        c->sort_temp_cap = tb;
+    }
+    uint32_t* u = c->d_sort_u32;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, sort_by_depth((const float4*)c->last_records, (uint32_t)n, world_to_view, u, u + n, u + 2 * n, u + 3 * n, c->d_sort_temp,
+                            c->sort_temp_cap, (float4*)c->d_sorted, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_sort_ms, c->ev[0], c->ev[1]));
+    c->sorted_n = n;
+    return M2S_OK;
+}
+
+const void* m2s_device_sorted_records(const m2s_ctx* c) { return c && c->sorted_n ? c->d_sorted : nullptr; }
+
+m2s_status m2s_download_sorted(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_records) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->sorted_n) return M2S_OK;
+    if (!dst) return fail(c, M2S_ERR_INVALID, "dst is NULL");
+    if (capacity_records < c->sorted_n) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer records than were sorted");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->d_sorted, c->sorted_n * sizeof(m2s_gaussian), hipMemcpyDeviceToHost));
+    return M2S_OK;
+}
+
+float m2s_last_sort_ms(const m2s_ctx* c) { return c ? c->last_sort_ms : 0.0f; }
 
 m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
     if (!c) return M2S_ERR_INVALID;

@@ -80,6 +80,10 @@ void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                   unsigned long long* total, uint32_t* status /* [0]=n_big [1]=error */, uint32_t epoch, hipStream_t st);
 
+size_t sort_temp_bytes(uint32_t n);
+hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                         uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st);
+
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
 inline uint32_t n_fused_blocks(uint32_t n_tri) { return (n_tri + kBlock - 1) / kBlock; }
 inline uint32_t n_fused_waves(uint32_t n_tri) { return (n_tri + 63) / 64; }

@@ -380,7 +380,7 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
 }  // namespace m2s_host
 
 // Test hook (not part of include/m2s.h): the loader's TRS composition and vertex transforms for one node,
-// so that oracle/ref_glm_xform_check.cpp can compare them bit-for-bit with glm compiled from the
+// so that the glm cross-check harness (ref_glm_xform_check.cpp, test infrastructure) can compare them bit-for-bit with glm compiled from the
 // reference's vendored copy.  trs = translation(3) rotation xyzw(4) scale(3); out = world(16, column-major),
 // transformed point(3), transformed+normalised normal(3), transformed+normalised tangent(3).
 extern "C" void m2s_debug_node_xform(const float trs[10], const float p[3], const float n[3], const float t[3], float out[25]) {

@@ -1,0 +1,56 @@
+// m2s_sort.hip — depth sort of the splat buffer (BASELINE config 5 "final radix sort of
+// the merged splat buffer").  Mirrors the reference's RadixSortPass (src/renderer/renderPasses/
+// RadixSortPass.cpp:8-90): key = floatBitsToUint(view-space z) (radixSortPrepass.glsl:23-33 on the depths
+// written by gaussianSplattingPrepassCS.glsl:203), value = index, 32-bit LSD radix sort ascending on the raw
+// bits (so negative view-space z sorts front to back), then a gather of the 6 x vec4 records
+// (radixSortGather.glsl:30-49).  Key build and gather are hand-written; the sort itself is rocPRIM's
+// device radix sort (a plain library primitive, like the reference's third-party glu::RadixSort).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "m2s_device.h"
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+__global__ void __launch_bounds__(kBlock) k_depth_keys(const float4* __restrict__ rec, uint32_t n, float v02, float v12,
+                                                       float v22, float v32, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = rec[(size_t)i * 6];  // position (xyz, 1)
+    const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;   // row 2 of worldToView * (P,1), pinned order
+    key[i] = __float_as_uint(z);
+    val[i] = i;
+}
+
+// one thread per float4: consecutive lanes write consecutive 16 B of the sorted buffer (fully coalesced
+// 1 KiB stores); the 96 B source records are gathered (6 lanes share one record)
+__global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restrict__ src, const uint32_t* __restrict__ val,
+                                                           uint32_t n, float4* __restrict__ dst) {
+    const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= (size_t)n * 6) return;
+    const uint32_t r = (uint32_t)(q / 6), k = (uint32_t)(q - (size_t)r * 6);
+    dst[q] = src[(size_t)val[r] * 6 + k];
+}
+
+size_t sort_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
+                                    (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                         uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_depth_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in,
+                       vals_in);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 32, st);
+    if (e != hipSuccess) return e;
+    const size_t nq = (size_t)n * 6;
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
+    return hipGetLastError();
+}
+
+}  // namespace m2s

@@ -153,3 +153,24 @@ def test_triangle_counts_match_oracle(conv, oracle):
     conv.set_max_gaussians(0)
     conv.convert(512)
     assert np.array_equal(conv.download_triangle_counts(), oracle.count_per_triangle(scene, 512))
+
+
+def test_depth_sort_matches_stable_argsort(hiplib, oracle):
+    """f-2 / RadixSortPass: key = floatBitsToUint(view-space z), ascending on the raw bits, stable."""
+    scene = synth.sphere_grid(2, n=6, tex_size=16)
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    n = c.convert(160)
+    rec = c.download()
+    ang = 0.7
+    view = np.array([[np.cos(ang), 0, np.sin(ang), -0.3], [0, 1, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), -4.0], [0, 0, 0, 1]], np.float32)
+    got = c.sort_by_depth(view)
+    assert got.shape == rec.shape == (n, 24)
+    f = np.float32
+    z = (f(view[2, 0]) * rec[:, 0] + f(view[2, 1]) * rec[:, 1]) + f(view[2, 2]) * rec[:, 2]
+    z = (z + f(view[2, 3])).astype(np.float32)
+    order = np.argsort(z.view(np.uint32), kind="stable")
+    assert np.array_equal(got.view(np.uint32), rec[order].view(np.uint32))
+    assert np.all(z < 0) and np.all(np.diff(-z[order]) >= 0)      # in front of the camera: front to back
+    c.close()
