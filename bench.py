@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()
 
 
@@ -93,9 +95,11 @@ def main():
     from mesh2splat_amd.converter import Converter
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n, tex, R = WORKLOADS[a.workload]
     scene = synth.colocated_spheres(world, n, tex)
@@ -106,7 +110,7 @@ def main():
     conv.upload_scene(scene)
     # N == 1: the reference's own cap formula.  N > 1: the merged scene exceeds the reference's
     # 7 M envelope, so the cap is lifted and each rank writes into its own buffer.
-    conv.set_max_gaussians(-1 if world == 1 else 0)
+    conv.set_max_gaussians(0 if multi else -1)
     T_local = conv.num_triangles
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -115,7 +119,7 @@ def main():
     mine = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def step():
-        if world == 1:
+        if not multi:
             return conv.convert(R)
         nonlocal out
         total = conv.convert_into(R, out.data_ptr(), out.shape[0], stream)
@@ -123,7 +127,7 @@ def main():
         dist.all_gather_into_tensor(counts, mine)   # offsets of every rank in the merged buffer
         return total
 
-    if world > 1:
+    if multi:
         # size the per-rank record buffer once (like the SSBO (re)allocation, outside the timed region)
         probe = torch.empty((1, 24), dtype=torch.float32, device="cuda")
         need = conv.convert_into(R, probe.data_ptr(), 1, stream)
@@ -131,7 +135,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +156,7 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -162,7 +166,7 @@ def main():
 
     # optional: the north-star record all-gather (xGMI-bound), measured outside the timed region
     gather = None
-    if world > 1 and not a.no_gather:
+    if multi and not a.no_gather:
         nmax = int(counts.max().item())
         send = torch.zeros((nmax, 24), dtype=torch.float32, device="cuda")
         send[: out.shape[0]] = out
@@ -198,7 +202,7 @@ def main():
             "config": {"workload": f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
                                    f"3 procedural {tex}^2 RGBA8 maps, R={R}",
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
-                       "cap": "reference formula" if world == 1 else "unlimited (merged scene exceeds the 7M envelope)"},
+                       "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula"},
             "kernel_ms": {k: v / a.steps for k, v in kms.items()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_" + dom,
@@ -221,7 +225,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds)
         print(json.dumps(res), flush=True)
 
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

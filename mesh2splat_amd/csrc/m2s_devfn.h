@@ -98,6 +98,11 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
 //    interpolation, texture filtering, normal mapping): FMA contraction and the hardware
 //    reciprocal / rsqrt / sqrt / log2 (<= 1 ulp each); agrees with the oracle to ~1e-6 relative,
 //    tolerance 1e-4.
+// Explicit fused multiply-add: VALUE arithmetic spells out every FMA instead of leaving contraction to the
+// compiler, so that the fused and the multi-pass pipelines (two inlining contexts of the same functions)
+// execute the same operations and produce bit-identical records.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3_(float ax, float ay, float az, float bx, float by, float bz) { return fma_(az, bz, fma_(ay, by, ax * bx)); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -120,7 +125,6 @@ __device__ __forceinline__ void geo_flat(const float p[9], const Geo& g, float& 
     if (fy > fb) { fb = fy; bi = 2; }
     if (fz > fb) { fb = fz; bi = 3; }
     {
-#pragma clang fp contract(fast)
         const float bv = fast_sqrt(fb + 1.0f) * 0.5f;
         const float mult = 0.25f * fast_rcp(bv);
         // off-diagonal sums/differences selected without divergent branches
@@ -135,15 +139,15 @@ __device__ __forceinline__ void geo_flat(const float p[9], const Geo& g, float& 
         // Jacobian: UVMatrix[col][row], inverse2x2 (GS:206-220), multiplyMat2x3WithMat2x2 (GS:222-235)
         const float U00 = g.ou[1] - g.ou[0], U10 = g.ou[2] - g.ou[0];
         const float U01 = g.ov[1] - g.ov[0], U11 = g.ov[2] - g.ov[0];
-        const float det = U00 * U11 - U01 * U10;
+        const float det = fma_(U00, U11, -(U01 * U10));
         const float invDet = det != 0.0f ? fast_rcp(det) : 0.0f;   // inverse2x2 returns mat2(0) for det == 0
         const float I00 = U11 * invDet, I10 = -U10 * invDet, I01 = -U01 * invDet, I11 = U00 * invDet;
         const float v0x = p[3] - p[0], v0y = p[4] - p[1], v0z = p[5] - p[2];
         const float v1x = p[6] - p[0], v1y = p[7] - p[1], v1z = p[8] - p[2];
-        const float jux = v0x * I00 + v1x * I01, juy = v0y * I00 + v1y * I01, juz = v0z * I00 + v1z * I01;
-        const float jvx = v0x * I10 + v1x * I11, jvy = v0y * I10 + v1y * I11, jvz = v0z * I10 + v1z * I11;
-        sx = fast_sqrt(jux * jux + juy * juy + juz * juz);
-        sy = fast_sqrt(jvx * jvx + jvy * jvy + jvz * jvz);
+        const float jux = fma_(v1x, I01, v0x * I00), juy = fma_(v1y, I01, v0y * I00), juz = fma_(v1z, I01, v0z * I00);
+        const float jvx = fma_(v1x, I11, v0x * I10), jvy = fma_(v1y, I11, v0y * I10), jvz = fma_(v1z, I11, v0z * I10);
+        sx = fast_sqrt(dot3_(jux, juy, juz, jux, juy, juz));
+        sy = fast_sqrt(dot3_(jvx, jvy, jvz, jvx, jvy, jvz));
     }
 }
 
@@ -290,16 +294,14 @@ struct TriShade {
 static_assert(sizeof(TriShade) == 80, "TriShade must be five float4");
 
 __device__ __forceinline__ float lod_from_grad(float fw, float fh, float dudx, float dvdx, float dudy, float dvdy) {
-#pragma clang fp contract(fast)
     const float sx = dudx * fw, tx = dvdx * fh, sy = dudy * fw, ty = dvdy * fh;
-    const float r2 = fmaxf(sx * sx + tx * tx, sy * sy + ty * ty);
+    const float r2 = fmaxf(fma_(tx, tx, sx * sx), fma_(ty, ty, sy * sy));
     return 0.5f * fast_log2(r2);   // log2(sqrt(r2))
 }
 
 // p: positions; b0/b1: uv planes of the triangle.  Needs a valid Raster.
 __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, const MeshParams* __restrict__ mp,
                                                 float4 b0, float2 b1, TriShade& ts) {
-#pragma clang fp contract(fast)
     // The barycentrics feed the texture coordinates, where any rounding difference is amplified by the
     // texture size and contrast: they follow the oracle's exact operation sequence
     // lambda_i = float(E_i) * (1 / float(area2)) with exact integer E_i (DECISION-class arithmetic).
@@ -324,8 +326,8 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
     if (hasA || hasN || hasM) {
         // UV is affine in window space (all w = 1, GS:439): d(lambda_i)/dx = A_i, d/dy = B_i per pixel
         const float du1 = b0.z - b0.x, du2 = b1.x - b0.x, dv1 = b0.w - b0.y, dv2 = b1.y - b0.y;
-        const float dudx = A1 * du1 + A2 * du2, dvdx = A1 * dv1 + A2 * dv2;
-        const float dudy = B1 * du1 + B2 * du2, dvdy = B1 * dv1 + B2 * dv2;
+        const float dudx = fma_(A2, du2, A1 * du1), dvdx = fma_(A2, dv2, A1 * dv1);
+        const float dudy = fma_(B2, du2, B1 * du1), dvdy = fma_(B2, dv2, B1 * dv1);
         if (hasA) ts.lod0 = lod_from_grad((float)ta->w, (float)ta->h, dudx, dvdx, dudy, dvdy);
         if (hasN) ts.lod1 = (hasA && tn->w == ta->w && tn->h == ta->h) ? ts.lod0
                           : lod_from_grad((float)tn->w, (float)tn->h, dudx, dvdx, dudy, dvdy);
@@ -391,19 +393,17 @@ __device__ __forceinline__ void tex_state(const TexDesc* __restrict__ t, float u
 
 template <int NCH>  // number of leading channels wanted (RGBA byte order)
 __device__ __forceinline__ void tap_fetch(const uint32_t* __restrict__ texels, const TexTap& t, float out[NCH]) {
-#pragma clang fp contract(fast)
     const uint32_t t00 = texels[t.o00], t10 = texels[t.o10], t01 = texels[t.o01], t11 = texels[t.o11];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const float c00 = (float)((t00 >> (8 * ch)) & 255u), c10 = (float)((t10 >> (8 * ch)) & 255u);
         const float c01 = (float)((t01 >> (8 * ch)) & 255u), c11 = (float)((t11 >> (8 * ch)) & 255u);
-        out[ch] = t.w00 * c00 + t.w10 * c10 + t.w01 * c01 + t.w11 * c11;
+        out[ch] = fma_(t.w11, c11, fma_(t.w01, c01, fma_(t.w10, c10, t.w00 * c00)));
     }
 }
 
 template <int NCH>
 __device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, const TexState& st, float out[NCH]) {
-#pragma clang fp contract(fast)
     float lo[NCH];
     tap_fetch<NCH>(texels, st.lo, lo);
     if (__ballot(st.f != 0.0f) != 0ull) {
@@ -411,7 +411,7 @@ __device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, 
         tap_fetch<NCH>(texels, st.hi, hi);
         const float f = st.f, nf = 1.0f - st.f;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) out[ch] = (nf * lo[ch] + f * hi[ch]) * kUnorm8;
+        for (int ch = 0; ch < NCH; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
     } else {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) out[ch] = lo[ch] * kUnorm8;
@@ -424,7 +424,6 @@ struct __attribute__((packed, aligned(4))) ComboPair { uint32_t v[6]; };  // {A,
 // un-normalised bilinear sums of one level for the nine channels we need:
 // albedo rgba (0-3), normal rgb (4-6), roughness = MR.g (7), metallic = MR.b (8)
 __device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, uint32_t W, uint32_t H, float uf, float vf, float out[9]) {
-#pragma clang fp contract(fast)
     float up, vp;
     {   // exact oracle sequence (no FMA), as in tex_tap
 #pragma clang fp contract(off)
@@ -452,8 +451,8 @@ __device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, ui
 #endif
     const float na = 1.0f - a, nb = 1.0f - b;
     const float w00 = na * nb, w10 = a * nb, w01 = na * b, w11 = a * b;
-#define M2S_CH(word, sh) (w00 * (float)((r0.v[word] >> (sh)) & 255u) + w10 * (float)((r0.v[(word) + 3] >> (sh)) & 255u) + \
-                          w01 * (float)((r1.v[word] >> (sh)) & 255u) + w11 * (float)((r1.v[(word) + 3] >> (sh)) & 255u))
+#define M2S_CH(word, sh) fma_(w11, (float)((r1.v[(word) + 3] >> (sh)) & 255u), fma_(w01, (float)((r1.v[word] >> (sh)) & 255u), \
+                          fma_(w10, (float)((r0.v[(word) + 3] >> (sh)) & 255u), w00 * (float)((r0.v[word] >> (sh)) & 255u))))
     out[0] = M2S_CH(0, 0); out[1] = M2S_CH(0, 8); out[2] = M2S_CH(0, 16); out[3] = M2S_CH(0, 24);
     out[4] = M2S_CH(1, 0); out[5] = M2S_CH(1, 8); out[6] = M2S_CH(1, 16);
     out[7] = M2S_CH(2, 8); out[8] = M2S_CH(2, 16);
@@ -462,7 +461,6 @@ __device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, ui
 
 __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, const TexDesc* __restrict__ t, float uf, float vf,
                                              float lambda, float out[9]) {
-#pragma clang fp contract(fast)
     const uint32_t nl = t->n_levels, w = t->w, h = t->h;
     const float q = (float)(nl - 1);
     float d = 0.0f, f = 0.0f;
@@ -482,7 +480,7 @@ __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, 
         combo_level(base + off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, hi);
         const float nf = 1.0f - f;
 #pragma unroll
-        for (int ch = 0; ch < 9; ch++) out[ch] = (nf * lo[ch] + f * hi[ch]) * kUnorm8;
+        for (int ch = 0; ch < 9; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
     } else {
 #pragma unroll
         for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] * kUnorm8;
@@ -505,7 +503,6 @@ __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
 // `mp` should be wave-uniform (scalar) for speed; correctness does not depend on it.
 __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, const MeshParams* __restrict__ mp,
                                                const TriShade& ts, float4 rec[6]) {
-#pragma clang fp contract(fast)
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
     const int dx256 = (x - (int)(ts.org & 0xFFFu)) * 256, dy256 = (y - (int)(ts.org >> 12)) * 256;
@@ -540,7 +537,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         U = (b0.x + l1 * (b0.z - b0.x)) + l2 * (b1.x - b0.x);
         V = (b0.y + l1 * (b0.w - b0.y)) + l2 * (b1.y - b0.y);
     }
-#define M2S_LERP(f0, f1, f2) ((f0) + l1 * ((f1) - (f0)) + l2 * ((f2) - (f0)))
+#define M2S_LERP(f0, f1, f2) fma_(l2, (f2) - (f0), fma_(l1, (f1) - (f0), (f0)))
 
     const TexDesc* __restrict__ ta = &mp->tex[0];
     const TexDesc* __restrict__ tn = &mp->tex[1];
@@ -592,16 +589,17 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     if (xn != nullptr) {
         const float Tx = M2S_LERP(d0.x, d1.x, d2.x), Ty = M2S_LERP(d0.y, d1.y, d2.y), Tz = M2S_LERP(d0.z, d1.z, d2.z);
         const float Tw = M2S_LERP(d0.w, d1.w, d2.w);
-        float rx = nrm[0] * 2.0f - 1.0f, ry = nrm[1] * 2.0f - 1.0f, rz = nrm[2] * 2.0f - 1.0f;
-        float inv = fast_rsq(rx * rx + ry * ry + rz * rz);
+        float rx = fma_(nrm[0], 2.0f, -1.0f), ry = fma_(nrm[1], 2.0f, -1.0f), rz = fma_(nrm[2], 2.0f, -1.0f);
+        float inv = fast_rsq(dot3_(rx, ry, rz, rx, ry, rz));
         rx *= inv; ry *= inv; rz *= inv;
-        float bx = Ny * Tz - Nz * Ty, by = Nz * Tx - Nx * Tz, bz = Nx * Ty - Ny * Tx;  // cross(Normal, Tangent.xyz)
-        inv = fast_rsq(bx * bx + by * by + bz * bz) * Tw;
+        // cross(Normal, Tangent.xyz)
+        float bx = fma_(Ny, Tz, -(Nz * Ty)), by = fma_(Nz, Tx, -(Nx * Tz)), bz = fma_(Nx, Ty, -(Ny * Tx));
+        inv = fast_rsq(dot3_(bx, by, bz, bx, by, bz)) * Tw;
         bx *= inv; by *= inv; bz *= inv;
-        inv = fast_rsq(Nx * Nx + Ny * Ny + Nz * Nz);
+        inv = fast_rsq(dot3_(Nx, Ny, Nz, Nx, Ny, Nz));
         const float nnx = Nx * inv, nny = Ny * inv, nnz = Nz * inv;
-        const float wx = Tx * rx + bx * ry + nnx * rz, wy = Ty * rx + by * ry + nny * rz, wz = Tz * rx + bz * ry + nnz * rz;
-        inv = fast_rsq(wx * wx + wy * wy + wz * wz);
+        const float wx = fma_(nnx, rz, fma_(bx, ry, Tx * rx)), wy = fma_(nny, rz, fma_(by, ry, Ty * rx)), wz = fma_(nnz, rz, fma_(bz, ry, Tz * rx));
+        inv = fast_rsq(dot3_(wx, wy, wz, wx, wy, wz));
         ox = wx * inv; oy = wy * inv; oz = wz * inv;
     }
 #undef M2S_LERP
