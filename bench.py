@@ -34,6 +34,7 @@ WORKLOADS = {
     "c3": (289, 2048, 1024),   # BASELINE configs[2] — default
     "c2": (76, 2048, 512),     # SciFiHelmet stand-in (I-2)
     "small": (24, 256, 256),   # CI-sized
+    "c4": ("grid", 1024, 1024),  # Sponza stand-in (I-4): 64 meshes x cube-sphere n=18, 64 materials (single GPU only)
 }
 
 
@@ -102,8 +103,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n, tex, R = WORKLOADS[a.workload]
-    scene = synth.colocated_spheres(world, n, tex)
-    tri_per_mesh = scene.meshes[0].n_triangles
+    if n == "grid":
+        if world > 1:
+            raise SystemExit("workload c4 is a single-GPU diagnostic")
+        scene = synth.sphere_grid(4, n=18, tex_size=tex)
+        tri_per_mesh = scene.n_triangles
+    else:
+        scene = synth.colocated_spheres(world, n, tex)
+        tri_per_mesh = scene.meshes[0].n_triangles
 
     conv = Converter(local_rank)
     conv.set_triangle_range(rank * tri_per_mesh, tri_per_mesh)
@@ -199,8 +206,10 @@ def main():
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
-                                   f"3 procedural {tex}^2 RGBA8 maps, R={R}",
+            "config": {"workload": (f"I-4 64 meshes x cube-sphere n=18 ({tri_per_mesh} triangles), 64 materials with 3 procedural "
+                                    f"{tex}^2 RGBA8 maps each, R={R}") if n == "grid" else
+                                   (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
+                                    f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula"},
             "kernel_ms": {k: v / a.steps for k, v in kms.items()},
@@ -221,7 +230,7 @@ def main():
         if gather:
             res["gather"] = gather
         if not a.no_cpu_baseline and world == 1:
-            one = synth.colocated_spheres(1, n, tex)
+            one = scene if n == "grid" else synth.colocated_spheres(1, n, tex)
             res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds)
         print(json.dumps(res), flush=True)
 

@@ -168,8 +168,9 @@ const char* m2s_io_last_error(void);
 
 /* ---- pipeline selection ------------------------------------------------------------------------ */
 /* AUTO (default): the single-pass fused kernel (k_fused); if the scene holds triangles larger than its
- * in-workgroup budget (> 32 pixel rows or > 2048 fragments) the call re-runs the multi-pass pipeline,
- * which balances work by output range and handles any triangle size.  MULTIPASS forces the latter.
+ * in-workgroup budget (> 16 pixel rows or > 96 fragments) the call re-runs the multi-pass pipeline,
+ * which balances work by output range and handles any triangle size (and later conversions of the same scene
+ * at the same R go straight to it).  MULTIPASS forces the latter.
  * Both produce bit-identical output. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1 };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);

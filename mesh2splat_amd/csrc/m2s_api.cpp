@@ -51,6 +51,7 @@ struct m2s_ctx {
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
+    uint32_t multipass_R = 0;               // AUTO: R at which this scene turned out to need the multi-pass pipeline
 
     // output
     void* d_records = nullptr;
@@ -100,6 +101,7 @@ static void free_scene(m2s_ctx* c) {
     if (c->d_chain) (void)hipFree(c->d_chain);
     c->d_chain = nullptr;
     c->sized_R = 0;
+    c->multipass_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
     c->d_cnt = c->d_off = c->d_partials = nullptr;
@@ -428,7 +430,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
 
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
-    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !counted) {
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !counted && c->multipass_R != R) {
         // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
         // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
         // counter and its two status words straight into pinned host memory.
@@ -443,6 +445,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
         if (err) return fail(c, M2S_ERR_HIP, "fused kernel: look-back chain timed out");
         done = (any_big == 0);
+        if (!done) c->multipass_R = R;   // remember: the next conversion of this scene at this R skips the fused attempt
     }
     if (!done) {
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);

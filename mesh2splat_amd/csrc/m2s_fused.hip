@@ -7,7 +7,7 @@
 //   triangle phase  (1 thread / triangle, 256 triangles / workgroup)
 //       coalesced 36 B position load -> GS setup -> exact coverage:
 //         * bbox <= 8x8 px : 64-bit coverage mask from incremental int32 edge functions
-//         * <= 32 rows     : closed-form row spans
+//         * <= 16 rows, <= 96 fragments : closed-form row spans
 //         * larger         : counted wave-cooperatively, emission deferred ("big" triangles)
 //       per-triangle fragment constants (edge functions, 1/area, Scale, Quaternion, LODs) -> LDS
 //   ordering        workgroup scan of the counts + decoupled look-back over a chain of 64-bit
@@ -30,7 +30,8 @@
 
 namespace m2s {
 
-constexpr uint32_t kBigCount = 2048;       // triangles with more fragments are deferred
+constexpr uint32_t kBigCount = 96;         // triangles with more fragments, or more than kFusedRows pixel rows, are
+constexpr int kFusedRows = 16;             // only counted here and emitted by the multi-pass pipeline
 constexpr uint32_t kSpinLimit = 1u << 22;  // look-back polls before giving up (~ seconds)
 
 // chain word = flag(2) | epoch(16) | value(46).  The epoch changes with every launch, so words left over
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                 e0 += by0; e1 += by1; e2 += by2;
             }
             cnt = (uint32_t)__popcll(mask);
-        } else if (rows <= kRowsThread) {
+        } else if (rows <= kFusedRows) {
             kind = kMedium;
             for (int y = rs.y0; y <= rs.y1; ++y) {
                 int xa, xb;
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         }
     }
     {   // big triangles spanning many rows: counted by the whole wave, one row per lane
-        unsigned long long bigm = __ballot(kind == kBig && rows > kRowsThread);
+        unsigned long long bigm = __ballot(kind == kBig && rows > kFusedRows);
         while (bigm) {
             const int src = __ffsll((long long)bigm) - 1;
             bigm &= bigm - 1;

@@ -129,15 +129,15 @@ __global__ void __launch_bounds__(kBlock) k_count(SceneDev sc, uint32_t R, uint3
         if (valid) ok = setup_raster_for(sc, t, m0, uniform_mesh, R, rs);
         const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
         uint32_t c = 0;
-        if (ok && rows <= kRowsThread) {
+        if (ok && rows <= kRowsCount) {
             for (int y = rs.y0; y <= rs.y1; ++y) {
                 int xa, xb;
                 row_span(rs, y, xa, xb);
                 c += (uint32_t)max(xb - xa + 1, 0);
             }
         }
-        // triangles spanning many rows: the whole wave counts one triangle, one row per lane
-        unsigned long long big = __ballot(ok && rows > kRowsThread);
+        // triangles spanning more rows: the whole wave counts one triangle, one row per lane
+        unsigned long long big = __ballot(ok && rows > kRowsCount);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
