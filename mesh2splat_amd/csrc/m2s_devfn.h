@@ -421,9 +421,13 @@ __device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, 
 // ---- combo path -----------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) ComboPair { uint32_t v[6]; };  // {A,N,M} of texel i and of texel i+1
 
-// un-normalised bilinear sums of one level for the nine channels we need:
-// albedo rgba (0-3), normal rgb (4-6), roughness = MR.g (7), metallic = MR.b (8)
-__device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, uint32_t W, uint32_t H, float uf, float vf, float out[9]) {
+// Address + weights of one level's footprint in the combo layout.
+struct ComboTap {
+    uint32_t o0, o1;   // dword offsets of the two row pairs (texel i0 and its right neighbour, rows j0 and j1)
+    float w00, w10, w01, w11;
+};
+
+__device__ __forceinline__ void combo_tap(uint32_t level_off, uint32_t W, uint32_t H, float uf, float vf, ComboTap& t) {
     float up, vp;
     {   // exact oracle sequence (no FMA), as in tex_tap
 #pragma clang fp contract(off)
@@ -438,21 +442,22 @@ __device__ __forceinline__ void combo_level(const uint32_t* __restrict__ lvl, ui
     j0 = j0 < 0 ? j0 + (int)H : j0;
     j1 = j1 >= (int)H ? j1 - (int)H : j1;
     const uint32_t stride = W + 1;
-#ifdef M2S_ABL_X4ONLY   // debug ablation: one 16-byte access per row instead of 24 bytes (x4 + x2 to the same line)
-    struct __attribute__((packed, aligned(4))) U4 { uint32_t v[4]; };
-    const U4 q0 = *reinterpret_cast<const U4*>(lvl + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u);
-    const U4 q1 = *reinterpret_cast<const U4*>(lvl + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u);
-    ComboPair r0, r1;
-    r0.v[0] = q0.v[0]; r0.v[1] = q0.v[1]; r0.v[2] = q0.v[2]; r0.v[3] = q0.v[3]; r0.v[4] = q0.v[1]; r0.v[5] = q0.v[2];
-    r1.v[0] = q1.v[0]; r1.v[1] = q1.v[1]; r1.v[2] = q1.v[2]; r1.v[3] = q1.v[3]; r1.v[4] = q1.v[1]; r1.v[5] = q1.v[2];
+#ifdef M2S_ABL_COHERENT   // debug ablation: perfectly coalesced texel addresses (wrong results, timing only)
+    t.o0 = level_off + ((threadIdx.x & 63u) * 6u + (blockIdx.x & 31u) * 768u) % 30000u;
+    t.o1 = t.o0 + 384u + (uint32_t)(i0 + j0 + j1) * 0u + stride * 0u;
 #else
-    const ComboPair r0 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u);
-    const ComboPair r1 = *reinterpret_cast<const ComboPair*>(lvl + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u);
+    t.o0 = level_off + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u;
+    t.o1 = level_off + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u;
 #endif
     const float na = 1.0f - a, nb = 1.0f - b;
-    const float w00 = na * nb, w10 = a * nb, w01 = na * b, w11 = a * b;
-#define M2S_CH(word, sh) fma_(w11, (float)((r1.v[(word) + 3] >> (sh)) & 255u), fma_(w01, (float)((r1.v[word] >> (sh)) & 255u), \
-                          fma_(w10, (float)((r0.v[(word) + 3] >> (sh)) & 255u), w00 * (float)((r0.v[word] >> (sh)) & 255u))))
+    t.w00 = na * nb; t.w10 = a * nb; t.w01 = na * b; t.w11 = a * b;
+}
+
+// un-normalised bilinear sums for the nine channels we need:
+// albedo rgba (0-3), normal rgb (4-6), roughness = MR.g (7), metallic = MR.b (8)
+__device__ __forceinline__ void combo_filter(const ComboPair& r0, const ComboPair& r1, const ComboTap& t, float out[9]) {
+#define M2S_CH(word, sh) fma_(t.w11, (float)((r1.v[(word) + 3] >> (sh)) & 255u), fma_(t.w01, (float)((r1.v[word] >> (sh)) & 255u), \
+                          fma_(t.w10, (float)((r0.v[(word) + 3] >> (sh)) & 255u), t.w00 * (float)((r0.v[word] >> (sh)) & 255u))))
     out[0] = M2S_CH(0, 0); out[1] = M2S_CH(0, 8); out[2] = M2S_CH(0, 16); out[3] = M2S_CH(0, 24);
     out[4] = M2S_CH(1, 0); out[5] = M2S_CH(1, 8); out[6] = M2S_CH(1, 16);
     out[7] = M2S_CH(2, 8); out[8] = M2S_CH(2, 16);
@@ -473,15 +478,26 @@ __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, 
     const uint32_t off0 = l0 == 0 ? 0u : l0 == 1 ? c1 : l0 == 2 ? c2 : l0 == 3 ? c3 : c4;
     const uint32_t off1 = l1 == 0 ? 0u : l1 == 1 ? c1 : l1 == 2 ? c2 : l1 == 3 ? c3 : c4;
     const uint32_t* __restrict__ base = mp->combo.texels;
+    ComboTap tlo, thi;
+    combo_tap(off0, max(1u, w >> l0), max(1u, h >> l0), uf, vf, tlo);
+    const bool two = __ballot(f != 0.0f) != 0ull;   // wave-uniform: does any lane blend two levels?
+    // ALL row reads of both levels are requested before the first one is consumed: one memory round trip
+    // instead of two (measured: the texel phase was 73 % of a strip with the levels fetched back to back)
+    const ComboPair a0 = *reinterpret_cast<const ComboPair*>(base + tlo.o0);
+    const ComboPair a1 = *reinterpret_cast<const ComboPair*>(base + tlo.o1);
     float lo[9];
-    combo_level(base + off0, max(1u, w >> l0), max(1u, h >> l0), uf, vf, lo);
-    if (__ballot(f != 0.0f) != 0ull) {
+    if (two) {
+        combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
+        const ComboPair b0 = *reinterpret_cast<const ComboPair*>(base + thi.o0);
+        const ComboPair b1 = *reinterpret_cast<const ComboPair*>(base + thi.o1);
+        combo_filter(a0, a1, tlo, lo);
         float hi[9];
-        combo_level(base + off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, hi);
+        combo_filter(b0, b1, thi, hi);
         const float nf = 1.0f - f;
 #pragma unroll
         for (int ch = 0; ch < 9; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
     } else {
+        combo_filter(a0, a1, tlo, lo);
 #pragma unroll
         for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] * kUnorm8;
     }
@@ -501,8 +517,9 @@ __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
 
 // The per-fragment part of rasteriser + FS (converterFS.glsl:44-104) for pixel (x,y) of triangle t.
 // `mp` should be wave-uniform (scalar) for speed; correctness does not depend on it.
+// `stamps` (debug timing builds only, else nullptr and folded away): three s_memtime slots.
 __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, const MeshParams* __restrict__ mp,
-                                               const TriShade& ts, float4 rec[6]) {
+                                               const TriShade& ts, float4 rec[6], unsigned long long* stamps = nullptr) {
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
     const int dx256 = (x - (int)(ts.org & 0xFFFu)) * 256, dy256 = (y - (int)(ts.org >> 12)) * 256;
@@ -545,6 +562,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     const uint32_t* xa = ta->texels;   // (non-const only for the debug ablation switch below)
     const uint32_t* xn = tn->texels;
     const uint32_t* xm = tm->texels;
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();   // uv planes arrived, U/V computed
     const float uf = frac_repeat(U), vf = frac_repeat(V);
     float col[4] = { 1.0f, 1.0f, 1.0f, 1.0f };   // FS:53-62
     float nrm[3] = { 0.0f, 0.0f, 1.0f };
@@ -581,6 +599,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
             metal = s[2]; rough = s[1];
         }
     }
+    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();   // texels arrived and filtered
     // the remaining varyings: by now their loads have had the whole texture fetch to arrive
     const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
     const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
@@ -603,6 +622,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         ox = wx * inv; oy = wy * inv; oz = wz * inv;
     }
 #undef M2S_LERP
+    if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();   // interpolation + TBN done
     // FS:98-103
     rec[0] = make_float4(Pxw, Pyw, Pzw, 1.0f);
     rec[1] = make_float4(col[0] * mp->color[0], col[1] * mp->color[1], col[2] * mp->color[2], col[3] * mp->color[3]);

@@ -141,7 +141,7 @@ __device__ __noinline__ unsigned long long lookback(const unsigned long long* ch
 
 #ifdef M2S_TIMING
 // debug build only: per-wave phase timestamps (s_memtime), read back by tools/fused_timing.py
-constexpr int kTimingSlots = 12, kTimingWaves = 16384;
+constexpr int kTimingSlots = 16, kTimingWaves = 16384;
 __device__ unsigned long long g_timing[kTimingSlots * kTimingWaves];
 #define M2S_STAMP(i) do { if (lane == 0 && wid < kTimingWaves) g_timing[(i) * kTimingWaves + wid] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -363,13 +363,24 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                 // wave inside one mesh (the common case): descriptors are wave-uniform -> SGPRs, scalar loads.
                 // wave straddling a mesh boundary: per-lane descriptor pointer.
                 const MeshParams* mp = uniform_mesh ? sc.meshes + m0 : sc.meshes + mymesh;
+#ifdef M2S_TIMING
+                unsigned long long st3[3] = { 0, 0, 0 };
+                shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), mp, ts, rec, st3);
+                if (win == 0 && e0 == 0 && lane == 0 && wid < kTimingWaves)
+                    for (int k = 0; k < 3; ++k) g_timing[(12 + k) * kTimingWaves + wid] = st3[k];
+#else
                 shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), mp, ts, rec);
+#endif
             }
             if (win == 0 && e0 == 0) M2S_STAMP(6);  // first strip shaded
             if (!have_base) resolve_base();
             if (win == 0 && e0 == 0) M2S_STAMP(7);  // base resolved
             const unsigned long long oidx = base + skipped + win + e;
+#ifdef M2S_DIRECT_STORE   // debug A/B: per-lane strided record stores instead of LDS-staged coalesced runs
+            if (false) {
+#else
             if (!anybig) {
+#endif
                 // the strip's records are consecutive in the output: stage half a wave at a time, then
                 // 16 B/lane fully coalesced stores (3 KiB contiguous per half)
                 const unsigned long long o0 = base + win + e0;

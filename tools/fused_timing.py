@@ -22,7 +22,7 @@ conv.set_profiling(True)
 n = conv.convert(wl[2])
 print("gaussians", n, "kernel ms", conv.last_kernel_ms())
 L = _lib.load()
-W, S = 16384, 12
+W, S = 16384, 16
 buf = np.zeros(S * W, np.uint64)
 rc = L.m2s_debug_read_timing(buf.ctypes.data_as(C.c_void_p), C.c_size_t(S * W))
 assert rc == 0
@@ -39,6 +39,10 @@ life = (t[8] - t[0]).astype(np.float64)
 print(f"{'wave lifetime':28s} median {np.median(life):9.0f}  mean {life.mean():9.0f}  p90 {np.percentile(life, 90):9.0f}")
 start = t[0] - t0
 print("wave start time percentiles (ticks):", [int(np.percentile(start, q)) for q in (1, 25, 50, 75, 99)])
+sub = [("  strip0: LDS + uv loads -> U,V", t[12] - t[5]), ("  strip0: texel fetch + filter", t[13] - t[12]), ("  strip0: interp + TBN", t[14] - t[13])]
+for nm, d in sub:
+    d = d.astype(np.float64)
+    print(f"{nm:34s} median {np.median(d):9.0f}  mean {d.mean():9.0f}  p90 {np.percentile(d, 90):9.0f}")
 print("frags/wave mean", t[9].mean(), "xcc ids", np.unique(t[10]))
 # concurrency estimate: sum of lifetimes / span
 print("avg concurrent waves", life.sum() / (t[8].max() - t0))
