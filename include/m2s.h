@@ -167,10 +167,11 @@ void m2s_free_records(m2s_gaussian* records);
 const char* m2s_io_last_error(void);
 
 /* ---- pipeline selection ------------------------------------------------------------------------ */
-/* AUTO (default): the single-pass fused kernel (k_fused); if the scene holds triangles larger than its
- * in-workgroup budget (> 16 pixel rows or > 96 fragments) the call re-runs the multi-pass pipeline,
- * which balances work by output range and handles any triangle size (and later conversions of the same scene
- * at the same R go straight to it).  MULTIPASS forces the latter.
+/* AUTO (default): the single-pass fused kernel (k_fused) emits every triangle that fits its in-workgroup
+ * budget (<= 16 pixel rows and <= 96 fragments); larger triangles only reserve their slice of the ordered
+ * output there and are emitted by a second kernel (k_emit_big, one workgroup per 1024-fragment chunk); scenes
+ * DOMINATED by such triangles are handed to the multi-pass pipeline instead (decision remembered per scene, R).
+ * MULTIPASS forces the count -> scan -> offsets -> emit pipeline (output-range balanced, any triangle size).
  * Both produce bit-identical output. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1 };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);

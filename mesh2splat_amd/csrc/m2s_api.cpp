@@ -47,11 +47,13 @@ struct m2s_ctx {
     size_t start_cap = 0;
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;  // pinned: [0] = fragment counter, [1] = status words of the fused kernel
-    unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per workgroup
+    unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
+    BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
+    uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions
+    uint32_t multipass_R = 0;               // AUTO: R at which this scene turned out to be dominated by big triangles
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
-    uint32_t multipass_R = 0;               // AUTO: R at which this scene turned out to need the multi-pass pipeline
 
     // output
     void* d_records = nullptr;
@@ -99,7 +101,9 @@ static void free_scene(m2s_ctx* c) {
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_chain) (void)hipFree(c->d_chain);
-    c->d_chain = nullptr;
+    if (c->d_biglist) (void)hipFree(c->d_biglist);
+    if (c->d_bigmeta) (void)hipFree(c->d_bigmeta);
+    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr;
     c->sized_R = 0;
     c->multipass_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
@@ -329,6 +333,9 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     HIPCHK(c, hipMalloc((void**)&c->d_partials, std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_chain, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(c->d_chain, 0, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMalloc((void**)&c->d_biglist, np * sizeof(BigItem)));
+    HIPCHK(c, hipMalloc((void**)&c->d_bigmeta, 4 * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries
     c->has_scene = true;
     c->last_total = c->last_stored = 0;
@@ -437,15 +444,37 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         c->h_total[0] = 0;
         c->h_total[1] = 0;
         if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-        launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch, st);
+        launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
+                     c->d_biglist, c->d_bigmeta, st);
         if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
         if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
         const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
         if (err) return fail(c, M2S_ERR_HIP, "fused kernel: look-back chain timed out");
-        done = (any_big == 0);
-        if (!done) c->multipass_R = R;   // remember: the next conversion of this scene at this R skips the fused attempt
+        done = true;
+        if (any_big) {
+            uint32_t meta[4] = { 0, 0, 0, 0 };
+            HIPCHK(c, hipMemcpyAsync(meta, c->d_bigmeta, sizeof meta, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, sizeof meta, st));   // restore the "zero between conversions" invariant
+            const uint64_t total_now = c->h_total[0];
+            if (meta[0] > 256 && (uint64_t)meta[2] * 8 > total_now) {
+                // Scene dominated by mid-size / big triangles (e.g. a coarse mesh at high density): one workgroup per
+                // triangle chunk would be mostly empty.  The output-partitioned multi-pass pipeline packs them densely;
+                // remember the decision so that later conversions of this scene at this R go straight to it.
+                c->multipass_R = R;
+                done = false;
+            } else {
+                // second stage: emit exactly the deferred triangles, one workgroup per 1024-fragment chunk
+                if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+                launch_emit_big(sc, R, c->d_biglist, meta[0], meta[1], limit, d_out, st);
+                if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
+            }
+        }
     }
     if (!done) {
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);

@@ -55,6 +55,12 @@ struct MeshParams {
     ComboDesc combo;
 };
 
+// One triangle deferred by the fused kernel (too large for its in-workgroup budget): emitted by k_emit_big.
+struct BigItem {
+    uint32_t t, cnt;           // local triangle index, fragment count
+    unsigned long long off;    // index of its first record in the canonically ordered output
+};
+
 struct SceneDev {
     TriPlanes tri;
     const MeshParams* meshes;
@@ -79,7 +85,10 @@ void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
 
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                  unsigned long long* total, uint32_t* status /* [0]=n_big [1]=error */, uint32_t epoch, hipStream_t st);
+                  unsigned long long* total, uint32_t* status /* [0]=any big [1]=error */, uint32_t epoch, BigItem* biglist,
+                  uint32_t* bigmeta /* [0]=count [1]=max fragments [2]=sum of fragments */, hipStream_t st);
+void launch_emit_big(const SceneDev& sc, uint32_t R, const BigItem* biglist, uint32_t n_big, uint32_t max_cnt, uint64_t limit,
+                     float4* out, hipStream_t st);
 
 size_t sort_temp_bytes(uint32_t n);
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,

@@ -172,7 +172,8 @@ struct WaveLds {
 __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                   unsigned long long limit, float4* __restrict__ out,
                                                   unsigned long long* __restrict__ total_out,
-                                                  uint32_t* __restrict__ status /* [0]=n_big, [1]=error */, uint32_t epoch) {
+                                                  uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
+                                                  BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta) {
     __shared__ WaveLds lds_all[kBlock / 64];
 #ifdef M2S_LDS_PAD   // debug: lower the occupancy artificially
     __shared__ volatile uint32_t lds_pad[M2S_LDS_PAD / 4];
@@ -315,10 +316,21 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         L.tskip[lane] = (uint32_t)(toff - ctoff);
     }
     L.park[lane] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), ctoff | (cntc << 18) | ((uint32_t)kind << 30), org);
-    // status lives in host-mapped memory: plain (idempotent) system-scope stores, no PCIe atomics needed
-    if (anybig && lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-
-    M2S_STAMP(4);  // TriShade in LDS
+    // Deferred (big) triangles: they own their slice of the ordered output (it is part of this wave's total),
+    // but are emitted by k_emit_big.  Needs the global base, so these (rare) waves resolve it right away.
+    if (anybig) {
+        if (!have_base) resolve_base();
+        if (kind == kBig) {
+            const uint32_t slot = atomicAdd(&bigmeta[0], 1u);
+            atomicMax(&bigmeta[1], cnt);
+            atomicAdd(&bigmeta[2], cnt);
+            BigItem it;
+            it.t = t; it.cnt = cnt; it.off = base + toff;
+            biglist[slot] = it;
+        }
+        // status lives in host-mapped memory: plain (idempotent) system-scope stores, no PCIe atomics needed
+        if (lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // ---------------- fragment phase, in windows of kWaveEntryCap ----------------
 #ifndef M2S_ABLATE_NOFRAG
     for (uint32_t win = 0; win < total_c; win += kWaveEntryCap) {
@@ -426,11 +438,11 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
 }
 
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                  unsigned long long* total, uint32_t* status, uint32_t epoch, hipStream_t st) {
+                  unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
     uint32_t nb = n_fused_blocks(sc.n_tri);
     if (!nb) return;
     nb = (nb + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);  // whole XCD runs; surplus workgroups exit at once
-    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status, epoch & 0xFFFFu);
+    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status, epoch & 0xFFFFu, biglist, bigmeta);
 }
 
 #ifdef M2S_TIMING

@@ -359,4 +359,103 @@ void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint
                        (unsigned long long)limit, out);
 }
 
+// ============================================================================================
+// k_emit_big: the second stage of the AUTO pipeline.  One workgroup per (deferred triangle, chunk of
+// kEmitF fragments): per-row spans of the whole triangle -> LDS prefix -> the chunk's fragments located
+// by binary search -> the same per-fragment code and staged stores as k_emit.  A 4096 x 4096 px triangle
+// becomes 8192 equal work items.
+// ============================================================================================
+__global__ void __launch_bounds__(kBlock) k_emit_big(SceneDev sc, uint32_t R, const BigItem* __restrict__ list, uint32_t n_big,
+                                                     unsigned long long limit, float4* __restrict__ out) {
+    __shared__ uint2 entries[kEmitF];
+    __shared__ float4 stage[kBlock * kStageStride];
+    __shared__ uint32_t rowoff[4096 + 1];   // exclusive prefix of the row lengths (R <= 4096 rows)
+    __shared__ uint16_t rowxa[4096];
+    __shared__ uint32_t wsum[kBlock / 64];
+    if (blockIdx.y >= n_big) return;
+    const BigItem item = list[blockIdx.y];
+    const uint32_t f0 = blockIdx.x * kEmitF;
+    if (f0 >= item.cnt) return;
+    const uint32_t f1 = min(f0 + (uint32_t)kEmitF, item.cnt);
+    if (item.off + f0 >= limit) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = find_mesh(sc, sc.tri_first + item.t);
+    Raster rs;
+    if (!setup_raster_for(sc, item.t, m, true, R, rs)) return;   // cannot happen: the fused kernel counted it
+    const int rows = rs.y1 - rs.y0 + 1;
+    // per-row lengths: thread i owns rows [16 i, 16 i + 16)
+    uint32_t local[16], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = threadIdx.x * 16 + k;
+        uint32_t len = 0;
+        if (r < rows) {
+            int xa, xb;
+            row_span(rs, rs.y0 + r, xa, xb);
+            len = (uint32_t)max(xb - xa + 1, 0);
+            rowxa[r] = (uint16_t)xa;
+        }
+        local[k] = len;
+        tsum += len;
+    }
+    const uint32_t incl = wave_incl_scan(tsum, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - tsum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = threadIdx.x * 16 + k;
+        if (r < rows) rowoff[r] = run;
+        run += local[k];
+    }
+    if (threadIdx.x == kBlock - 1) rowoff[rows] = run;   // == item.cnt
+    __syncthreads();
+    // the chunk's fragments: largest r with rowoff[r] <= f (rows of length 0 share an offset with their successor)
+    for (uint32_t f = f0 + threadIdx.x; f < f1; f += kBlock) {
+        int lo = 0, hi = rows;   // invariant: rowoff[lo] <= f < rowoff[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rowoff[mid] <= f) lo = mid; else hi = mid;
+        }
+        const uint32_t x = (uint32_t)rowxa[lo] + (f - rowoff[lo]);
+        entries[f - f0] = make_uint2(item.t, ((uint32_t)(rs.y0 + lo) << 16) | x);
+    }
+    __syncthreads();
+    const uint32_t n_here = f1 - f0;
+    const unsigned long long base = item.off + f0;
+    for (uint32_t e0 = 0; e0 < n_here; e0 += kBlock) {
+        const uint32_t e = e0 + threadIdx.x;
+        if (e < n_here) {
+            const uint2 en = entries[e];
+            float4 rec[6];
+            shade_fragment(sc, en.x, (int)(en.y & 0xFFFFu), (int)(en.y >> 16), m, true, R, rec);
+#pragma unroll
+            for (int k = 0; k < 6; k++) stage[threadIdx.x * kStageStride + k] = rec[k];
+        }
+        __syncthreads();
+        uint32_t nrec = min((uint32_t)kBlock, n_here - e0);
+        const unsigned long long o0 = base + e0;
+        if (o0 >= limit) nrec = 0;
+        else if (limit - o0 < nrec) nrec = (uint32_t)(limit - o0);
+        float4* __restrict__ dst = out + o0 * 6;
+        for (uint32_t q = threadIdx.x; q < nrec * 6; q += kBlock) {
+            const uint32_t r = q / 6, k = q - r * 6;
+            dst[q] = stage[r * kStageStride + k];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_emit_big(const SceneDev& sc, uint32_t R, const BigItem* biglist, uint32_t n_big, uint32_t max_cnt, uint64_t limit,
+                     float4* out, hipStream_t st) {
+    if (!n_big || !max_cnt) return;
+    const uint32_t chunks = (max_cnt + kEmitF - 1) / kEmitF;
+    // grid.y is limited to 65535: loop over slabs of triangles
+    for (uint32_t y0 = 0; y0 < n_big; y0 += 65535u) {
+        const uint32_t ny = min(65535u, n_big - y0);
+        hipLaunchKernelGGL(k_emit_big, dim3(chunks, ny), dim3(kBlock), 0, st, sc, R, biglist + y0, ny, (unsigned long long)limit, out);
+    }
+}
+
 }  // namespace m2s
