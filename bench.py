@@ -52,12 +52,28 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, further limited by a cgroup CPU quota if any."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(scene_one_mesh, R, budget_s):
     """Oracle (CPU port of the reference path) on the host cores: same workload, same timed region as the
     GPU (geometry + textures + mip chains resident, output buffer allocated -> records + count)."""
     from oracle import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     prep = oracle.PreparedScene(scene_one_mesh)
     total, out = prep.convert(R, n_threads=cores)             # warm-up, sizes the output buffer
     res = {}

@@ -451,8 +451,14 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
         if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
         const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
-        if (err) return fail(c, M2S_ERR_HIP, "fused kernel: look-back chain timed out");
         done = true;
+        if (err) {
+            // The bounded look-back spin gave up (never observed; would need a dispatcher that starves earlier
+            // workgroups).  Degrade to the multi-pass pipeline, which has no inter-workgroup dependency.
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
+            c->multipass_R = R;
+            done = false;
+        } else
         if (any_big) {
             uint32_t meta[4] = { 0, 0, 0, 0 };
             HIPCHK(c, hipMemcpyAsync(meta, c->d_bigmeta, sizeof meta, hipMemcpyDeviceToHost, st));

@@ -98,6 +98,14 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
 //    interpolation, texture filtering, normal mapping): FMA contraction and the hardware
 //    reciprocal / rsqrt / sqrt / log2 (<= 1 ulp each); agrees with the oracle to ~1e-6 relative,
 //    tolerance 1e-4.
+// (float)int64 with a single rounding, for |v| < 2^53: the two halves are exact in fp64, their sum is exact,
+// the final fp64 -> fp32 conversion rounds once (== the oracle's (float)E).  5 instructions instead of the
+// compiler's ~12-instruction integer normalisation sequence.
+__device__ __forceinline__ float i64_to_f32(long long v) {
+    const double d = __builtin_fma((double)(int)(v >> 32), 4294967296.0, (double)(unsigned)v);
+    return (float)d;
+}
+
 // Explicit fused multiply-add: VALUE arithmetic spells out every FMA instead of leaving contraction to the
 // compiler, so that the fused and the multi-pass pipelines (two inlining contexts of the same functions)
 // execute the same operations and produce bit-identical records.
@@ -485,21 +493,23 @@ __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, 
     // instead of two (measured: the texel phase was 73 % of a strip with the levels fetched back to back)
     const ComboPair a0 = *reinterpret_cast<const ComboPair*>(base + tlo.o0);
     const ComboPair a1 = *reinterpret_cast<const ComboPair*>(base + tlo.o1);
-    float lo[9];
     if (two) {
         combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
         const ComboPair b0 = *reinterpret_cast<const ComboPair*>(base + thi.o0);
         const ComboPair b1 = *reinterpret_cast<const ComboPair*>(base + thi.o1);
+        // fold the level blend (1-f, f) and the UNORM8 scale into the eight bilinear weights: 8 FMAs per
+        // channel and nothing else (VALUE arithmetic: same quantity as (1-f)*tau_lo + f*tau_hi, other rounding)
+        const float klo = (1.0f - f) * kUnorm8, khi = f * kUnorm8;
+        tlo.w00 *= klo; tlo.w10 *= klo; tlo.w01 *= klo; tlo.w11 *= klo;
+        thi.w00 *= khi; thi.w10 *= khi; thi.w01 *= khi; thi.w11 *= khi;
+        float lo[9], hi[9];
         combo_filter(a0, a1, tlo, lo);
-        float hi[9];
         combo_filter(b0, b1, thi, hi);
-        const float nf = 1.0f - f;
 #pragma unroll
-        for (int ch = 0; ch < 9; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
+        for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] + hi[ch];
     } else {
-        combo_filter(a0, a1, tlo, lo);
-#pragma unroll
-        for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] * kUnorm8;
+        tlo.w00 *= kUnorm8; tlo.w10 *= kUnorm8; tlo.w01 *= kUnorm8; tlo.w11 *= kUnorm8;
+        combo_filter(a0, a1, tlo, out);
     }
 }
 
@@ -528,8 +538,8 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     float l1, l2;
     {
 #pragma clang fp contract(off)
-        l1 = (float)E1 * ts.inva;
-        l2 = (float)E2 * ts.inva;
+        l1 = i64_to_f32(E1) * ts.inva;
+        l2 = i64_to_f32(E2) * ts.inva;
     }
 
     // smooth varyings (converterGS.glsl:432-441): Position, Normal, Tangent, UV.

@@ -99,7 +99,7 @@ constexpr int kLbWindows = 8;
 __device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t epoch,
                                                     uint32_t* status) {
     const unsigned long long virt_prefix = kFlagPrefix | ((unsigned long long)epoch << kEpochShift);
-    unsigned long long base = 0;
+    unsigned long long acc = 0;             // per-lane partial sum; reduced across the wave once, at the end
     long long first = (long long)wid - 1;   // nearest predecessor not yet accounted for
     uint32_t spins = 0;
     for (;;) {
@@ -118,11 +118,11 @@ __device__ __noinline__ unsigned long long lookback(const unsigned long long* ch
             if (pm) {
                 const int pl = __ffsll((long long)pm) - 1;        // nearest inclusive prefix in this window
                 if ((im & ((1ull << pl) - 1ull)) == 0) {           // every nearer entry is published
-                    base += wave_sum64(lane <= pl ? (v[j] & kValMask) : 0ull);
+                    if (lane <= pl) acc += v[j] & kValMask;
                     done = true;
                 } else stalled = true;
             } else if (im == 0) {                                  // 64 aggregates: take them, go further back
-                base += wave_sum64(v[j] & kValMask);
+                acc += v[j] & kValMask;
                 first -= 64;
             } else stalled = true;
         }
@@ -135,6 +135,7 @@ __device__ __noinline__ unsigned long long lookback(const unsigned long long* ch
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    const unsigned long long base = wave_sum64(acc);
     return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
            __builtin_amdgcn_readfirstlane((uint32_t)base);
 }
@@ -397,8 +398,10 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                 // 16 B/lane fully coalesced stores (3 KiB contiguous per half)
                 const unsigned long long o0 = base + win + e0;
                 uint32_t nvalid = min(64u, nwin - e0);
-                if (o0 >= limit) nvalid = 0;
-                else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
+                if (o0 + 64ull > limit) {   // (wave-uniform) only strips that straddle the cap need the 64-bit clipping
+                    if (o0 >= limit) nvalid = 0;
+                    else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
+                }
 #pragma unroll 1
                 for (int half = 0; half < 2; ++half) {
                     if (have && (lane >> 5) == half) {
