@@ -60,6 +60,28 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """If PyTorch-ROCm is installed, load ITS libamdhip64 first (without importing torch).
+
+    torch wheels bundle their own HIP runtime (same SONAME libamdhip64.so.7 as /opt/rocm's).  A process must
+    not end up with two HIP runtimes: if this library pulled in /opt/rocm's copy first, a later `import torch`
+    would find no GPU.  Loading torch's copy up front makes both sides share one runtime regardless of import
+    order; the stand-alone C++ CLI simply uses /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # best effort: without torch there is nothing to reconcile
+
+
 def load():
     """Load the library; raise loudly if it is missing (no silent fallback)."""
     global _lib
@@ -68,6 +90,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the conversion pass)")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64
     sigs = {

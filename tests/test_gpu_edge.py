@@ -1,0 +1,128 @@
+"""-m gpu: edge cases of the C ABI and of the pinned rasteriser on the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mesh2splat_amd import _lib, synth
+from mesh2splat_amd.converter import Converter
+from mesh2splat_amd.scene import Mesh, Scene
+from parity import assert_records_match
+
+pytestmark = pytest.mark.gpu
+
+
+def both(oracle, scene, R, cap=0, pipeline="auto"):
+    c = Converter(0)
+    c.set_pipeline(pipeline)
+    c.upload_scene(scene)
+    c.set_max_gaussians(cap)
+    total = c.convert(R)
+    rec = c.download()
+    c.close()
+    ototal, orec, _ = oracle.convert(scene, R, cap=cap)
+    assert total == ototal, (total, ototal)
+    assert_records_match(rec, orec, f"R={R}")
+    return total
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 4095, 4096])
+def test_extreme_resolutions(hiplib, oracle, R):
+    """R = 1 .. 4096 (the UI's maximum, ImGuiUi.hpp:116-118): quad covers exactly R*R pixels."""
+    scene = synth.unit_quad() if R > 100 else synth.cube_sphere(3)
+    n = both(oracle, scene, R)
+    if R > 100:
+        assert n == R * R
+
+
+def test_nonfinite_and_out_of_range_geometry(hiplib, oracle):
+    """NaN / inf positions and positions far outside a caller-supplied bbox: dropped identically by both sides
+    (non-finite or |window coordinate| >= 16384 px), the rest of the mesh is unaffected."""
+    base = synth.cube_sphere(3).meshes[0].vertices.copy()
+    v = base.copy()
+    v[0, 0] = np.nan
+    v[4, 1] = np.inf
+    v[6:9, 0:3] *= 1e6          # far outside the bbox -> guard band
+    v[9:12, 0:3] += 3.0         # outside the bbox but inside the guard band: clipped to the viewport
+    scene = Scene([Mesh("m", v, bbox_min=np.float32([-1, -1, -1]), bbox_max=np.float32([1, 1, 1]))])
+    for pipe in ("auto", "multipass"):
+        assert both(oracle, scene, 64, pipeline=pipe) > 0
+
+
+def test_degenerate_uvs_and_tiny_textures(hiplib, oracle):
+    """1x1 and 2x1 textures (a single mip level / NPOT chain), constant UVs (zero derivatives -> lambda = -inf)."""
+    tex = {"baseColorTexture": np.full((1, 1, 4), 200, np.uint8), "normalTexture": np.array([[[128, 128, 255, 255], [255, 128, 128, 255]]], np.uint8),
+           "metallicRoughnessTexture": np.array([[[0, 64, 192, 255]], [[0, 200, 10, 255]], [[0, 1, 2, 255]]], np.uint8)}
+    scene = synth.unit_quad(tex)
+    scene.meshes[0].vertices[:3, 10:12] = 0.25     # first triangle: constant uv
+    both(oracle, scene, 48)
+
+
+def test_many_small_meshes_straddling_waves(hiplib, oracle):
+    """Mesh boundaries inside a 64-triangle wave tile (per-lane mesh lookup path) and empty meshes in between."""
+    rng = np.random.default_rng(3)
+    meshes = []
+    for k in range(40):
+        nt = int(rng.integers(0, 30))
+        s = synth.random_soup(max(nt, 1), seed=100 + k, textures=synth.procedural_textures(8, k) if k % 3 == 0 else None)
+        m = s.meshes[0]
+        m.name = f"m_{k}"
+        if nt == 0:
+            m = Mesh(f"m_{k}", np.zeros((0, 12), np.float32))
+        m.bbox_min = m.bbox_max = None
+        m.base_color = (0.2 + 0.02 * k, 0.5, 1.0 - 0.02 * k, 1.0)
+        meshes.append(m)
+    scene = Scene(meshes)
+    for pipe in ("auto", "multipass"):
+        both(oracle, scene, 200, pipeline=pipe)
+
+
+def test_api_errors(hiplib):
+    L = _lib.load()
+    c = Converter(0)
+    with pytest.raises(_lib.M2SError, match="M2S_ERR_STATE"):
+        c.convert(64)                                  # convert before upload
+    c.upload_scene(synth.unit_quad())
+    with pytest.raises(_lib.M2SError, match="M2S_ERR_INVALID"):
+        c.convert(0)
+    with pytest.raises(_lib.M2SError, match="M2S_ERR_INVALID"):
+        c.convert(5000)
+    with pytest.raises(_lib.M2SError, match="M2S_ERR_INVALID"):
+        c.set_max_gaussians(-5)
+    bad = (_lib.MeshC * 1)()
+    bad[0].n_vertices = 4
+    bad[0].stride_floats = 12
+    assert L.m2s_upload_scene(c._h, bad, 1) == 1       # not a multiple of 3
+    bad[0].n_vertices = 3
+    bad[0].stride_floats = 11
+    assert L.m2s_upload_scene(c._h, bad, 1) == 1       # stride too small
+    c.upload_scene(synth.unit_quad())
+    assert c.convert(8) == 64
+    small = np.zeros((10, 24), np.float32)
+    assert L.m2s_download(c._h, small.ctypes.data, 10) == 5    # M2S_ERR_CAPACITY
+    assert b"fewer records" in L.m2s_last_error(c._h)
+    with pytest.raises(_lib.M2SError, match="M2S_ERR_IO"):
+        c.export_ply("/nonexistent_dir/x.ply")
+    c.close()
+
+
+def test_convert_into_user_buffer_and_capacity(hiplib, oracle):
+    """m2s_convert_into: records land in caller-owned device memory; capacity bounds what is stored, the counter
+    is unaffected."""
+    torch = pytest.importorskip("torch")
+    scene = synth.cube_sphere(10, tex_size=32)
+    total, orec, _ = oracle.convert(scene, 100, cap=0)
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    buf = torch.zeros((total, 24), dtype=torch.float32, device="cuda")
+    n = c.convert_into(100, buf.data_ptr(), total, torch.cuda.current_stream().cuda_stream)
+    assert n == total and c.num_stored == total
+    assert_records_match(buf.cpu().numpy(), orec, "convert_into")
+    half = torch.full((total // 2 + 7, 24), -1.0, dtype=torch.float32, device="cuda")
+    n = c.convert_into(100, half.data_ptr(), total // 2, torch.cuda.current_stream().cuda_stream)
+    assert n == total and c.num_stored == total // 2
+    h = half.cpu().numpy()
+    assert_records_match(h[: total // 2], orec[: total // 2], "capacity")
+    assert np.all(h[total // 2:] == -1.0)              # nothing written past the capacity
+    c.close()
