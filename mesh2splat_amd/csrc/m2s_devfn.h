@@ -80,13 +80,16 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
     float bminA = useY_asA ? bmin[1] : bmin[0], bmaxA = useY_asA ? bmax[1] : bmax[0];
     float bminB = useY_asB ? bmin[1] : bmin[2], bmaxB = useY_asB ? bmax[1] : bmax[2];
     float range = fmaxf(bmaxA - bminA, bmaxB - bminB);
-    float invRange = 1.0f / range;
+    // u = rel / range: correctly rounded IEEE divisions, as the shader writes them (GS:362-363,375-376,388-389)
+    // and as the oracle, which is checked bit for bit against the reference's GLSL run through glm, evaluates
+    // them.  (rel * (1/range) differs in the last place for ~15 % of the vertices, and the UV->3D Jacobian of a
+    // thin triangle amplifies that to 1e-3 in Scale.)
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float pa = useY_asA ? p[3 * i + 1] : p[3 * i + 0];
         float pb = useY_asB ? p[3 * i + 1] : p[3 * i + 2];
-        g.ou[i] = (pa - bminA) * invRange;
-        g.ov[i] = (pb - bminB) * invRange;
+        g.ou[i] = (pa - bminA) / range;
+        g.ov[i] = (pb - bminB) / range;
     }
 }
 

@@ -78,7 +78,13 @@ M4 node_local(const m2s_json::Value& node) {  // SceneManager.cpp:224-255
     }
     M4 T = identity(), R = identity(), S = identity();
     const auto& t = node["translation"];
-    if (t.is_array() && t.size() == 3) for (int i = 0; i < 3; ++i) T.c[3][i] = (float)t[(size_t)i].number_or(0.0);
+    if (t.is_array() && t.size() == 3) {
+        // glm::translate(mat4(1), v): Result[3] = m[0]*v[0] + m[1]*v[1] + m[2]*v[2] + m[3], evaluated as written
+        // (signed zeros included: a translation of -0 becomes +0, as in glm)
+        const float v[3] = { (float)t[(size_t)0].number_or(0.0), (float)t[(size_t)1].number_or(0.0), (float)t[(size_t)2].number_or(0.0) };
+        const M4 I = identity();
+        for (int i = 0; i < 4; ++i) T.c[3][i] = ((I.c[0][i] * v[0] + I.c[1][i] * v[1]) + I.c[2][i] * v[2]) + I.c[3][i];
+    }
     const auto& q = node["rotation"];
     if (q.is_array() && q.size() == 4) {  // glm::mat4_cast(quat(w, x, y, z))
         const float x = (float)q[(size_t)0].number_or(0), y = (float)q[(size_t)1].number_or(0), z = (float)q[(size_t)2].number_or(0),
@@ -89,7 +95,11 @@ M4 node_local(const m2s_json::Value& node) {  // SceneManager.cpp:224-255
         R.c[2][0] = 2.0f * (qxz + qwy); R.c[2][1] = 2.0f * (qyz - qwx); R.c[2][2] = 1.0f - 2.0f * (qxx + qyy);
     }
     const auto& s = node["scale"];
-    if (s.is_array() && s.size() == 3) for (int i = 0; i < 3; ++i) S.c[i][i] = (float)s[(size_t)i].number_or(1.0);
+    if (s.is_array() && s.size() == 3)   // glm::scale(mat4(1), v): Result[i] = m[i] * v[i] (whole columns: a negative
+        for (int i = 0; i < 3; ++i) {      // factor turns the column's zeros into -0, which glm then carries along)
+            const float f = (float)s[(size_t)i].number_or(1.0);
+            for (int r = 0; r < 4; ++r) S.c[i][r] = S.c[i][r] * f;
+        }
     return mul(mul(T, R), S);
 }
 

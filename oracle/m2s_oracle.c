@@ -203,6 +203,7 @@ typedef struct {
     int x0, x1, y0, y1;       /* inclusive pixel bbox (clamped to the viewport)           */
     float scale_x, scale_y;   /* |Ju|, |Jv|                                               */
     float rot[4];             /* (w,x,y,z)                                                */
+    float ou[3], ov[3];       /* bbox-normalised orthogonal UVs (GS:353-399); gl_Position.xy = uv*2-1 */
     v3 p[3];
 } tri_setup;
 
@@ -231,12 +232,14 @@ static int setup_triangle(const float* v0, const float* v1, const float* v2, con
     else { A = 0; B = 1; }
     float rangeA = bmax[A] - bmin[A], rangeB = bmax[B] - bmin[B];
     float range = fmaxf(rangeA, rangeB);
-    float invRange = 1.0f / range; /* pinned: x / range evaluated as x * (1/range) */
+    /* u = rel / range: a true IEEE division, as the shader writes it (GS:362-363,375-376,388-389).  Checked
+     * bit for bit against the reference's own GLSL run through glm (oracle/ref_glsl_check.cpp). */
     const float* pv[3] = { v0, v1, v2 };
     float ou[3], ov[3];
     for (int i = 0; i < 3; i++) {
-        ou[i] = (pv[i][A] - bmin[A]) * invRange;
-        ov[i] = (pv[i][B] - bmin[B]) * invRange;
+        ou[i] = (pv[i][A] - bmin[A]) / range;
+        ov[i] = (pv[i][B] - bmin[B]) / range;
+        s->ou[i] = ou[i]; s->ov[i] = ov[i];
     }
     /* GS:401-407 rotation */
     v3 ya = v3normalize(v3cross(nrm, xa));
@@ -341,6 +344,46 @@ static float lod_lambda(const tex_t* t, float dudx, float dvdx, float dudy, floa
     return log2f(rho);
 }
 
+/* converterFS.glsl:44-104 for ONE fragment: f = the interpolated varyings (pos 0-2, normal 3-5, tangent 6-9,
+ * uv 10-11), lam = the per-texture level of detail, flat inputs Scale/Quaternion from the GS. */
+static void shade_fragment(const mesh_t* m, const float f[12], const float lam[3], float scale_x, float scale_y,
+                           const float rot[4], float* o) {
+    const float* P = f; const float* N = f + 3; const float* T = f + 6; const float* UV = f + 10;
+    /* colour: FS:53-62,99 */
+    float col[4] = { 1, 1, 1, 1 };
+    if (m->tex[0].chain) sample_lod(&m->tex[0], UV[0], UV[1], lam[0], col);
+    /* normal: FS:66-81 */
+    float nout[3] = { N[0], N[1], N[2] };
+    if (m->tex[1].chain) {
+        float tn[4];
+        sample_lod(&m->tex[1], UV[0], UV[1], lam[1], tn);
+        v3 r = { tn[0] * 2.0f - 1.0f, tn[1] * 2.0f - 1.0f, tn[2] * 2.0f - 1.0f };
+        r = v3normalize(r);
+        v3 Nv = { N[0], N[1], N[2] }, Tv = { T[0], T[1], T[2] };
+        v3 bt = v3normalize(v3cross(Nv, Tv));
+        bt.x *= T[3]; bt.y *= T[3]; bt.z *= T[3];
+        v3 Nn = v3normalize(Nv);
+        v3 w = { (Tv.x * r.x + bt.x * r.y) + Nn.x * r.z, (Tv.y * r.x + bt.y * r.y) + Nn.y * r.z,
+                 (Tv.z * r.x + bt.z * r.y) + Nn.z * r.z };
+        w = v3normalize(w);
+        nout[0] = w.x; nout[1] = w.y; nout[2] = w.z;
+    }
+    /* metallic-roughness: FS:87-95 */
+    float metal = 0.1f, rough = 0.5f;
+    if (m->tex[2].chain) {
+        float mr[4];
+        sample_lod(&m->tex[2], UV[0], UV[1], lam[2], mr);
+        metal = mr[2]; rough = mr[1];
+    }
+    /* record: FS:98-103 */
+    o[0] = P[0]; o[1] = P[1]; o[2] = P[2]; o[3] = 1.0f;
+    for (int k = 0; k < 4; k++) o[4 + k] = col[k] * m->color[k];
+    o[8] = scale_x; o[9] = scale_y; o[10] = 1e-7f; o[11] = 0.0f;
+    o[12] = nout[0]; o[13] = nout[1]; o[14] = nout[2]; o[15] = 0.0f;
+    o[16] = rot[0]; o[17] = rot[1]; o[18] = rot[2]; o[19] = rot[3];
+    o[20] = metal; o[21] = rough; o[22] = 0.0f; o[23] = 1.0f;
+}
+
 /* converterFS.glsl:44-104 for every covered pixel of one triangle; returns fragments visited. */
 static uint64_t emit_triangle(const tri_setup* s, const mesh_t* m, const float* v0, const float* v1,
                               const float* v2, uint64_t gtri, uint64_t base, uint64_t cap, float* out,
@@ -369,41 +412,7 @@ static uint64_t emit_triangle(const tri_setup* s, const mesh_t* m, const float* 
             float l1 = (float)E[1] * inva, l2 = (float)E[2] * inva;
             float f[12];
             for (int k = 0; k < 12; k++) f[k] = (v0[k] + l1 * (v1[k] - v0[k])) + l2 * (v2[k] - v0[k]);
-            const float* P = f; const float* N = f + 3; const float* T = f + 6; const float* UV = f + 10;
-            float* o = out + idx * ORC_RECORD_FLOATS;
-            /* colour: FS:53-62,99 */
-            float col[4] = { 1, 1, 1, 1 };
-            if (m->tex[0].chain) sample_lod(&m->tex[0], UV[0], UV[1], lam[0], col);
-            /* normal: FS:66-81 */
-            float nout[3] = { N[0], N[1], N[2] };
-            if (m->tex[1].chain) {
-                float tn[4];
-                sample_lod(&m->tex[1], UV[0], UV[1], lam[1], tn);
-                v3 r = { tn[0] * 2.0f - 1.0f, tn[1] * 2.0f - 1.0f, tn[2] * 2.0f - 1.0f };
-                r = v3normalize(r);
-                v3 Nv = { N[0], N[1], N[2] }, Tv = { T[0], T[1], T[2] };
-                v3 bt = v3normalize(v3cross(Nv, Tv));
-                bt.x *= T[3]; bt.y *= T[3]; bt.z *= T[3];
-                v3 Nn = v3normalize(Nv);
-                v3 w = { (Tv.x * r.x + bt.x * r.y) + Nn.x * r.z, (Tv.y * r.x + bt.y * r.y) + Nn.y * r.z,
-                         (Tv.z * r.x + bt.z * r.y) + Nn.z * r.z };
-                w = v3normalize(w);
-                nout[0] = w.x; nout[1] = w.y; nout[2] = w.z;
-            }
-            /* metallic-roughness: FS:87-95 */
-            float metal = 0.1f, rough = 0.5f;
-            if (m->tex[2].chain) {
-                float mr[4];
-                sample_lod(&m->tex[2], UV[0], UV[1], lam[2], mr);
-                metal = mr[2]; rough = mr[1];
-            }
-            /* record: FS:98-103 */
-            o[0] = P[0]; o[1] = P[1]; o[2] = P[2]; o[3] = 1.0f;
-            for (int k = 0; k < 4; k++) o[4 + k] = col[k] * m->color[k];
-            o[8] = s->scale_x; o[9] = s->scale_y; o[10] = 1e-7f; o[11] = 0.0f;
-            o[12] = nout[0]; o[13] = nout[1]; o[14] = nout[2]; o[15] = 0.0f;
-            o[16] = s->rot[0]; o[17] = s->rot[1]; o[18] = s->rot[2]; o[19] = s->rot[3];
-            o[20] = metal; o[21] = rough; o[22] = 0.0f; o[23] = 1.0f;
+            shade_fragment(m, f, lam, s->scale_x, s->scale_y, s->rot, out + idx * ORC_RECORD_FLOATS);
             if (keys) keys[idx] = (gtri << 24) | ((uint64_t)y << 12) | (uint64_t)x;
         }
     }
@@ -542,6 +551,29 @@ uint64_t orc_count_per_triangle(const orc_mesh* meshes, uint32_t n_meshes, uint3
     }
     free_meshes(ms, n_meshes);
     return total;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* test hooks for oracle/ref_glsl_check.cpp (the reference's shader source run as C++)     */
+/* ------------------------------------------------------------------------------------ */
+int orc_debug_gs(const float* v0, const float* v1, const float* v2, const float bmin[3], const float bmax[3],
+                 uint32_t R, float ndc_xy[6], float scale_xyz[3], float rot_wxyz[4]) {
+    tri_setup s;
+    memset(&s, 0, sizeof s);
+    int ok = setup_triangle(v0, v1, v2, bmin, bmax, R, &s);
+    for (int i = 0; i < 3; i++) { ndc_xy[2 * i] = s.ou[i] * 2.0f - 1.0f; ndc_xy[2 * i + 1] = s.ov[i] * 2.0f - 1.0f; }
+    scale_xyz[0] = s.scale_x; scale_xyz[1] = s.scale_y; scale_xyz[2] = 1e-7f;
+    for (int i = 0; i < 4; i++) rot_wxyz[i] = s.rot[i];
+    return ok;
+}
+
+void orc_debug_sample(const orc_scene* sc, uint32_t mesh, int slot, float u, float v, float lambda, float out[4]) {
+    sample_lod(&sc->ms[mesh].tex[slot], u, v, lambda, out);
+}
+
+void orc_debug_fs(const orc_scene* sc, uint32_t mesh, const float varyings[12], const float lam[3],
+                  const float scale_xy[2], const float rot_wxyz[4], float record[ORC_RECORD_FLOATS]) {
+    shade_fragment(&sc->ms[mesh], varyings, lam, scale_xy[0], scale_xy[1], rot_wxyz, record);
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -74,6 +74,15 @@ void orc_scene_destroy(orc_scene* sc);
 uint64_t orc_scene_convert(const orc_scene* sc, uint32_t R, uint64_t tri_first, uint64_t tri_count, uint64_t cap,
                            float* out, uint64_t out_capacity, uint64_t* keys, int n_threads);
 
+/* Test hooks used by oracle/ref_glsl_check.cpp, which runs the reference's GLSL source as C++ and compares
+ * stage by stage: the GS outputs of one triangle (gl_Position.xy of the three vertices, Scale, Quaternion as
+ * stored, i.e. w,x,y,z), one texture fetch, and the FS for one set of interpolated varyings. */
+int orc_debug_gs(const float* v0, const float* v1, const float* v2, const float bmin[3], const float bmax[3],
+                 uint32_t R, float ndc_xy[6], float scale_xyz[3], float rot_wxyz[4]);
+void orc_debug_sample(const orc_scene* sc, uint32_t mesh, int slot, float u, float v, float lambda, float out[4]);
+void orc_debug_fs(const orc_scene* sc, uint32_t mesh, const float varyings[12], const float lam[3],
+                  const float scale_xy[2], const float rot_wxyz[4], float record[ORC_RECORD_FLOATS]);
+
 /* Per-triangle fragment counts only (for shard balancing tests). counts has n_triangles entries. */
 uint64_t orc_count_per_triangle(const orc_mesh* meshes, uint32_t n_meshes, uint32_t R,
                                 uint32_t* counts);

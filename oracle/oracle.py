@@ -67,6 +67,11 @@ def lib():
         L.orc_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.orc_write_ply.restype = C.c_int
         L.orc_write_ply.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_float]
+        L.orc_debug_gs.restype = C.c_int
+        L.orc_debug_gs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+        L.orc_debug_fs.restype = None
+        L.orc_debug_fs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_cast.restype = None
         L.orc_quat_cast.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
@@ -144,6 +149,13 @@ class PreparedScene:
         total = L.orc_scene_convert(self._h, R, 0, (1 << 64) - 1, cap, out.ctypes.data, out.shape[0], None, n_threads)
         return int(total), out
 
+    def debug_fs(self, mesh: int, varyings, lam, scale_xy, rot_wxyz) -> np.ndarray:
+        """converterFS.glsl for one set of interpolated varyings (12), LODs (3) and flat inputs -> 24-float record."""
+        a = [np.ascontiguousarray(x, np.float32) for x in (varyings, lam, scale_xy, rot_wxyz)]
+        rec = np.zeros(24, np.float32)
+        lib().orc_debug_fs(self._h, mesh, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, rec.ctypes.data)
+        return rec
+
     def close(self):
         if self._h:
             lib().orc_scene_destroy(self._h)
@@ -151,6 +163,15 @@ class PreparedScene:
 
     def __del__(self):
         self.close()
+
+
+def debug_gs(v0, v1, v2, bmin, bmax, R: int):
+    """converterGS.glsl for one triangle (three 12-float vertices) -> (ok, ndc_xy[3,2], scale[3], rot_wxyz[4])."""
+    a = [np.ascontiguousarray(x, np.float32) for x in (v0, v1, v2, bmin, bmax)]
+    ndc, scl, rot = np.zeros(6, np.float32), np.zeros(3, np.float32), np.zeros(4, np.float32)
+    ok = lib().orc_debug_gs(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data, R,
+                            ndc.ctypes.data, scl.ctypes.data, rot.ctypes.data)
+    return bool(ok), ndc.reshape(3, 2), scl, rot
 
 
 def count_per_triangle(scene, R: int) -> np.ndarray:

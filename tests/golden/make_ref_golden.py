@@ -1,0 +1,101 @@
+#!/usr/bin/env python
+"""Regenerates tests/golden/ref_host/: outputs of the REFERENCE's own host code (oracle/_ref/ref_host_check,
+built by `make -C oracle ref` from /root/reference) on small synthetic inputs, so that the comparison with the
+real reference also runs where /root/reference does not exist.
+
+    python tests/golden/make_ref_golden.py
+
+Inputs (.glb written by mesh2splat_amd.gltf_io.write_glb, records.bin from the oracle) and the reference's
+outputs (*.scene.bin = dump of SceneManager::loadModel's vertex upload / bbox / material / textures,
+ref_fmt*.ply = parsers::savePlyVector, ref_read_fmt*.bin = parsers::loadPlyFile, glsl_*.dump.bin = what the
+reference's converter{VS,GS,FS}.glsl computed when run as C++ through glm by oracle/_ref/ref_glsl_check) are all
+committed."""
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import refhost  # noqa: E402
+from mesh2splat_amd import gltf_io, synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+OUT = os.path.join(HERE, "ref_host")
+
+
+def scene_cases():
+    q = np.array([0.1, 0.5, -0.2, 0.8])
+    q /= np.linalg.norm(q)
+    trs = [dict(translation=(1, 2, 3), rotation=q, scale=(2, 0.5, 1.5)), dict(scale=(1, -1, 1)), dict(translation=(-0.0, 4, 0)),
+           dict(matrix=[1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 5, 6, 7, 1])] + [{}] * 4
+    yield "trs_nested", synth.sphere_grid(2, n=2, tex_size=8), dict(node_trs=trs, nested=True)
+    yield "flat_nonindexed", synth.cube_sphere(2), dict(with_normals=False, with_tangents=False, indexed=False)
+    yield "no_uv_u8", synth.cube_sphere(2), dict(with_uvs=False, index_type="u8")
+    mixed = synth.sphere_grid(2, n=2, tex_size=8)
+    mixed.meshes[1].textures.pop("normalTexture", None)
+    mixed.meshes[2].textures.clear()
+    mixed.meshes[3].base_color = (0.2, 0.4, 0.6, 0.8)
+    yield "mixed_materials_u32", mixed, dict(index_type="u32")
+
+
+def glsl_cases():
+    """(name, scene, R, FS samples per triangle) for the shader-level fixtures."""
+    yield "sphere", synth.cube_sphere(4, tex_size=16), 64, 3
+    yield "soup", synth.random_soup(150, seed=21, textures=synth.procedural_textures(8, 2)), 64, 3
+    plain = synth.random_soup(100, seed=22)
+    plain.meshes[0].base_color = (0.25, 0.5, 0.75, 0.5)
+    yield "soup_untextured", plain, 64, 2
+
+
+def sample_records():
+    scene = synth.random_soup(24, seed=11, textures=synth.procedural_textures(16, 2))
+    scene.meshes[0].base_color = (1.0, 0.9, 0.8, 1.0)
+    _, rec, _ = oracle.convert(scene, 40, cap=0)
+    rec = rec[:120].copy()
+    rec[::3, 7] = 1.0            # opaque -> opacity +inf
+    rec[1::3, 7] = 0.37
+    rec[5, 4:7] = (1.5, -0.25, 0.5)
+    rec[7, 12:15] = (0.0, 0.0, -1.0)
+    rec[8, 12:15] = (-0.3, 0.2, -0.6)
+    return rec
+
+
+def main():
+    assert refhost.available(), "build oracle/_ref first: make -C oracle ref"
+    shutil.rmtree(OUT, ignore_errors=True)
+    os.makedirs(OUT)
+    tmp = tempfile.mkdtemp()
+    for name, scene, kw in scene_cases():
+        glb = os.path.join(OUT, name + ".glb")
+        gltf_io.write_glb(scene, glb, **kw)
+        refhost.load_scene(glb, tmp)
+        shutil.copy(os.path.join(tmp, "ref_scene.bin"), os.path.join(OUT, name + ".scene.bin"))
+    rec = sample_records()
+    rec.tofile(os.path.join(OUT, "records.bin"))
+    sm = np.float32(0.65) / np.float32(40)
+    for fmt in (0, 1, 2):
+        ply = os.path.join(OUT, f"ref_fmt{fmt}.ply")
+        refhost.write_ply(rec, ply, fmt, sm, tmp)
+        if fmt in (0, 1):
+            refhost.read_ply(ply, tmp)
+            shutil.copy(os.path.join(tmp, "ref_plyread.bin"), os.path.join(OUT, f"ref_read_fmt{fmt}.bin"))
+    # the reference's conversion SHADERS run as C++ (oracle/ref_glsl_check.cpp): keep what they produced
+    assert refhost.glsl_available()
+    for name, scene, R, samples in glsl_cases():
+        dump = os.path.join(OUT, f"glsl_{name}.dump.bin")
+        rep = refhost.run_glsl_check(scene, R, samples, tmp, dump_path=dump)
+        shutil.copy(os.path.join(tmp, "glsl_scene.bin"), os.path.join(OUT, f"glsl_{name}.scene.bin"))
+        with open(os.path.join(OUT, f"glsl_{name}.report.json"), "w") as f:
+            json.dump(dict(R=R, samples=samples, **rep), f, indent=1)
+    print("wrote", sorted(os.listdir(OUT)), sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

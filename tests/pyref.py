@@ -72,9 +72,8 @@ def triangle_setup(p, bmin, bmax, R):
         else:
             A, B = 0, 1
         rng = f32(max(bmax[A] - bmin[A], bmax[B] - bmin[B]))
-        inv = f32(1.0) / rng
-        ou = [f32((p[i][A] - bmin[A]) * inv) for i in range(3)]
-        ov = [f32((p[i][B] - bmin[B]) * inv) for i in range(3)]
+        ou = [f32(f32(p[i][A] - bmin[A]) / rng) for i in range(3)]   # true division, as the shader writes it
+        ov = [f32(f32(p[i][B] - bmin[B]) / rng) for i in range(3)]
         ya = _normalize(_cross(nrm, xa))
         q = quat_cast([xa, ya, nrm])
         rot = (q[3], q[0], q[1], q[2])

@@ -1,0 +1,154 @@
+"""Test helper: drive oracle/_ref/ref_host_check (the REFERENCE's own loader / PLY code compiled by
+oracle/Makefile from /root/reference, GL calls stubbed) and parse its dumps.  Test infrastructure only."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "ref_host_check")
+TEX_KEYS = ("baseColorTexture", "normalTexture", "metallicRoughnessTexture")
+
+
+def available() -> bool:
+    return os.path.isfile(BIN) and os.access(BIN, os.X_OK)
+
+
+def parse_scene_dump(blob: bytes):
+    """-> list of dicts {name, vertices (n,17) f32, bbox_min, bbox_max, base_color, textures{key: (h,w,c) u8}}"""
+    o = 0
+
+    def u32():
+        nonlocal o
+        v = struct.unpack_from("<I", blob, o)[0]
+        o += 4
+        return v
+
+    out = []
+    for _ in range(u32()):
+        ln = u32()
+        name = blob[o:o + ln].decode()
+        o += ln
+        vcount, nfl = u32(), u32()
+        v = np.frombuffer(blob, np.float32, nfl, o).reshape(-1, 17).copy() if nfl else np.zeros((0, 17), np.float32)
+        o += nfl * 4
+        assert v.shape[0] == vcount
+        bb = np.frombuffer(blob, np.float32, 6, o).copy()
+        o += 24
+        col = np.frombuffer(blob, np.float32, 4, o).copy()
+        o += 16
+        tex = {}
+        for key in TEX_KEYS:
+            w, h, c, nb = u32(), u32(), u32(), u32()
+            if nb:
+                tex[key] = np.frombuffer(blob, np.uint8, nb, o).reshape(h, w, c).copy()
+            o += nb
+        out.append(dict(name=name, vertices=v, bbox_min=bb[:3], bbox_max=bb[3:], base_color=col, textures=tex))
+    assert o == len(blob)
+    return out
+
+
+def load_scene(glb_path: str, tmp_dir: str):
+    out = os.path.join(tmp_dir, "ref_scene.bin")
+    r = subprocess.run([BIN, "scene", glb_path, out], capture_output=True, text=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference loader failed rc={r.returncode}: {r.stdout[-400:]} {r.stderr[-400:]}")
+    with open(out, "rb") as f:
+        return parse_scene_dump(f.read())
+
+
+def write_ply(records: np.ndarray, ply_path: str, fmt: int, scale_multiplier, tmp_dir: str) -> None:
+    rb = os.path.join(tmp_dir, "ref_records.bin")
+    np.ascontiguousarray(records, np.float32).tofile(rb)
+    r = subprocess.run([BIN, "plywrite", rb, ply_path, str(int(fmt)), "%.9g" % float(np.float32(scale_multiplier))],
+                       capture_output=True, text=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference PLY writer failed rc={r.returncode}: {r.stderr[-400:]}")
+
+
+def parse_ply_dump(blob: bytes):
+    pbr, n = struct.unpack_from("<II", blob, 0)
+    return np.frombuffer(blob, np.float32, n * 24, 8).reshape(n, 24).copy(), bool(pbr)
+
+
+def read_ply(ply_path: str, tmp_dir: str):
+    out = os.path.join(tmp_dir, "ref_plyread.bin")
+    r = subprocess.run([BIN, "plyread", ply_path, out], capture_output=True, text=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference PLY reader failed rc={r.returncode}: {r.stderr[-400:]}")
+    with open(out, "rb") as f:
+        return parse_ply_dump(f.read())
+
+
+# ---- the reference's GLSL run as C++ (oracle/_ref/ref_glsl_check) ---------------------------------------
+GLSL_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_glsl_check")
+
+
+def glsl_available() -> bool:
+    return os.path.isfile(GLSL_BIN) and os.access(GLSL_BIN, os.X_OK)
+
+
+def dump_scene_for_glsl(scene, path: str) -> None:
+    """scene.bin layout documented in oracle/ref_glsl_check.cpp."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", scene.n_meshes))
+        for m in scene.meshes:
+            v = np.ascontiguousarray(m.vertices[:, :12], np.float32)
+            f.write(struct.pack("<I", v.shape[0]))
+            f.write(np.asarray(m.bbox_min, np.float32).tobytes())
+            f.write(np.asarray(m.bbox_max, np.float32).tobytes())
+            f.write(np.asarray(m.base_color, np.float32).tobytes())
+            f.write(v.tobytes())
+            for key in TEX_KEYS:
+                t = m.textures.get(key)
+                if t is None:
+                    f.write(struct.pack("<II", 0, 0))
+                else:
+                    t = np.ascontiguousarray(t, np.uint8)
+                    f.write(struct.pack("<II", t.shape[1], t.shape[0]))
+                    f.write(t.tobytes())
+
+
+def run_glsl_check(scene, R: int, samples: int, tmp_dir: str, dump_path: str = None) -> dict:
+    import json
+    p = os.path.join(tmp_dir, "glsl_scene.bin")
+    dump_scene_for_glsl(scene, p)
+    cmd = [GLSL_BIN, p, str(int(R)), str(int(samples))] + ([dump_path] if dump_path else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError(f"ref_glsl_check failed rc={r.returncode}: {r.stderr[-400:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def parse_glsl_dump(blob: bytes, n_triangles: int, samples: int):
+    """-> (gs (T,13) float32: ndc xy x3, Scale xyz, Quaternion wxyz;  fs (T,samples,39): varyings 12, lod 3, record 24)."""
+    a = np.frombuffer(blob, np.float32).reshape(n_triangles, 13 + samples * 39)
+    return a[:, :13].copy(), a[:, 13:].reshape(n_triangles, samples, 39).copy()
+
+
+def parse_glsl_scene(blob: bytes):
+    """Inverse of dump_scene_for_glsl -> mesh2splat_amd.scene.Scene (12-float vertices, bboxes as stored)."""
+    from mesh2splat_amd.scene import Mesh, Scene
+    o = 0
+    n = struct.unpack_from("<I", blob, o)[0]
+    o += 4
+    meshes = []
+    for i in range(n):
+        nv = struct.unpack_from("<I", blob, o)[0]
+        o += 4
+        hdr = np.frombuffer(blob, np.float32, 10, o).copy()
+        o += 40
+        v = np.frombuffer(blob, np.float32, nv * 12, o).reshape(nv, 12).copy()
+        o += nv * 48
+        tex = {}
+        for key in TEX_KEYS:
+            w, h = struct.unpack_from("<II", blob, o)
+            o += 8
+            if w * h:
+                tex[key] = np.frombuffer(blob, np.uint8, w * h * 4, o).reshape(h, w, 4).copy()
+                o += w * h * 4
+        meshes.append(Mesh(name=f"m_{i}", vertices=v, base_color=tuple(float(x) for x in hdr[6:10]), textures=tex,
+                           bbox_min=hdr[0:3].copy(), bbox_max=hdr[3:6].copy()))
+    assert o == len(blob)
+    return Scene(meshes)

@@ -1,0 +1,110 @@
+"""CPU: this repository's loader and PLY writers/readers against the REFERENCE'S OWN host code.
+
+Two layers:
+  * golden  — outputs of the reference's SceneManager::loadModel / parsers::savePlyVector / parsers::loadPlyFile
+              (compiled from /root/reference by oracle/Makefile into oracle/_ref/ref_host_check, GL stubbed),
+              committed under tests/golden/ref_host/ by tests/golden/make_ref_golden.py.  Always runs.
+  * live    — the same comparison on more inputs by running that binary; skipped where it was not built.
+Bar: bit-exact (vertex floats compared as uint32, signed zeros included; .ply files byte for byte)."""
+import os
+
+import numpy as np
+import pytest
+
+import refhost
+from mesh2splat_amd import gltf_io, synth
+from mesh2splat_amd.converter import write_ply
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host")
+SCENES = ["trs_nested", "flat_nonindexed", "no_uv_u8", "mixed_materials_u32"]
+live = pytest.mark.skipif(not refhost.available(), reason="oracle/_ref/ref_host_check not built (needs /root/reference)")
+
+
+def assert_scene_equal(ref, mine):
+    assert len(ref) == mine.n_meshes
+    for r, m in zip(ref, mine.meshes):
+        assert r["name"] == m.name
+        assert r["vertices"].shape == m.vertices.shape
+        assert np.array_equal(r["vertices"].view(np.uint32), np.ascontiguousarray(m.vertices).view(np.uint32)), m.name
+        assert np.array_equal(r["bbox_min"], m.bbox_min) and np.array_equal(r["bbox_max"], m.bbox_max)   # cumulative bbox (Q1)
+        assert np.array_equal(r["base_color"], np.asarray(m.base_color, np.float32))
+        assert set(r["textures"]) == set(m.textures)
+        for k, t in r["textures"].items():
+            assert t.shape[2] == 4 and np.array_equal(t, m.textures[k])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_loader_matches_reference_golden(hiplib, name):
+    with open(os.path.join(GOLD, name + ".scene.bin"), "rb") as f:
+        ref = refhost.parse_scene_dump(f.read())
+    assert_scene_equal(ref, gltf_io.load_glb(os.path.join(GOLD, name + ".glb")))
+
+
+def golden_records():
+    return np.fromfile(os.path.join(GOLD, "records.bin"), np.float32).reshape(-1, 24)
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_ply_writers_match_reference_golden(tmp_path, hiplib, oracle, fmt):
+    rec = golden_records()
+    sm = np.float32(0.65) / np.float32(40)
+    want = open(os.path.join(GOLD, f"ref_fmt{fmt}.ply"), "rb").read()
+    a, b = str(tmp_path / "prod.ply"), str(tmp_path / "orc.ply")
+    write_ply(a, rec, fmt, sm)
+    oracle.write_ply(b, rec, fmt, sm)
+    assert open(a, "rb").read() == want      # product (m2s_write_ply)
+    assert open(b, "rb").read() == want      # oracle restatement
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_ply_reader_matches_reference_golden(hiplib, fmt):
+    with open(os.path.join(GOLD, f"ref_read_fmt{fmt}.bin"), "rb") as f:
+        want, want_pbr = refhost.parse_ply_dump(f.read())
+    got, pbr = gltf_io.read_ply(os.path.join(GOLD, f"ref_fmt{fmt}.ply"))
+    assert pbr == want_pbr == (fmt == 1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- live -----------------------------------------------------------------------------------------------
+def live_scene_cases():
+    rng = np.random.default_rng(5)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    trs = [dict(rotation=q, scale=(-1.5, 2, -0.25)), dict(translation=(0.5, -0.0, -3)), dict(scale=(1, 1, -1), translation=(0, 0, 1)), {}]
+    yield "trs", synth.sphere_grid(2, n=3, tex_size=16), dict(node_trs=trs, nested=True)
+    yield "u16", synth.cube_sphere(8, tex_size=16), dict(index_type="u16")
+    yield "soup", synth.random_soup(200, seed=3, textures=synth.procedural_textures(8, 1)), dict(indexed=False)
+    yield "soup_flat", synth.random_soup(80, seed=4), dict(with_normals=False, with_tangents=False)
+    yield "colocated", synth.colocated_spheres(3, n=3, tex_size=8), dict()
+
+
+@live
+@pytest.mark.parametrize("case", list(live_scene_cases()), ids=lambda c: c[0])
+def test_loader_matches_reference_live(tmp_path, hiplib, case):
+    name, scene, kw = case
+    glb = str(tmp_path / (name + ".glb"))
+    gltf_io.write_glb(scene, glb, **kw)
+    assert_scene_equal(refhost.load_scene(glb, str(tmp_path)), gltf_io.load_glb(glb))
+
+
+@live
+@pytest.mark.parametrize("fmt", [0, 1, 2, 7])
+def test_ply_matches_reference_live(tmp_path, hiplib, oracle, fmt):
+    rng = np.random.default_rng(fmt)
+    rec = rng.uniform(-1.0, 1.0, (5000, 24)).astype(np.float32)
+    rec[:, 4:8] = rng.uniform(0.0, 1.0, (5000, 4))            # colour / alpha
+    rec[:, 8:10] = rng.uniform(1e-4, 0.1, (5000, 2))          # scale (log taken)
+    rec[:, 10] = 1e-7
+    rec[::7, 7] = 1.0
+    rec[:, 20:22] = rng.uniform(0.0, 1.0, (5000, 2))
+    sm = np.float32(0.65) / np.float32(333)
+    a, b, c = (str(tmp_path / n) for n in ("ref.ply", "prod.ply", "orc.ply"))
+    refhost.write_ply(rec, a, fmt, sm, str(tmp_path))
+    write_ply(b, rec, fmt, sm)
+    oracle.write_ply(c, rec, fmt, sm)
+    want = open(a, "rb").read()
+    assert open(b, "rb").read() == want and open(c, "rb").read() == want
+    if fmt in (0, 1):
+        r, rp = refhost.read_ply(b, str(tmp_path))
+        m, mp = gltf_io.read_ply(b)
+        assert rp == mp and np.array_equal(r.view(np.uint32), m.view(np.uint32))
