@@ -9,7 +9,17 @@
  *  operation, no fused multiply-add", so that every discrete decision — longest edge,
  *  triplanar axis, sub-pixel snapping — is reproducible bit-for-bit on the GPU.)
  *
- * PARITY UNPINNED: no reference golden vectors exist for this path (see header).
+ * PARITY: the reference ships no golden vectors or tests for this path, and its OpenGL implementation cannot
+ * run here (no GL/EGL/OSMesa).  What pins this file instead is the reference ITSELF, run on this machine:
+ *   - everything the shaders compute (converterVS/GS/FS.glsl: edge swap, triplanar axis, bbox-normalised UVs,
+ *     Jacobian scale, quat_cast, TBN normal, colour, metallic/roughness, record layout) is checked BIT FOR BIT
+ *     against the reference's own GLSL source, executed as C++ through its vendored glm
+ *     (oracle/ref_glsl_check.cpp, tests/test_ref_glsl.py, fixtures tests/golden/ref_host/glsl_*);
+ *   - the PLY writers are checked byte for byte against the reference's parsers.cpp (oracle/ref_host_check.cpp).
+ * STILL UNPINNED (fixed-function GL, no reference code exists for it): which pixel centres a triangle covers
+ * (top-left rule on a 1/256 px grid), varying interpolation, mip generation, LOD selection and trilinear
+ * filtering.  Those follow the OpenGL 4.6 specification as cited at each function and are frozen by our own
+ * known-answer tests (tests/test_oracle_kat.py) and golden fixtures.
  */
 #include "m2s_oracle.h"
 

@@ -15,12 +15,18 @@
  * pixel-centre rasterisation, screen-linear attribute interpolation, trilinear REPEAT
  * sampling, GenerateMipmap), pinned as written in DESIGN.md section "Pinned semantics".
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or sample assets for this
- * path and its implementation (GLSL on an OpenGL 4.6 driver inside a Windows GUI app) can
- * be neither built nor run in this environment.  The oracle is therefore anchored on
- * hand-derived known-answer tests (tests/test_oracle_kat.py) and, for the one sub-function
- * with compilable third-party provenance (quat_cast == glm::quat_cast), on glm itself
- * (oracle/ref_glm_check.cpp -> oracle/_ref/).
+ * PARITY.  The reference ships no tests, golden vectors or sample assets for this path, and its implementation
+ * (GLSL on an OpenGL 4.6 driver inside a Windows GUI app) cannot run here.  The oracle is pinned on the reference
+ * itself wherever reference CODE exists, by compiling that code from where it lies (oracle/Makefile -> oracle/_ref/):
+ *   - converterVS/GS/FS.glsl executed as C++ through the vendored glm: gl_Position, Scale, Quaternion and the
+ *     24-float record agree BIT FOR BIT (oracle/ref_glsl_check.cpp, tests/test_ref_glsl.py);
+ *   - parsers.cpp / SceneManager.cpp / tiny_gltf / stb_image with GL stubbed: PLY writers byte for byte, PLY reader
+ *     and .glb loader bit for bit (oracle/ref_host_check.cpp, tests/test_ref_host.py);
+ *   - glm::quat_cast and the glm node transforms (oracle/ref_glm_check.cpp, ref_glm_xform_check.cpp).
+ * The reference's outputs are committed as fixtures (tests/golden/ref_host/, generator alongside).
+ * PARITY UNPINNED for the fixed-function part only — pixel coverage, varying interpolation, mip generation, LOD and
+ * trilinear filtering have no reference code (the GL driver does them); they follow the GL 4.6 specification as
+ * pinned in DESIGN.md and are frozen by hand-derived known-answer tests (tests/test_oracle_kat.py).
  */
 #ifndef M2S_ORACLE_H
 #define M2S_ORACLE_H

@@ -1,8 +1,10 @@
-"""CPU: pins the C oracle.  The reference ships no golden vectors for this path ("parity
-unpinned"), so the anchors are (a) hand-derived known answers K-1..K-10, (b) an
-independent line-by-line Python transcription of the shaders (tests/pyref.py) on small cases,
-(c) glm::quat_cast compiled from the reference's vendored glm (oracle/_ref/glm_check), and
-(d) committed golden fixtures that freeze the oracle's outputs across rounds.
+"""CPU: pins the C oracle.  The reference ships no golden vectors for this path; the shader-level
+logic is pinned on the reference's own GLSL in tests/test_ref_glsl.py.  This file anchors the rest,
+in particular the fixed-function stages no reference code exists for ("parity unpinned" there):
+(a) hand-derived known answers K-1..K-10, (b) an independent line-by-line Python
+transcription of the shaders + pinned rasteriser (tests/pyref.py) on small cases, (c) glm::quat_cast
+compiled from the reference's vendored glm (oracle/_ref/glm_check), and (d) committed golden
+fixtures that freeze the oracle's outputs across rounds.
 """
 import os
 import subprocess
