@@ -219,6 +219,54 @@ typedef struct {
 
 #define GUARD_PX 16384.0f
 
+/* Fixed-function part (no reference code exists for it): GL 4.6 13.8.1 viewport transform with
+ * glViewport(0,0,R,R) (ConversionPass.cpp:45): xw = (R/2)*xd + R/2; snap to 1/256 px, round-to-nearest-even;
+ * integer edge functions, both windings (no culling, ConversionPass.cpp:48), top-left style ownership.
+ * Input: the three clip-space positions' x,y (z = 0, w = 1).  Returns 0 if no fragment can result. */
+static int raster_setup(const float ndx[3], const float ndy[3], uint32_t R, tri_setup* s) {
+    float half = (float)R * 0.5f;
+    int64_t X[3], Y[3];
+    for (int i = 0; i < 3; i++) {
+        float xw = half * ndx[i] + half, yw = half * ndy[i] + half;
+        if (!(fabsf(xw) < GUARD_PX) || !(fabsf(yw) < GUARD_PX)) return 0; /* NaN/inf/absurd */
+        X[i] = (int64_t)rintf(xw * 256.0f);
+        Y[i] = (int64_t)rintf(yw * 256.0f);
+    }
+    /* edge i is opposite vertex i: E0 = orient(V1,V2,P), E1 = orient(V2,V0,P), E2 = orient(V0,V1,P) */
+    static const int ea[3] = { 1, 2, 0 }, eb[3] = { 2, 0, 1 };
+    for (int i = 0; i < 3; i++) {
+        int64_t Ax = X[ea[i]], Ay = Y[ea[i]], Bx = X[eb[i]], By = Y[eb[i]];
+        s->a[i] = -(By - Ay);
+        s->b[i] = (Bx - Ax);
+        s->c[i] = (By - Ay) * Ax - (Bx - Ax) * Ay;
+    }
+    int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+    if (area2 == 0) return 0;
+    if (area2 < 0) { /* no culling (ConversionPass.cpp:48): accept both windings */
+        area2 = -area2;
+        for (int i = 0; i < 3; i++) { s->a[i] = -s->a[i]; s->b[i] = -s->b[i]; s->c[i] = -s->c[i]; }
+    }
+    s->area2 = area2;
+    for (int i = 0; i < 3; i++) s->bias[i] = (s->a[i] > 0) || (s->a[i] == 0 && s->b[i] > 0);
+    /* pixel bbox: centres 256*x+128 within [min,max], clamped to the R x R viewport */
+    int64_t xmin = X[0], xmax = X[0], ymin = Y[0], ymax = Y[0];
+    for (int i = 1; i < 3; i++) {
+        if (X[i] < xmin) xmin = X[i];
+        if (X[i] > xmax) xmax = X[i];
+        if (Y[i] < ymin) ymin = Y[i];
+        if (Y[i] > ymax) ymax = Y[i];
+    }
+    int64_t bx0 = (xmin - 128 + 255) >> 8, bx1 = (xmax - 128) >> 8;
+    int64_t by0 = (ymin - 128 + 255) >> 8, by1 = (ymax - 128) >> 8;
+    if (bx0 < 0) bx0 = 0;
+    if (by0 < 0) by0 = 0;
+    if (bx1 > (int64_t)R - 1) bx1 = (int64_t)R - 1;
+    if (by1 > (int64_t)R - 1) by1 = (int64_t)R - 1;
+    s->x0 = (int)bx0; s->x1 = (int)bx1; s->y0 = (int)by0; s->y1 = (int)by1;
+    return bx0 <= bx1 && by0 <= by1;
+}
+
+
 /* converterGS.glsl:326-443 + viewport transform (ConversionPass.cpp:45) + pinned raster setup.
  * Returns 0 if the triangle can produce no fragments. */
 static int setup_triangle(const float* v0, const float* v1, const float* v2, const float bmin[3],
@@ -275,51 +323,11 @@ static int setup_triangle(const float* v0, const float* v1, const float* v2, con
     s->scale_x = v3len(Ju);
     s->scale_y = v3len(Jv);
 
-    /* GS:439 gl_Position = (uv*2-1, 0, 1); GL 4.6 13.8.1 viewport transform with
-     * glViewport(0,0,R,R): xw = (R/2)*xd + R/2.  Snap to 1/256 px, round-to-nearest-even. */
-    float half = (float)R * 0.5f;
-    int64_t X[3], Y[3];
-    for (int i = 0; i < 3; i++) {
-        float ndx = ou[i] * 2.0f - 1.0f, ndy = ov[i] * 2.0f - 1.0f;
-        float xw = half * ndx + half, yw = half * ndy + half;
-        if (!(fabsf(xw) < GUARD_PX) || !(fabsf(yw) < GUARD_PX)) return 0; /* NaN/inf/absurd */
-        X[i] = (int64_t)rintf(xw * 256.0f);
-        Y[i] = (int64_t)rintf(yw * 256.0f);
-    }
-    /* edge i is opposite vertex i: E0 = orient(V1,V2,P), E1 = orient(V2,V0,P), E2 = orient(V0,V1,P) */
-    static const int ea[3] = { 1, 2, 0 }, eb[3] = { 2, 0, 1 };
-    for (int i = 0; i < 3; i++) {
-        int64_t Ax = X[ea[i]], Ay = Y[ea[i]], Bx = X[eb[i]], By = Y[eb[i]];
-        s->a[i] = -(By - Ay);
-        s->b[i] = (Bx - Ax);
-        s->c[i] = (By - Ay) * Ax - (Bx - Ax) * Ay;
-    }
-    int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-    if (area2 == 0) return 0;
-    if (area2 < 0) { /* no culling (ConversionPass.cpp:48): accept both windings */
-        area2 = -area2;
-        for (int i = 0; i < 3; i++) { s->a[i] = -s->a[i]; s->b[i] = -s->b[i]; s->c[i] = -s->c[i]; }
-    }
-    s->area2 = area2;
-    for (int i = 0; i < 3; i++) s->bias[i] = (s->a[i] > 0) || (s->a[i] == 0 && s->b[i] > 0);
-    /* pixel bbox: centres 256*x+128 within [min,max], clamped to the R x R viewport */
-    int64_t xmin = X[0], xmax = X[0], ymin = Y[0], ymax = Y[0];
-    for (int i = 1; i < 3; i++) {
-        if (X[i] < xmin) xmin = X[i];
-        if (X[i] > xmax) xmax = X[i];
-        if (Y[i] < ymin) ymin = Y[i];
-        if (Y[i] > ymax) ymax = Y[i];
-    }
-    int64_t bx0 = (xmin - 128 + 255) >> 8, bx1 = (xmax - 128) >> 8;
-    int64_t by0 = (ymin - 128 + 255) >> 8, by1 = (ymax - 128) >> 8;
-    if (bx0 < 0) bx0 = 0;
-    if (by0 < 0) by0 = 0;
-    if (bx1 > (int64_t)R - 1) bx1 = (int64_t)R - 1;
-    if (by1 > (int64_t)R - 1) by1 = (int64_t)R - 1;
-    s->x0 = (int)bx0; s->x1 = (int)bx1; s->y0 = (int)by0; s->y1 = (int)by1;
-    return bx0 <= bx1 && by0 <= by1;
+    /* GS:439 gl_Position = (uv*2-1, 0, 1) */
+    float ndx[3], ndy[3];
+    for (int i = 0; i < 3; i++) { ndx[i] = ou[i] * 2.0f - 1.0f; ndy[i] = ov[i] * 2.0f - 1.0f; }
+    return raster_setup(ndx, ndy, R, s);
 }
-
 static inline int covered(const tri_setup* s, int x, int y, int64_t E[3]) {
     int64_t Px = 256 * (int64_t)x + 128, Py = 256 * (int64_t)y + 128;
     for (int i = 0; i < 3; i++) {
@@ -575,6 +583,38 @@ int orc_debug_gs(const float* v0, const float* v1, const float* v2, const float 
     scale_xyz[0] = s.scale_x; scale_xyz[1] = s.scale_y; scale_xyz[2] = 1e-7f;
     for (int i = 0; i < 4; i++) rot_wxyz[i] = s.rot[i];
     return ok;
+}
+
+/* Fixed-function stages for the software-GL harness (oracle/ref_pipeline_check.cpp): the fragments, in canonical
+ * (row, column) order, of the triangle whose clip-space positions are (ndc_x, ndc_y, 0, 1).  xy[2i..] = pixel,
+ * l12[2i..] = screen-linear weights of vertices 1 and 2, grad = d(l1)/dx, d(l2)/dx, d(l1)/dy, d(l2)/dy per pixel. */
+uint64_t orc_debug_raster(const float ndc_xy[6], uint32_t R, uint64_t max_frag, int32_t* xy, float* l12, float grad[4]) {
+    tri_setup s;
+    memset(&s, 0, sizeof s);
+    const float ndx[3] = { ndc_xy[0], ndc_xy[2], ndc_xy[4] }, ndy[3] = { ndc_xy[1], ndc_xy[3], ndc_xy[5] };
+    if (!raster_setup(ndx, ndy, R, &s)) return 0;
+    float inva = 1.0f / (float)s.area2;
+    grad[0] = (float)(s.a[1] * 256) * inva; grad[1] = (float)(s.a[2] * 256) * inva;
+    grad[2] = (float)(s.b[1] * 256) * inva; grad[3] = (float)(s.b[2] * 256) * inva;
+    uint64_t n = 0;
+    int64_t E[3];
+    for (int y = s.y0; y <= s.y1; y++)
+        for (int x = s.x0; x <= s.x1; x++) {
+            if (!covered(&s, x, y, E)) continue;
+            if (n < max_frag) {
+                xy[2 * n] = x; xy[2 * n + 1] = y;
+                l12[2 * n] = (float)E[1] * inva; l12[2 * n + 1] = (float)E[2] * inva;
+            }
+            n++;
+        }
+    return n;
+}
+
+float orc_debug_lod(uint32_t w, uint32_t h, float dudx, float dvdx, float dudy, float dvdy) {
+    tex_t t;
+    memset(&t, 0, sizeof t);
+    t.w = w; t.h = h;
+    return lod_lambda(&t, dudx, dvdx, dudy, dvdy);
 }
 
 void orc_debug_sample(const orc_scene* sc, uint32_t mesh, int slot, float u, float v, float lambda, float out[4]) {

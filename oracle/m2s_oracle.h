@@ -22,6 +22,9 @@
  *     24-float record agree BIT FOR BIT (oracle/ref_glsl_check.cpp, tests/test_ref_glsl.py);
  *   - parsers.cpp / SceneManager.cpp / tiny_gltf / stb_image with GL stubbed: PLY writers byte for byte, PLY reader
  *     and .glb loader bit for bit (oracle/ref_host_check.cpp, tests/test_ref_host.py);
+ *   - the whole path (SceneManager::loadModel -> ConversionPass::execute -> shaders -> SceneManager::exportPly) on a
+ *     minimal software GL built from this oracle's fixed-function stages: counter, cap, every record and the .ply
+ *     agree bit for bit with orc_convert / orc_write_ply (oracle/ref_pipeline_check.cpp, tests/test_ref_pipeline.py);
  *   - glm::quat_cast and the glm node transforms (oracle/ref_glm_check.cpp, ref_glm_xform_check.cpp).
  * The reference's outputs are committed as fixtures (tests/golden/ref_host/, generator alongside).
  * PARITY UNPINNED for the fixed-function part only — pixel coverage, varying interpolation, mip generation, LOD and
@@ -85,6 +88,8 @@ uint64_t orc_scene_convert(const orc_scene* sc, uint32_t R, uint64_t tri_first, 
  * stored, i.e. w,x,y,z), one texture fetch, and the FS for one set of interpolated varyings. */
 int orc_debug_gs(const float* v0, const float* v1, const float* v2, const float bmin[3], const float bmax[3],
                  uint32_t R, float ndc_xy[6], float scale_xyz[3], float rot_wxyz[4]);
+uint64_t orc_debug_raster(const float ndc_xy[6], uint32_t R, uint64_t max_frag, int32_t* xy, float* l12, float grad[4]);
+float orc_debug_lod(uint32_t w, uint32_t h, float dudx, float dvdx, float dudy, float dvdy);
 void orc_debug_sample(const orc_scene* sc, uint32_t mesh, int slot, float u, float v, float lambda, float out[4]);
 void orc_debug_fs(const orc_scene* sc, uint32_t mesh, const float varyings[12], const float lam[3],
                   const float scale_xy[2], const float rot_wxyz[4], float record[ORC_RECORD_FLOATS]);

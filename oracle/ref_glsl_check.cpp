@@ -21,8 +21,7 @@
 //
 // scene.bin (written by tests/test_ref_glsl.py): u32 n_meshes; per mesh: u32 n_vertices, float bmin[3], bmax[3],
 // color[4], n_vertices x 12 floats (pos, normal, tangent, uv), 3 x {u32 w, u32 h, w*h*4 bytes}.
-#define GLM_FORCE_SWIZZLE
-#include <glm/glm.hpp>
+#include "ref_glsl_env.h"
 
 #include <cmath>
 #include <cstdint>
@@ -35,51 +34,15 @@ extern "C" {
 #include "m2s_oracle.h"
 }
 
-// ---- GLSL environment shared by the three stages -----------------------------------------------------------
-namespace glsl_env {
-using namespace glm;
-
-struct Emitted { vec4 gl_Position; vec3 Position, Scale, Normal; vec2 UV; vec4 Tangent, Quaternion; };
-static std::vector<Emitted> g_emitted;
-
-struct sampler2D { int slot; };
-struct atomic_uint { unsigned v; };
-static inline uint atomicCounterIncrement(atomic_uint& c) { return c.v++; }
-
+// texture(): bound to the oracle's sampler with an explicit level of detail per texture slot
 static const orc_scene* g_scene = nullptr;
 static uint32_t g_mesh = 0;
 static float g_lambda[3] = { 0, 0, 0 };
-static inline vec4 texture(const sampler2D& s, vec2 uv) {
+static glm::vec4 fetch_texel(int slot, glm::vec2 uv) {
     float o[4];
-    orc_debug_sample(g_scene, g_mesh, s.slot, uv.x, uv.y, g_lambda[s.slot], o);
-    return vec4(o[0], o[1], o[2], o[3]);
+    orc_debug_sample(g_scene, g_mesh, slot, uv.x, uv.y, g_lambda[slot], o);
+    return glm::vec4(o[0], o[1], o[2], o[3]);
 }
-}  // namespace glsl_env
-
-namespace vs {
-using namespace glm;
-#include "_ref/gen/converterVS.inc"
-}  // namespace vs
-
-namespace gs {
-using namespace glm;
-static vec4 gl_Position;
-static void EmitVertex();
-static void EndPrimitive() {}
-#include "_ref/gen/converterGS.inc"
-static void EmitVertex() {
-    glsl_env::g_emitted.push_back({ gl_Position, Position, Scale, Normal, UV, Tangent, Quaternion });
-}
-}  // namespace gs
-
-namespace fs {
-using namespace glm;
-using glsl_env::atomic_uint;
-using glsl_env::atomicCounterIncrement;
-using glsl_env::sampler2D;
-using glsl_env::texture;
-#include "_ref/gen/converterFS.inc"
-}  // namespace fs
 
 // ---- statistics -------------------------------------------------------------------------------------------------
 struct Stat {
@@ -144,7 +107,8 @@ int main(int argc, char** argv) {
     }
     fclose(f);
     orc_scene* sc = orc_scene_create(om.data(), n_meshes);
-    glsl_env::g_scene = sc;
+    g_scene = sc;
+    glsl_env::g_texture = fetch_texel;
 
     Stat st_ndc, st_scale, st_quat, st_pos, st_col, st_nrm, st_pbr, st_const;
     uint64_t n_tri = 0, n_frag = 0, n_quat_sign = 0, n_degenerate = 0;
@@ -153,38 +117,38 @@ int main(int argc, char** argv) {
 
     for (uint32_t m = 0; m < n_meshes; ++m) {
         const MeshIn& mi = meshes[m];
-        glsl_env::g_mesh = m;
+        g_mesh = m;
         // uniforms (ConversionPass.cpp:100-112)
-        gs::u_bboxMin = glm::vec3(mi.bmin[0], mi.bmin[1], mi.bmin[2]);
-        gs::u_bboxMax = glm::vec3(mi.bmax[0], mi.bmax[1], mi.bmax[2]);
-        fs::albedoTexture.slot = 0; fs::normalTexture.slot = 1; fs::metallicRoughnessTexture.slot = 2;
-        fs::hasAlbedoMap = mi.tex[0].empty() ? 0 : 1;
-        fs::hasNormalMap = mi.tex[1].empty() ? 0 : 1;
-        fs::hasMetallicRoughnessMap = mi.tex[2].empty() ? 0 : 1;
-        fs::u_materialFactor = glm::vec4(mi.color[0], mi.color[1], mi.color[2], mi.color[3]);
-        fs::u_maxGaussians = 1 << 30;
+        ref_gs::u_bboxMin = glm::vec3(mi.bmin[0], mi.bmin[1], mi.bmin[2]);
+        ref_gs::u_bboxMax = glm::vec3(mi.bmax[0], mi.bmax[1], mi.bmax[2]);
+        ref_fs::albedoTexture.unit = 0; ref_fs::normalTexture.unit = 1; ref_fs::metallicRoughnessTexture.unit = 2;
+        ref_fs::hasAlbedoMap = mi.tex[0].empty() ? 0 : 1;
+        ref_fs::hasNormalMap = mi.tex[1].empty() ? 0 : 1;
+        ref_fs::hasMetallicRoughnessMap = mi.tex[2].empty() ? 0 : 1;
+        ref_fs::u_materialFactor = glm::vec4(mi.color[0], mi.color[1], mi.color[2], mi.color[3]);
+        ref_fs::u_maxGaussians = 1 << 30;
         const size_t nt = mi.verts.size() / 36;
         for (size_t t = 0; t < nt; ++t) {
             const float* v[3] = { &mi.verts[(t * 3 + 0) * 12], &mi.verts[(t * 3 + 1) * 12], &mi.verts[(t * 3 + 2) * 12] };
             // ---- VS (reference) x3 -> GS inputs
             for (int i = 0; i < 3; ++i) {
-                vs::position = glm::vec3(v[i][0], v[i][1], v[i][2]);
-                vs::normal = glm::vec3(v[i][3], v[i][4], v[i][5]);
-                vs::tangent = glm::vec4(v[i][6], v[i][7], v[i][8], v[i][9]);
-                vs::uv = glm::vec2(v[i][10], v[i][11]);
-                vs::normalizedUv = glm::vec2(0);
-                vs::scale = glm::vec3(0);
-                vs::main_();
-                gs::gs_in[i].position = vs::vs_out.position;
-                gs::gs_in[i].normal = vs::vs_out.normal;
-                gs::gs_in[i].tangent = vs::vs_out.tangent;
-                gs::gs_in[i].uv = vs::vs_out.uv;
-                gs::gs_in[i].normalizedUv = vs::vs_out.normalizedUv;
-                gs::gs_in[i].scale = vs::vs_out.scale;
+                ref_vs::position = glm::vec3(v[i][0], v[i][1], v[i][2]);
+                ref_vs::normal = glm::vec3(v[i][3], v[i][4], v[i][5]);
+                ref_vs::tangent = glm::vec4(v[i][6], v[i][7], v[i][8], v[i][9]);
+                ref_vs::uv = glm::vec2(v[i][10], v[i][11]);
+                ref_vs::normalizedUv = glm::vec2(0);
+                ref_vs::scale = glm::vec3(0);
+                ref_vs::main_();
+                ref_gs::gs_in[i].position = ref_vs::vs_out.position;
+                ref_gs::gs_in[i].normal = ref_vs::vs_out.normal;
+                ref_gs::gs_in[i].tangent = ref_vs::vs_out.tangent;
+                ref_gs::gs_in[i].uv = ref_vs::vs_out.uv;
+                ref_gs::gs_in[i].normalizedUv = ref_vs::vs_out.normalizedUv;
+                ref_gs::gs_in[i].scale = ref_vs::vs_out.scale;
             }
             // ---- GS (reference)
             glsl_env::g_emitted.clear();
-            gs::main_();
+            ref_gs::main_();
             if (glsl_env::g_emitted.size() != 3) { fprintf(stderr, "GS emitted %zu vertices\n", glsl_env::g_emitted.size()); return 3; }
             const auto& E = glsl_env::g_emitted;
             // ---- oracle GS
@@ -227,24 +191,24 @@ int main(int argc, char** argv) {
                 // level of detail: an input to both sides (fixed-function in GL); exercise magnification,
                 // fractional levels and the clamp at the last level
                 const float lam_choices[5] = { -1.5f, 0.0f, 0.37f, 1.62f, 9.0f };
-                for (int k = 0; k < 3; ++k) glsl_env::g_lambda[k] = lam_choices[(s + k + (int)t) % 5];
+                for (int k = 0; k < 3; ++k) g_lambda[k] = lam_choices[(s + k + (int)t) % 5];
                 // reference FS, flat inputs from the reference GS (provoking vertex = last, all three equal here)
-                fs::Position = glm::vec3(vary[0], vary[1], vary[2]);
-                fs::Normal = glm::vec3(vary[3], vary[4], vary[5]);
-                fs::Tangent = glm::vec4(vary[6], vary[7], vary[8], vary[9]);
-                fs::UV = glm::vec2(vary[10], vary[11]);
-                fs::Scale = E[2].Scale;
-                fs::Quaternion = E[2].Quaternion;
-                fs::GaussianVertex slot;
+                ref_fs::Position = glm::vec3(vary[0], vary[1], vary[2]);
+                ref_fs::Normal = glm::vec3(vary[3], vary[4], vary[5]);
+                ref_fs::Tangent = glm::vec4(vary[6], vary[7], vary[8], vary[9]);
+                ref_fs::UV = glm::vec2(vary[10], vary[11]);
+                ref_fs::Scale = E[2].Scale;
+                ref_fs::Quaternion = E[2].Quaternion;
+                ref_fs::GaussianVertex slot;
                 std::memset(&slot, 0, sizeof slot);
-                fs::gaussianBuffer.vertices = &slot;
-                fs::g_validCounter.v = 0;
-                fs::main_();
+                ref_fs::gaussianBuffer.vertices = &slot;
+                ref_fs::g_validCounter.v = 0;
+                ref_fs::main_();
                 const float* ref = reinterpret_cast<const float*>(&slot);
-                if (dump) { fwrite(vary, 4, 12, dump); fwrite(glsl_env::g_lambda, 4, 3, dump); fwrite(ref, 4, 24, dump); }
+                if (dump) { fwrite(vary, 4, 12, dump); fwrite(g_lambda, 4, 3, dump); fwrite(ref, 4, 24, dump); }
                 // oracle FS, flat inputs from the oracle GS
                 float rec[24];
-                orc_debug_fs(sc, m, vary, glsl_env::g_lambda, scl, rot, rec);
+                orc_debug_fs(sc, m, vary, g_lambda, scl, rot, rec);
                 ++n_frag;
                 const float pm = vmax3(ref);
                 for (int k = 0; k < 3; ++k) st_pos.add(ref[k], rec[k], pm);

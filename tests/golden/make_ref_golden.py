@@ -54,6 +54,19 @@ def glsl_cases():
     yield "soup_untextured", plain, 64, 2
 
 
+def pipeline_cases():
+    """(name, scene, R, write_glb kwargs) for the whole-pass fixtures (kept small: they are committed)."""
+    mixed = synth.sphere_grid(2, n=2, tex_size=8)
+    mixed.meshes[1].textures.pop("normalTexture", None)
+    mixed.meshes[2].textures.clear()
+    mixed.meshes[3].base_color = (0.2, 0.4, 0.6, 0.8)
+    q = np.array([0.3, -0.1, 0.2, 0.9])
+    q /= np.linalg.norm(q)
+    trs = [dict(translation=(0.5, 0, 0), rotation=q), dict(scale=(1, -1, 1)), {}, dict(scale=(0.5, 2, 1))] + [{}] * 4
+    yield "mixed_trs", mixed, 16, dict(node_trs=trs, nested=True)
+    yield "soup", synth.random_soup(60, seed=9, textures=synth.procedural_textures(8, 2)), 32, dict(indexed=False)
+
+
 def sample_records():
     scene = synth.random_soup(24, seed=11, textures=synth.procedural_textures(16, 2))
     scene.meshes[0].base_color = (1.0, 0.9, 0.8, 1.0)
@@ -94,6 +107,13 @@ def main():
         shutil.copy(os.path.join(tmp, "glsl_scene.bin"), os.path.join(OUT, f"glsl_{name}.scene.bin"))
         with open(os.path.join(OUT, f"glsl_{name}.report.json"), "w") as f:
             json.dump(dict(R=R, samples=samples, **rep), f, indent=1)
+    # the reference's WHOLE path (loadModel -> ConversionPass::execute -> shaders -> exportPly) on the software GL
+    assert refhost.pipeline_available()
+    for name, scene, R, kw in pipeline_cases():
+        glb = os.path.join(OUT, f"pipe_{name}.glb")
+        gltf_io.write_glb(scene, glb, **kw)
+        ply = os.path.join(OUT, f"pipe_{name}_R{R}.ply") if name == "soup" else None   # SceneManager::exportPly, format 1
+        refhost.run_pipeline(glb, R, tmp, ply_path=ply, fmt=1, std=0.65, out_path=os.path.join(OUT, f"pipe_{name}_R{R}.records.bin"))
     print("wrote", sorted(os.listdir(OUT)), sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)), "bytes")
 
 

@@ -152,3 +152,31 @@ def parse_glsl_scene(blob: bytes):
                            bbox_min=hdr[0:3].copy(), bbox_max=hdr[3:6].copy()))
     assert o == len(blob)
     return Scene(meshes)
+
+
+# ---- the reference's whole conversion path on a software GL (oracle/_ref/ref_pipeline_check) ---------------
+PIPE_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_pipeline_check")
+
+
+def pipeline_available() -> bool:
+    return os.path.isfile(PIPE_BIN) and os.access(PIPE_BIN, os.X_OK)
+
+
+def parse_pipeline_dump(blob: bytes):
+    """-> dict(counter, max_gaussians, ssbo_bytes, records (n,24) float32)"""
+    counter, cap, ssbo = struct.unpack_from("<IIQ", blob, 0)
+    rec = np.frombuffer(blob, np.float32, -1, 16).reshape(-1, 24).copy()
+    assert rec.shape[0] == min(counter, cap)
+    return dict(counter=counter, max_gaussians=cap, ssbo_bytes=ssbo, records=rec)
+
+
+def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, out_path: str = None):
+    out = out_path or os.path.join(tmp_dir, "ref_pipeline.bin")
+    cmd = [PIPE_BIN, glb_path, str(int(R)), out]
+    if ply_path:
+        cmd += [ply_path, str(int(fmt)), "%.9g" % float(np.float32(std))]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(f"ref_pipeline_check failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-400:]}")
+    with open(out, "rb") as f:
+        return parse_pipeline_dump(f.read())

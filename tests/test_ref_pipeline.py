@@ -1,0 +1,75 @@
+"""CPU: the oracle against the reference's WHOLE conversion path.
+
+oracle/ref_pipeline_check.cpp runs SceneManager::loadModel -> ConversionPass::execute -> converter{VS,GS,FS}.glsl ->
+SceneManager::exportPly, all compiled from /root/reference, on a minimal software GL whose fixed-function stages
+(raster, interpolation, LOD, filtering, mip generation) are the oracle's pinned ones.  Counter, cap (u_maxGaussians),
+SSBO size, every record and the exported .ply must be IDENTICAL to orc_convert / orc_write_ply on the loaded scene:
+that pins draw order, cumulative bounding boxes, per-mesh uniforms and texture flags, cap and counter semantics.
+
+  * golden — committed reference outputs (tests/golden/ref_host/pipe_*); always runs.
+  * live   — more scenes, incl. a cap overflow; skipped where oracle/_ref was not built."""
+import os
+
+import numpy as np
+import pytest
+
+import refhost
+from mesh2splat_amd import gltf_io, synth
+from mesh2splat_amd.scene import reference_cap
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host")
+GOLDEN = [("mixed_trs", 16), ("soup", 32)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def check_against_oracle(oracle, ref, scene, R):
+    cap = reference_cap(R, scene.n_meshes)
+    assert ref["max_gaussians"] == cap == oracle.reference_cap(R, scene.n_meshes)
+    assert ref["ssbo_bytes"] == cap * 96                                   # ConversionPass.cpp:25-33
+    total, rec, _ = oracle.convert(scene, R, cap=cap)
+    assert ref["counter"] == total                                          # unclamped counter (ConversionPass.cpp:56-59)
+    assert rec.shape == ref["records"].shape and np.array_equal(bits(rec), bits(ref["records"]))
+    return rec
+
+
+@pytest.mark.parametrize("name,R", GOLDEN)
+def test_oracle_matches_reference_pipeline_golden(tmp_path, hiplib, oracle, name, R):
+    with open(os.path.join(GOLD, f"pipe_{name}_R{R}.records.bin"), "rb") as f:
+        ref = refhost.parse_pipeline_dump(f.read())
+    scene = gltf_io.load_glb(os.path.join(GOLD, f"pipe_{name}.glb"))
+    rec = check_against_oracle(oracle, ref, scene, R)
+    ply = os.path.join(GOLD, f"pipe_{name}_R{R}.ply")
+    if os.path.exists(ply):                                                 # SceneManager::exportPly, format 1, std 0.65
+        mine = str(tmp_path / "o.ply")
+        oracle.write_ply(mine, rec, 1, np.float32(0.65) / np.float32(R))
+        assert open(mine, "rb").read() == open(ply, "rb").read()
+
+
+def live_cases():
+    yield "sphere", synth.cube_sphere(8, tex_size=32), 96, {}
+    yield "grid", synth.sphere_grid(2, n=3, tex_size=8), 48, {}
+    yield "colocated", synth.colocated_spheres(3, n=3, tex_size=8), 40, {}
+    yield "soup_flat", synth.random_soup(200, seed=4), 64, dict(with_normals=False, with_tangents=False)
+    yield "quad", synth.unit_quad(), 33, {}
+    yield "cap_overflow", synth.random_soup(2500, seed=8, textures=synth.procedural_textures(8, 1)), 32, dict(indexed=False)
+
+
+@pytest.mark.skipif(not refhost.pipeline_available(), reason="oracle/_ref/ref_pipeline_check not built (needs /root/reference)")
+@pytest.mark.parametrize("case", list(live_cases()), ids=lambda c: c[0])
+def test_oracle_matches_reference_pipeline_live(tmp_path, hiplib, oracle, case):
+    name, scene, R, kw = case
+    glb = str(tmp_path / (name + ".glb"))
+    gltf_io.write_glb(scene, glb, **kw)
+    overflow = name == "cap_overflow"
+    ply = None if overflow else str(tmp_path / "ref.ply")
+    ref = refhost.run_pipeline(glb, R, str(tmp_path), ply_path=ply, fmt=0, std=0.65)
+    rec = check_against_oracle(oracle, ref, gltf_io.load_glb(glb), R)
+    if overflow:
+        assert ref["counter"] > ref["max_gaussians"] == len(rec)            # counter keeps counting past the cap (FS:46-51)
+    else:
+        mine = str(tmp_path / "o.ply")
+        oracle.write_ply(mine, rec, 0, np.float32(0.65) / np.float32(R))
+        assert open(mine, "rb").read() == open(ply, "rb").read()
