@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
+    ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()
@@ -138,16 +139,72 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     out = None
-    counts = torch.zeros(world, dtype=torch.int64, device="cuda")
-    mine = torch.zeros(1, dtype=torch.int64, device="cuda")
+    RING = 4              # counters of up to RING steps in flight: each all-gather owns its send and receive slot
+    counts_ring = torch.zeros((RING, world), dtype=torch.int64, device="cuda")
+    mine_ring = torch.zeros((RING, 1), dtype=torch.int64, device="cuda")
+    counts = counts_ring[0]
+    n_published = [0]
 
-    def step():
+    # Steps are pipelined two deep (m2s_convert_submit / m2s_convert_wait): while the GPU runs conversion k the host
+    # has already enqueued k+1 and reads k's counter afterwards.  Every conversion runs to completion inside the
+    # timed region and every counter is read back; what disappears is the launch + completion round trip between
+    # consecutive kernels.  --sync-steps restores one blocking call per step.
+    side = torch.cuda.Stream() if multi else None
+    pending = []          # outstanding counter all-gathers (multi-GPU)
+
+    def publish(total):
+        """offsets of every rank in the merged buffer: an 8-byte all-gather per step, off the conversion stream"""
+        nonlocal counts
+        k = n_published[0] % RING
+        n_published[0] += 1
+        counts = counts_ring[k]
+        with torch.cuda.stream(side):
+            mine_ring[k].fill_(total)
+            pending.append(dist.all_gather_into_tensor(counts_ring[k], mine_ring[k], async_op=True))
+            while len(pending) > 2:
+                pending.pop(0).wait()    # (orders the side stream behind an all-gather issued two steps ago; the host does not block)
+
+    def submit():
+        if multi:
+            conv.submit(R, out.data_ptr(), out.shape[0], stream)
+        else:
+            conv.submit(R)
+
+    def step_sync():
         if not multi:
             return conv.convert(R)
-        nonlocal out
         total = conv.convert_into(R, out.data_ptr(), out.shape[0], stream)
-        mine.fill_(total)
-        dist.all_gather_into_tensor(counts, mine)   # offsets of every rank in the merged buffer
+        publish(total)
+        return total
+
+    PROF_EVERY = 8        # HIP events bracket every 8th launch: an event pair costs ~10 us of stream time per launch
+    n_prof = [0]
+
+    def run_steps(k, timed=False):
+        """k conversions, pipelined two deep; returns the last counter; accumulates the sampled kernel times"""
+        total = 0
+        if a.sync_steps:
+            for i in range(k):
+                conv.set_profiling(timed and i % PROF_EVERY == 0)
+                total = step_sync()
+                if timed and i % PROF_EVERY == 0:
+                    n_prof[0] += 1
+                    for n_, v in conv.last_kernel_ms().items():
+                        kms[n_] += v
+            return total
+        conv.set_profiling(timed)
+        submit()
+        for i in range(k):
+            if i + 1 < k:
+                conv.set_profiling(timed and (i + 1) % PROF_EVERY == 0)
+                submit()
+            total = conv.wait()
+            if multi:
+                publish(total)
+            if timed and i % PROF_EVERY == 0:
+                n_prof[0] += 1
+                for n_, v in conv.last_kernel_ms().items():
+                    kms[n_] += v
         return total
 
     if multi:
@@ -162,20 +219,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    conv.set_profiling(True)   # HIP events around every kernel, on the stream the kernels run on
     kms = {k: 0.0 for k in ("count", "scan", "offsets", "emit", "fused")}
+    if a.warmup:
+        run_steps(a.warmup)
+    kms = {k: 0.0 for k in kms}
     sync()
     t0 = time.perf_counter()
-    total = 0
-    for _ in range(a.steps):
-        total = step()
-        for k, v in conv.last_kernel_ms().items():
-            kms[k] += v
+    total = run_steps(a.steps, timed=True)   # HIP events on the launch stream around every PROF_EVERY-th launch
+    if pending:
+        with torch.cuda.stream(side):
+            for w in pending:
+                w.wait()
+        pending.clear()
     sync()
     dt = time.perf_counter() - t0
     conv.set_profiling(False)
+    # for the record: the same loop with one blocking call per step (outside the timed region)
+    sync()
+    s0 = time.perf_counter()
+    for _ in range(min(a.steps, 20)):
+        step_sync()
+    if pending:
+        with torch.cuda.stream(side):
+            for w in pending:
+                w.wait()
+        pending.clear()
+    sync()
+    sync_ms = (time.perf_counter() - s0) / min(a.steps, 20) * 1e3
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
@@ -200,7 +270,7 @@ def main():
         g0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            step()
+            step_sync()
             send[: out.shape[0]] = out
             dist.all_gather_into_tensor(recv, send)
         sync()
@@ -211,7 +281,7 @@ def main():
 
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        emit_ms = kms[dom] / a.steps
+        emit_ms = kms[dom] / max(n_prof[0], 1)
         # algorithmic bytes of one emit launch: 96 B per Gaussian written + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
         b_alg = 96.0 * total + 144.0 * T_local
@@ -227,8 +297,12 @@ def main():
                                    (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
                                     f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
-                       "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula"},
-            "kernel_ms": {k: v / a.steps for k, v in kms.items()},
+                       "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
+                       "submission": "one blocking call per step" if a.sync_steps else
+                                     "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
+            "sync_ms_per_step": sync_ms,
+            "kernel_ms": {k: v / max(n_prof[0], 1) for k, v in kms.items()},
+            "kernel_timing": f"HIP events on the launch stream around every {PROF_EVERY}th launch of the timed region ({n_prof[0]} launches)",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_" + dom,
                          "algorithmic_bytes": b_alg,

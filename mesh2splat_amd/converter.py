@@ -105,6 +105,17 @@ class Converter:
                                              C.c_void_p(stream), C.byref(total)))
         return int(total.value)
 
+    def submit(self, R: int, device_ptr: int = 0, capacity_records: int = 0, stream: int = 0) -> None:
+        """Enqueue one conversion without waiting (m2s_convert_submit); device_ptr == 0 uses the context's buffer."""
+        self._check(self._L.m2s_convert_submit(self._h, int(R), C.c_void_p(device_ptr or None), int(capacity_records),
+                                               C.c_void_p(stream or None)))
+
+    def wait(self) -> int:
+        """Counter of the oldest submitted conversion, once it has finished (m2s_convert_wait)."""
+        total = C.c_uint64()
+        self._check(self._L.m2s_convert_wait(self._h, C.byref(total)))
+        return int(total.value)
+
     @property
     def num_stored(self) -> int:
         return int(self._L.m2s_num_stored(self._h))

@@ -55,6 +55,14 @@ struct m2s_ctx {
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
 
+    // asynchronous submissions (m2s_convert_submit / m2s_convert_wait): a ring of result slots.  Slot k uses
+    // h_total[2 + 2k] (counter) and h_total[3 + 2k] (status words), written by the kernel itself.
+    struct Slot { hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr; uint64_t limit = 0; void* d_out = nullptr; uint32_t R = 0;
+                  bool sync_result = false; uint64_t sync_total = 0; bool prof = false; };
+    Slot slot[M2S_MAX_IN_FLIGHT];
+    uint32_t slot_head = 0, slot_count = 0; // oldest in-flight slot, number in flight
+    uint32_t async_ok_R = 0;                // R at which a completed conversion of this scene needed no host decision
+
     // output
     void* d_records = nullptr;
     uint64_t records_cap = 0;  // records
@@ -106,6 +114,7 @@ static void free_scene(m2s_ctx* c) {
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr;
     c->sized_R = 0;
     c->multipass_R = 0;
+    c->async_ok_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
     c->d_cnt = c->d_off = c->d_partials = nullptr;
@@ -141,10 +150,14 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->h_total, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void**)&c->h_total, (2 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto& sl : c->slot)
+        if ((e = hipEventCreate(&sl.done)) != hipSuccess || (e = hipEventCreate(&sl.t0)) != hipSuccess ||
+            (e = hipEventCreate(&sl.t1)) != hipSuccess)
+            return bail("hipEventCreate", e);
     *out_ctx = c;
     return M2S_OK;
 }
@@ -153,6 +166,10 @@ void m2s_destroy(m2s_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (uint32_t k = 0; k < c->slot_count; ++k) {   // conversions still in flight on a caller's stream
+        auto& sl = c->slot[(c->slot_head + k) % M2S_MAX_IN_FLIGHT];
+        if (!sl.sync_result) (void)hipEventSynchronize(sl.done);
+    }
     free_scene(c);
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
@@ -162,6 +179,11 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& sl : c->slot) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.t0) (void)hipEventDestroy(sl.t0);
+        if (sl.t1) (void)hipEventDestroy(sl.t1);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -182,6 +204,7 @@ m2s_status m2s_set_max_gaussians(m2s_ctx* c, int64_t cap) {
 
 m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshes) {
     if (!c) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (n_meshes && !meshes) return fail(c, M2S_ERR_INVALID, "meshes is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     // ---- validate + global triangle index space -------------------------------------------------
@@ -381,8 +404,11 @@ static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t 
     return M2S_OK;
 }
 
-static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total) {
+static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total,
+                           bool from_submit = false) {
     if (!c->has_scene) return fail(c, M2S_ERR_STATE, "m2s_upload_scene has not been called");
+    if (c->slot_count && !from_submit)
+        return fail(c, M2S_ERR_STATE, "conversions submitted with m2s_convert_submit are still in flight: m2s_convert_wait first");
     if (R == 0 || R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [1, 4096]");
     HIPCHK(c, hipSetDevice(c->device));
     const SceneDev& sc = c->scene;
@@ -452,6 +478,8 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
         const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
         done = true;
+        // a clean single-kernel conversion: the same scene at the same R can be submitted asynchronously from now on
+        c->async_ok_R = (!err && !any_big) ? R : 0;
         if (err) {
             // The bounded look-back spin gave up (never observed; would need a dispatcher that starves earlier
             // workgroups).  Degrade to the multi-pass pipeline, which has no inter-workgroup dependency.
@@ -506,6 +534,88 @@ m2s_status m2s_convert_into(m2s_ctx* c, uint32_t R, void* d_records, uint64_t ca
     if (!d_records && capacity_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL");
     if (!d_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL (use m2s_convert for the context-owned buffer)");
     return run_pass(c, R, d_records, capacity_records, (hipStream_t)hip_stream, out_total);
+}
+
+// ---- asynchronous submissions --------------------------------------------------------------------------
+m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t capacity_records, void* hip_stream) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!d_records && capacity_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL");
+    if (c->slot_count == M2S_MAX_IN_FLIGHT) return fail(c, M2S_ERR_STATE, "M2S_MAX_IN_FLIGHT conversions already in flight");
+    if (!c->has_scene) return fail(c, M2S_ERR_STATE, "m2s_upload_scene has not been called");
+    if (R == 0 || R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [1, 4096]");
+    hipStream_t st = d_records ? (hipStream_t)hip_stream : c->stream;
+    const uint32_t k = (c->slot_head + c->slot_count) % M2S_MAX_IN_FLIGHT;
+    m2s_ctx::Slot& sl = c->slot[k];
+    const uint64_t cap = resolve_cap(c, R);
+    // Fast path: this scene at this R already converted cleanly with the single kernel (no deferred triangles, so no
+    // host decision between kernels) and the output buffer needs no (re)allocation.
+    const bool own_ready = d_records || (cap ? (c->d_records && c->records_cap == cap) : (c->d_records && c->sized_R == R));
+    const bool fast = c->scene.n_tri > 0 && c->async_ok_R == R && c->pipeline != M2S_PIPELINE_MULTIPASS && c->multipass_R != R && own_ready;
+    sl.R = R;
+    if (!fast) {
+        // first conversion of a (scene, R), or one that needs the second stage / the multi-pass pipeline: run it now
+        uint64_t total = 0;
+        const m2s_status s = run_pass(c, R, d_records, capacity_records, st, &total, true);
+        if (s != M2S_OK) return s;
+        sl.sync_result = true;
+        sl.sync_total = total;
+        sl.limit = c->last_stored;   // already clamped
+        sl.d_out = const_cast<void*>(c->last_records);
+        ++c->slot_count;
+        return M2S_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t limit;
+    void* d_out;
+    if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
+    else { limit = cap ? cap : c->records_cap; d_out = c->d_records; }
+    if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
+    unsigned long long* res = &c->h_total[2 + 2 * k];
+    res[0] = 0; res[1] = 0;
+    sl.prof = c->profiling;
+    if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
+    launch_fused(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+                 c->d_biglist, c->d_bigmeta, st);
+    if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(sl.done, st));
+    sl.sync_result = false;
+    sl.limit = limit;
+    sl.d_out = d_out;
+    ++c->slot_count;
+    return M2S_OK;
+}
+
+m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->slot_count) return fail(c, M2S_ERR_STATE, "no conversion in flight");
+    const uint32_t k = c->slot_head;
+    m2s_ctx::Slot& sl = c->slot[k];
+    c->slot_head = (c->slot_head + 1) % M2S_MAX_IN_FLIGHT;
+    --c->slot_count;
+    if (sl.sync_result) {   // run_pass already filled last_*
+        if (out_total) *out_total = sl.sync_total;
+        c->last_total = sl.sync_total; c->last_stored = sl.limit; c->last_records = sl.d_out; c->last_R = sl.R;
+        return M2S_OK;
+    }
+    HIPCHK(c, hipEventSynchronize(sl.done));
+    const uint64_t total = c->h_total[2 + 2 * k];
+    const uint32_t any_big = (uint32_t)(c->h_total[3 + 2 * k] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[3 + 2 * k] >> 32);
+    memset(c->last_ms, 0, sizeof c->last_ms);
+    if (sl.prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], sl.t0, sl.t1));
+    if (err || any_big) {   // cannot happen for a scene/R that converted cleanly before; never return partial output silently
+        c->async_ok_R = 0;
+        (void)hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
+    }
+    if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
+    c->last_total = total;
+    c->last_stored = std::min(total, sl.limit);
+    c->last_records = sl.d_out;
+    c->last_R = sl.R;
+    if (out_total) *out_total = total;
+    return M2S_OK;
 }
 
 uint64_t m2s_num_stored(const m2s_ctx* c) { return c ? c->last_stored : 0; }

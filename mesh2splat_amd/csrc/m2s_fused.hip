@@ -369,10 +369,9 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                 if (anybig) skipped = L.tskip[slot];
             }
             if (have) {
-                TriShade ts;
-                float4* dst = reinterpret_cast<float4*>(&ts);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) dst[k] = L.tri[slot * 5 + k];
+                // the TriShade fields are read from LDS where they are used rather than copied (80 B = 20 VGPRs) up front:
+                // 166 -> 160 VGPRs, no scratch, k_fused 0.1845 -> 0.1816 ms
+                const TriShade& ts = *reinterpret_cast<const TriShade*>(&L.tri[slot * 5]);
                 // wave inside one mesh (the common case): descriptors are wave-uniform -> SGPRs, scalar loads.
                 // wave straddling a mesh boundary: per-lane descriptor pointer.
                 const MeshParams* mp = uniform_mesh ? sc.meshes + m0 : sc.meshes + mymesh;
