@@ -475,6 +475,12 @@ __device__ __forceinline__ void combo_filter(const ComboPair& r0, const ComboPai
 #undef M2S_CH
 }
 
+__device__ __forceinline__ float frac_repeat(float u) {
+    float f = u - floorf(u);
+    f = (f >= 0.0f) ? f : 0.0f;   // NaN -> 0
+    return fminf(f, 1.0f);
+}
+
 __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, const TexDesc* __restrict__ t, float uf, float vf,
                                              float lambda, float out[9]) {
     const uint32_t nl = t->n_levels, w = t->w, h = t->h;
@@ -516,11 +522,6 @@ __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, 
     }
 }
 
-__device__ __forceinline__ float frac_repeat(float u) {
-    float f = u - floorf(u);
-    f = (f >= 0.0f) ? f : 0.0f;   // NaN -> 0
-    return fminf(f, 1.0f);
-}
 
 template <typename T>
 __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
