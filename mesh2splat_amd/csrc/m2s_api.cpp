@@ -330,7 +330,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
                 cd.coff[l] = (uint32_t)tot;
                 tot += (size_t)(std::max(1u, ta.w >> l) + 1) * std::max(1u, ta.h >> l) * 3;
             }
-            if (tot > 0xFFFFFFFFull) continue;  // 32-bit dword offsets
+            if (tot > 0x3FFFFFF0ull) continue;  // the sampler addresses the combo texels with 32-bit BYTE offsets
             void* mem = nullptr;
             HIPCHK(c, hipMalloc(&mem, tot * 4));
             c->tex_mem.push_back(mem);

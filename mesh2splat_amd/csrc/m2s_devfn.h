@@ -383,7 +383,8 @@ struct TexState {
     float f;     // weight of `hi` (0 = single level)
 };
 
-__device__ __forceinline__ void tex_state(const TexDesc* __restrict__ t, float uf, float vf, float lambda, TexState& st) {
+template <class TD>   // const TexDesc* in the generic or in the constant address space (see shade_from_tri)
+__device__ __forceinline__ void tex_state(TD t, float uf, float vf, float lambda, TexState& st) {
     const uint32_t nl = t->n_levels, w = t->w, h = t->h;
     const float q = (float)(nl - 1);
     float d = 0.0f, f = 0.0f;
@@ -481,8 +482,8 @@ __device__ __forceinline__ float frac_repeat(float u) {
     return fminf(f, 1.0f);
 }
 
-__device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, const TexDesc* __restrict__ t, float uf, float vf,
-                                             float lambda, float out[9]) {
+template <class MP, class TD>
+__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, float lambda, float out[9]) {
     const uint32_t nl = t->n_levels, w = t->w, h = t->h;
     const float q = (float)(nl - 1);
     float d = 0.0f, f = 0.0f;
@@ -500,12 +501,14 @@ __device__ __forceinline__ void combo_sample(const MeshParams* __restrict__ mp, 
     const bool two = __ballot(f != 0.0f) != 0ull;   // wave-uniform: does any lane blend two levels?
     // ALL row reads of both levels are requested before the first one is consumed: one memory round trip
     // instead of two (measured: the texel phase was 73 % of a strip with the levels fetched back to back)
-    const ComboPair a0 = *reinterpret_cast<const ComboPair*>(base + tlo.o0);
-    const ComboPair a1 = *reinterpret_cast<const ComboPair*>(base + tlo.o1);
+    // 32-bit byte offsets from the (scalar) base: saddr + voffset addressing, no 64-bit address arithmetic per lane
+    // (m2s_upload_scene only builds a combo texture whose size fits)
+    const ComboPair a0 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo.o0 * 4u));
+    const ComboPair a1 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo.o1 * 4u));
     if (two) {
         combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
-        const ComboPair b0 = *reinterpret_cast<const ComboPair*>(base + thi.o0);
-        const ComboPair b1 = *reinterpret_cast<const ComboPair*>(base + thi.o1);
+        const ComboPair b0 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi.o0 * 4u));
+        const ComboPair b1 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi.o1 * 4u));
         // fold the level blend (1-f, f) and the UNORM8 scale into the eight bilinear weights: 8 FMAs per
         // channel and nothing else (VALUE arithmetic: same quantity as (1-f)*tau_lo + f*tau_hi, other rounding)
         const float klo = (1.0f - f) * kUnorm8, khi = f * kUnorm8;
@@ -532,7 +535,15 @@ __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
 // The per-fragment part of rasteriser + FS (converterFS.glsl:44-104) for pixel (x,y) of triangle t.
 // `mp` should be wave-uniform (scalar) for speed; correctness does not depend on it.
 // `stamps` (debug timing builds only, else nullptr and folded away): three s_memtime slots.
-__device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, const MeshParams* __restrict__ mp,
+// MP is `const MeshParams*` or the same pointer in the CONSTANT address space (kConstMesh below).  The mesh table is
+// written at upload and never while a conversion runs; saying so lets the compiler use scalar loads (s_load) for the
+// descriptor fields when the pointer is wave-uniform, even after the kernel's own record stores (which otherwise make
+// every later global read a vector load: alias analysis cannot tell the records from the table).
+typedef const __attribute__((address_space(4))) MeshParams* ConstMeshPtr;
+__device__ __forceinline__ ConstMeshPtr kConstMesh(const MeshParams* p) { return (ConstMeshPtr)p; }
+
+template <class MP>
+__device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, MP mp,
                                                const TriShade& ts, float4 rec[6], unsigned long long* stamps = nullptr) {
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
@@ -570,9 +581,9 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     }
 #define M2S_LERP(f0, f1, f2) fma_(l2, (f2) - (f0), fma_(l1, (f1) - (f0), (f0)))
 
-    const TexDesc* __restrict__ ta = &mp->tex[0];
-    const TexDesc* __restrict__ tn = &mp->tex[1];
-    const TexDesc* __restrict__ tm = &mp->tex[2];
+    const auto ta = &mp->tex[0];
+    const auto tn = &mp->tex[1];
+    const auto tm = &mp->tex[2];
     const uint32_t* xa = ta->texels;   // (non-const only for the debug ablation switch below)
     const uint32_t* xn = tn->texels;
     const uint32_t* xm = tm->texels;

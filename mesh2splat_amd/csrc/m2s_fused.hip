@@ -372,16 +372,20 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                 // the TriShade fields are read from LDS where they are used rather than copied (80 B = 20 VGPRs) up front:
                 // 166 -> 160 VGPRs, no scratch, k_fused 0.1845 -> 0.1816 ms
                 const TriShade& ts = *reinterpret_cast<const TriShade*>(&L.tri[slot * 5]);
-                // wave inside one mesh (the common case): descriptors are wave-uniform -> SGPRs, scalar loads.
-                // wave straddling a mesh boundary: per-lane descriptor pointer.
-                const MeshParams* mp = uniform_mesh ? sc.meshes + m0 : sc.meshes + mymesh;
+                // Two copies of the shading code on purpose.  Wave inside one mesh (the common case): the descriptor
+                // pointer is an SGPR pair in the constant address space, so sizes / level offsets / texel base come
+                // from scalar loads and the texel fetches use the saddr + 32-bit offset form.  Wave straddling a mesh
+                // boundary: per-lane pointer.  (A single call with a selected pointer made EVERY descriptor read a
+                // per-lane vector load: 38 instead of 19 vector loads per strip.)
 #ifdef M2S_TIMING
                 unsigned long long st3[3] = { 0, 0, 0 };
-                shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), mp, ts, rec, st3);
+                if (uniform_mesh) shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m0), ts, rec, st3);
+                else shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + mymesh, ts, rec, st3);
                 if (win == 0 && e0 == 0 && lane == 0 && wid < kTimingWaves)
                     for (int k = 0; k < 3; ++k) g_timing[(12 + k) * kTimingWaves + wid] = st3[k];
 #else
-                shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), mp, ts, rec);
+                if (uniform_mesh) shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m0), ts, rec);
+                else shade_from_tri(sc.tri, t0 + slot, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + mymesh, ts, rec);
 #endif
             }
             if (win == 0 && e0 == 0) M2S_STAMP(6);  // first strip shaded
