@@ -205,6 +205,7 @@ m2s_status m2s_set_max_gaussians(m2s_ctx* c, int64_t cap) {
 m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshes) {
     if (!c) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    if (n_meshes > 0xFFFFFFu) return fail(c, M2S_ERR_INVALID, "more than 2^24-1 meshes");   // TriShade keeps the index in 24 bits
     if (n_meshes && !meshes) return fail(c, M2S_ERR_INVALID, "meshes is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     // ---- validate + global triangle index space -------------------------------------------------

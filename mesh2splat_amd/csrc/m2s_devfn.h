@@ -299,8 +299,10 @@ struct TriShade {
     float inva, sx, sy, lod0;  // 1/area2 (IEEE), Scale.xy (GS:423-430), LOD lambda of map 0
     float4 rot;              // Quaternion (w,x,y,z)
     float lod1, lod2;        // LOD lambda of maps 1, 2 (constant per triangle: UV is affine in the window)
+                             // -- meshes with a combo texture: lod0 = level blend weight, lod1/lod2 = bits of the two
+                             //    level offsets, mesh[31:24] = l0 | l1 << 4 (see tri_shade_setup)
     uint32_t org;            // y0 << 12 | x0
-    uint32_t mesh;           // mesh index (read by waves that straddle a mesh boundary)
+    uint32_t mesh;           // [23:0] mesh index (read by waves that straddle a mesh boundary)
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be five float4");
 
@@ -345,6 +347,28 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
         if (hasM) ts.lod2 = (hasA && tm->w == ta->w && tm->h == ta->h) ? ts.lod0
                           : (hasN && tm->w == tn->w && tm->h == tn->h) ? ts.lod1
                           : lod_from_grad((float)tm->w, (float)tm->h, dudx, dvdx, dudy, dvdy);
+        if (mp->combo.texels != nullptr) {
+            // Interleaved maps (one size, one LOD): everything the sampler derives from the level of detail is a
+            // per-TRIANGLE constant, so it is derived here once instead of once per fragment: the two mip levels, the
+            // blend weight and the dword offsets of the levels inside the combo chain.  TriShade then carries
+            //   lod0 = blend weight f (0: single level), lod1 / lod2 = bit patterns of the level offsets,
+            //   mesh[31:24] = l0 | l1 << 4.
+            const uint32_t nl = ta->n_levels;
+            const float q = (float)(nl - 1), lambda = ts.lod0;
+            float d = 0.0f, f = 0.0f;
+            if (lambda > 0.0f) {   // false for NaN: magnification
+                if (lambda >= q) d = q;
+                else { d = floorf(lambda); f = lambda - d; }
+            }
+            const uint32_t l0 = (uint32_t)d, l1 = min(l0 + 1u, nl - 1u);
+            const uint32_t c1 = mp->combo.coff[1], c2 = mp->combo.coff[2], c3 = mp->combo.coff[3], c4 = mp->combo.coff[4];
+            const uint32_t off0 = l0 == 0 ? 0u : l0 == 1 ? c1 : l0 == 2 ? c2 : l0 == 3 ? c3 : c4;
+            const uint32_t off1 = l1 == 0 ? 0u : l1 == 1 ? c1 : l1 == 2 ? c2 : l1 == 3 ? c3 : c4;
+            ts.lod0 = f;
+            ts.lod1 = __uint_as_float(off0);
+            ts.lod2 = __uint_as_float(off1);
+            ts.mesh = (l0 | (l1 << 4)) << 24;
+        }
     }
 }
 
@@ -483,18 +507,12 @@ __device__ __forceinline__ float frac_repeat(float u) {
 }
 
 template <class MP, class TD>
-__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, float lambda, float out[9]) {
-    const uint32_t nl = t->n_levels, w = t->w, h = t->h;
-    const float q = (float)(nl - 1);
-    float d = 0.0f, f = 0.0f;
-    if (lambda > 0.0f) {   // false for NaN: magnification
-        if (lambda >= q) d = q;
-        else { d = floorf(lambda); f = lambda - d; }
-    }
-    const uint32_t l0 = (uint32_t)d, l1 = min(l0 + 1u, nl - 1u);
-    const uint32_t c1 = mp->combo.coff[1], c2 = mp->combo.coff[2], c3 = mp->combo.coff[3], c4 = mp->combo.coff[4];
-    const uint32_t off0 = l0 == 0 ? 0u : l0 == 1 ? c1 : l0 == 2 ? c2 : l0 == 3 ? c3 : c4;
-    const uint32_t off1 = l1 == 0 ? 0u : l1 == 1 ? c1 : l1 == 2 ? c2 : l1 == 3 ? c3 : c4;
+__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, const TriShade& ts, float out[9]) {
+    // level selection was done per triangle (tri_shade_setup)
+    const uint32_t w = t->w, h = t->h;
+    const float f = ts.lod0;
+    const uint32_t off0 = __float_as_uint(ts.lod1), off1 = __float_as_uint(ts.lod2);
+    const uint32_t l0 = (ts.mesh >> 24) & 15u, l1 = ts.mesh >> 28;
     const uint32_t* __restrict__ base = mp->combo.texels;
     ComboTap tlo, thi;
     combo_tap(off0, max(1u, w >> l0), max(1u, h >> l0), uf, vf, tlo);
@@ -599,7 +617,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     if (cmb != nullptr) {
         // all three maps, same size: one LOD state, interleaved texels, 2 x 24-byte row reads per level
         float acc[9];
-        combo_sample(mp, ta, uf, vf, ts.lod0, acc);
+        combo_sample(mp, ta, uf, vf, ts, acc);
         col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2]; col[3] = acc[3];
         nrm[0] = acc[4]; nrm[1] = acc[5]; nrm[2] = acc[6];
         rough = acc[7]; metal = acc[8];

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     if (cntc) {
         TriShade ts;
         tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
-        ts.mesh = m;
+        ts.mesh |= m;   // low 24 bits; the top byte carries the combo sampler's mip levels
         const float4* src = reinterpret_cast<const float4*>(&ts);
 #pragma unroll
         for (int k = 0; k < 5; ++k) L.tri[lane * 5 + k] = src[k];
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                     ++ci;
                 }
             } else if (kd == kMedium && cto < wend && cto + cn > win) {
-                expand_medium(sc.tri.A0, sc.tri.A1, sc.tri.A2, sc.meshes + reinterpret_cast<const uint32_t*>(&L.tri[lane * 5 + 4])[3], t0 + lane, R, (uint32_t)lane, cto, win, wend, L.entries);
+                expand_medium(sc.tri.A0, sc.tri.A1, sc.tri.A2, sc.meshes + (reinterpret_cast<const uint32_t*>(&L.tri[lane * 5 + 4])[3] & 0xFFFFFFu), t0 + lane, R, (uint32_t)lane, cto, win, wend, L.entries);
             }
         }
         wave_lds_sync();  // entries + tri visible to the whole wave
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
             if (have) {
                 en = L.entries[e];
                 slot = en >> 24;
-                if (!uniform_mesh) mymesh = reinterpret_cast<const uint32_t*>(&L.tri[slot * 5 + 4])[3];
+                if (!uniform_mesh) mymesh = reinterpret_cast<const uint32_t*>(&L.tri[slot * 5 + 4])[3] & 0xFFFFFFu;
                 if (anybig) skipped = L.tskip[slot];
             }
             if (have) {
