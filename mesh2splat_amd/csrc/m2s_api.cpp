@@ -58,7 +58,7 @@ struct m2s_ctx {
     // asynchronous submissions (m2s_convert_submit / m2s_convert_wait): a ring of result slots.  Slot k uses
     // h_total[2 + 2k] (counter) and h_total[3 + 2k] (status words), written by the kernel itself.
     struct Slot { hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr; uint64_t limit = 0; void* d_out = nullptr; uint32_t R = 0;
-                  bool sync_result = false; uint64_t sync_total = 0; bool prof = false; };
+                  bool sync_result = false; uint64_t sync_total = 0; bool prof = false; float ms[M2S_K_N] = {}; };
     Slot slot[M2S_MAX_IN_FLIGHT];
     uint32_t slot_head = 0, slot_count = 0; // oldest in-flight slot, number in flight
     uint32_t async_ok_R = 0;                // R at which a completed conversion of this scene needed no host decision
@@ -560,6 +560,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         if (s != M2S_OK) return s;
         sl.sync_result = true;
         sl.sync_total = total;
+        memcpy(sl.ms, c->last_ms, sizeof sl.ms);   // a later submit overwrites last_ms before this slot is waited for
         sl.limit = c->last_stored;   // already clamped
         sl.d_out = const_cast<void*>(c->last_records);
         ++c->slot_count;
@@ -597,6 +598,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     if (sl.sync_result) {   // run_pass already filled last_*
         if (out_total) *out_total = sl.sync_total;
         c->last_total = sl.sync_total; c->last_stored = sl.limit; c->last_records = sl.d_out; c->last_R = sl.R;
+        memcpy(c->last_ms, sl.ms, sizeof sl.ms);
         return M2S_OK;
     }
     HIPCHK(c, hipEventSynchronize(sl.done));

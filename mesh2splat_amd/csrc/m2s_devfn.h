@@ -313,7 +313,8 @@ __device__ __forceinline__ float lod_from_grad(float fw, float fh, float dudx, f
 }
 
 // p: positions; b0/b1: uv planes of the triangle.  Needs a valid Raster.
-__device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, const MeshParams* __restrict__ mp,
+template <class MP>   // const MeshParams* in the generic or the constant address space (kConstMesh)
+__device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, MP mp,
                                                 float4 b0, float2 b1, TriShade& ts) {
     // The barycentrics feed the texture coordinates, where any rounding difference is amplified by the
     // texture size and contrast: they follow the oracle's exact operation sequence
@@ -332,9 +333,9 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
     const float A2 = (float)rs.a[2] * 256.0f * ts.inva, B2 = (float)rs.b[2] * 256.0f * ts.inva;
     geo_flat(p, g, ts.sx, ts.sy, ts.rot);
     ts.lod0 = ts.lod1 = ts.lod2 = 0.0f;
-    const TexDesc* __restrict__ ta = &mp->tex[0];
-    const TexDesc* __restrict__ tn = &mp->tex[1];
-    const TexDesc* __restrict__ tm = &mp->tex[2];
+    const auto ta = &mp->tex[0];
+    const auto tn = &mp->tex[1];
+    const auto tm = &mp->tex[2];
     const bool hasA = ta->texels != nullptr, hasN = tn->texels != nullptr, hasM = tm->texels != nullptr;
     if (hasA || hasN || hasM) {
         // UV is affine in window space (all w = 1, GS:439): d(lambda_i)/dx = A_i, d/dy = B_i per pixel
@@ -676,20 +677,26 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
 }
 
 // Everything the GS + rasteriser + FS produce for ONE fragment (multi-pass emit: per-triangle part recomputed).
-__device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, int x, int y, uint32_t mesh_hint,
-                                               bool uniform_mesh, uint32_t R, float4 rec[6]) {
+template <class MP>
+__device__ __forceinline__ void shade_fragment_mp(const SceneDev& sc, uint32_t t, int x, int y, MP mp, uint32_t R, float4 rec[6]) {
     const TriPlanes& tp = sc.tri;
     float p[9];
     load_positions(tp, t, p);
-    const uint32_t m = uniform_mesh ? mesh_hint : find_mesh(sc, sc.tri_first + t);
-    const MeshParams* __restrict__ mp = sc.meshes + m;
+    const float bmin[3] = { mp->bmin[0], mp->bmin[1], mp->bmin[2] }, bmax[3] = { mp->bmax[0], mp->bmax[1], mp->bmax[2] };
     Geo g;
-    geo_setup(p, mp->bmin, mp->bmax, g);
+    geo_setup(p, bmin, bmax, g);
     Raster rs;
     raster_setup(g, R, rs);
     TriShade ts;
     tri_shade_setup(p, g, rs, mp, tp.B0[t], tp.B1[t], ts);
     shade_from_tri(tp, t, x, y, mp, ts, rec);
+}
+// Two instantiations on purpose (see k_fused): a wave-uniform mesh gets the constant-address-space pointer and with it
+// scalar descriptor loads; otherwise the mesh is looked up per lane.
+__device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, int x, int y, uint32_t mesh_hint,
+                                               bool uniform_mesh, uint32_t R, float4 rec[6]) {
+    if (uniform_mesh) shade_fragment_mp(sc, t, x, y, kConstMesh(sc.meshes + mesh_hint), R, rec);
+    else shade_fragment_mp(sc, t, x, y, sc.meshes + find_mesh(sc, sc.tri_first + t), R, rec);
 }
 
 }  // namespace m2s

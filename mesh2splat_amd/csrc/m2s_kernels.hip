@@ -242,7 +242,7 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
 // ============================================================================================
 // K2: emit.  Workgroup b owns output records [b*kEmitF, (b+1)*kEmitF).
 // ============================================================================================
-__global__ void __launch_bounds__(kBlock) k_emit(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                  const uint32_t* __restrict__ start,
                                                  const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                  float4* __restrict__ out) {
