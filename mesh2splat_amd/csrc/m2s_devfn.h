@@ -236,6 +236,80 @@ __device__ __forceinline__ void row_span(const Raster& s, int y, int& xa, int& x
     else { xa = (int)lo; xb = (int)hi; }
 }
 
+// Division-free row stepping for loops that visit a triangle's rows IN ORDER (row_span is the closed form for an
+// arbitrary row: ~250 instructions, two fp64 divisions per edge; the wave-cooperative paths, which evaluate one row
+// per lane, keep using it).  Per edge the bound of row y is floor(n(y) / D) with D = 256 |a| and a numerator that
+// advances by a constant per row, so quotient and remainder are stepped Bresenham-style:
+//     r += sr;  q += sq;  if (r >= D) { r -= D; ++q; }
+// Exact: identical spans to row_span for every row (tests/test_gpu_parity.py::test_row_walker_*, and every count test).
+struct RowWalker {
+    long long q[3];      // floor(n/D) of the current row
+    uint32_t r[3];       // n - q*D, in [0, D)
+    int sq[3];           // floor(step / D):  |step| = 256 |b| < 2^31 and D >= 256  ->  |sq| < 2^23
+    uint32_t sr[3];      // step - sq*D, in [0, D)
+    uint32_t D[3];       // 256 |a|; 0 marks a horizontal edge
+    long long beta[3];   // horizontal edges only: beta(y), stepped by 256 b
+    int bstep[3];
+    int lower;           // bit i: edge i bounds x from below (a > 0)
+    int x0, x1;
+};
+__device__ __forceinline__ void row_walker_init(const Raster& s, int y, RowWalker& w) {
+    const long long Py = 256ll * y + 128;
+    w.lower = 0;
+    w.x0 = s.x0; w.x1 = s.x1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const long long alpha = 256ll * s.a[i];
+        const long long beta = 128ll * s.a[i] + (long long)s.b[i] * Py + s.c[i] + ((s.bias >> i) & 1);
+        const int bs = 256 * s.b[i];
+        w.beta[i] = beta;
+        w.bstep[i] = bs;
+        if (alpha > 0) {          // x >= floor((alpha - beta) / alpha)
+            w.lower |= 1 << i;
+            w.D[i] = (uint32_t)alpha;
+            const long long n = alpha - beta;
+            w.q[i] = floordiv_pos(n, alpha);
+            w.r[i] = (uint32_t)(n - w.q[i] * alpha);
+            const long long st = -(long long)bs;
+            const long long fq = floordiv_pos(st, alpha);
+            w.sq[i] = (int)fq;
+            w.sr[i] = (uint32_t)(st - fq * alpha);
+        } else if (alpha < 0) {   // x <= floor((beta - 1) / -alpha)
+            const long long d = -alpha;
+            w.D[i] = (uint32_t)d;
+            const long long n = beta - 1;
+            w.q[i] = floordiv_pos(n, d);
+            w.r[i] = (uint32_t)(n - w.q[i] * d);
+            const long long st = (long long)bs;
+            const long long fq = floordiv_pos(st, d);
+            w.sq[i] = (int)fq;
+            w.sr[i] = (uint32_t)(st - fq * d);
+        } else {
+            w.D[i] = 0; w.q[i] = 0; w.r[i] = 0; w.sq[i] = 0; w.sr[i] = 0;
+        }
+    }
+}
+// span of the current row, then advance to the next one
+__device__ __forceinline__ void row_walker_next(RowWalker& w, int& xa, int& xb) {
+    long long lo = w.x0, hi = w.x1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (w.D[i]) {
+            if ((w.lower >> i) & 1) lo = w.q[i] > lo ? w.q[i] : lo;
+            else hi = w.q[i] < hi ? w.q[i] : hi;
+            uint32_t r = w.r[i] + w.sr[i];     // < 2^32: both < D < 2^31
+            long long q = w.q[i] + w.sq[i];
+            if (r >= w.D[i]) { r -= w.D[i]; q += 1; }
+            w.r[i] = r; w.q[i] = q;
+        } else {
+            if (w.beta[i] < 1) hi = lo - 1;
+            w.beta[i] += w.bstep[i];
+        }
+    }
+    if (hi < lo) { xa = 0; xb = -1; }
+    else { xa = (int)lo; xb = (int)hi; }
+}
+
 __device__ __forceinline__ Raster shfl_raster(const Raster& s, int src) {
     Raster r;
 #pragma unroll

@@ -11,7 +11,7 @@ constexpr int kBlock = 256;              // 4 wave64 per workgroup
 constexpr int kTriPerBlock = 1024;       // triangles per workgroup in the count / offsets kernels
 constexpr int kEmitF = 1024;             // output records per workgroup in the emit kernel
 constexpr int kRowsThread = 32;          // k_emit: triangles with more pixel rows are expanded wave-cooperatively
-constexpr int kRowsCount = 8;            // k_count: triangles with more pixel rows are counted wave-cooperatively
+constexpr int kRowsCount = 128;          // k_count: triangles with more pixel rows are counted wave-cooperatively
 constexpr int kStageStride = 7;          // float4 per staged record in LDS (6 + 1 pad: conflict-free b128)
 
 // ---- HBM layout of the geometry: 144 B / triangle in 11 coalescable planes ------------------

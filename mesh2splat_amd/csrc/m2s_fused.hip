@@ -81,9 +81,11 @@ __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, c
     Raster r2;
     if (!raster_setup(g, R, r2)) return;
     uint32_t ci = cto;
+    RowWalker rw;
+    row_walker_init(r2, r2.y0, rw);
     for (int y = r2.y0; y <= r2.y1 && ci < wend; ++y) {
         int xa, xb;
-        row_span(r2, y, xa, xb);
+        row_walker_next(rw, xa, xb);
         for (int x = xa; x <= xb; ++x, ++ci)
             if (ci >= win && ci < wend) entries[ci - win] = (lane << 24) | ((uint32_t)y << 12) | (uint32_t)x;
     }
@@ -247,18 +249,29 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
             cnt = (uint32_t)__popcll(mask);
         } else if (rows <= kFusedRows) {
             kind = kMedium;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
             for (int y = rs.y0; y <= rs.y1; ++y) {
                 int xa, xb;
-                row_span(rs, y, xa, xb);
+                row_walker_next(rw, xa, xb);
                 cnt += (uint32_t)max(xb - xa + 1, 0);
             }
             if (cnt > kBigCount) kind = kBig;
         } else {
-            kind = kBig;
+            kind = kBig;   // emitted by the second stage; still counted here (its slice of the ordered output)
+            if (rows <= kRowsCount) {
+                RowWalker rw;
+                row_walker_init(rs, rs.y0, rw);
+                for (int y = rs.y0; y <= rs.y1; ++y) {
+                    int xa, xb;
+                    row_walker_next(rw, xa, xb);
+                    cnt += (uint32_t)max(xb - xa + 1, 0);
+                }
+            }
         }
     }
-    {   // big triangles spanning many rows: counted by the whole wave, one row per lane
-        unsigned long long bigm = __ballot(kind == kBig && rows > kFusedRows);
+    {   // big triangles spanning very many rows: counted by the whole wave, one row per lane
+        unsigned long long bigm = __ballot(kind == kBig && rows > kRowsCount);
         while (bigm) {
             const int src = __ffsll((long long)bigm) - 1;
             bigm &= bigm - 1;

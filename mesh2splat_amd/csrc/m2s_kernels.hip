@@ -130,9 +130,11 @@ __global__ void __launch_bounds__(kBlock) k_count(SceneDev sc, uint32_t R, uint3
         const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
         uint32_t c = 0;
         if (ok && rows <= kRowsCount) {
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
             for (int y = rs.y0; y <= rs.y1; ++y) {
                 int xa, xb;
-                row_span(rs, y, xa, xb);
+                row_walker_next(rw, xa, xb);
                 c += (uint32_t)max(xb - xa + 1, 0);
             }
         }
@@ -281,9 +283,11 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
         const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
         if (ok && rows <= kRowsThread) {
             uint32_t k = o0;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
             for (int y = rs.y0; y <= rs.y1 && k < end; ++y) {
                 int xa, xb;
-                row_span(rs, y, xa, xb);
+                row_walker_next(rw, xa, xb);
                 for (int x = xa; x <= xb; ++x, ++k)
                     if (k >= base && k < end) entries[k - base] = make_uint2(t, ((uint32_t)y << 16) | (uint32_t)x);
             }
