@@ -64,10 +64,6 @@ __device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long lon
 
 enum : int { kNone = 0, kSmall = 1, kMedium = 2, kBig = 3 };
 
-__device__ __forceinline__ void nt_store(float4* p, float4 v) {
-    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
-    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // merged into one dwordx4 nt
-}
 
 // Rare path, deliberately NOT inlined: its closed-form span code (fp64 divisions) would otherwise add ~30
 // VGPRs of pressure to the fragment loop of every wave.  Re-derives the raster setup from global memory.

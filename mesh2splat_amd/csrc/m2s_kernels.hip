@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
         float4* __restrict__ dst = out + ((size_t)base + e0) * 6;
         for (uint32_t q = threadIdx.x; q < nrec * 6; q += kBlock) {
             const uint32_t r = q / 6, k = q - r * 6;
-            dst[q] = stage[r * kStageStride + k];
+            nt_store(&dst[q], stage[r * kStageStride + k]);
         }
         __syncthreads();
     }
@@ -428,12 +428,23 @@ __global__ void __launch_bounds__(kBlock) k_emit_big(SceneDev sc, uint32_t R, co
     __syncthreads();
     const uint32_t n_here = f1 - f0;
     const unsigned long long base = item.off + f0;
+    // every fragment of this workgroup belongs to ONE triangle: its fragment constants are computed once, not per strip
+    const ConstMeshPtr mp = kConstMesh(sc.meshes + m);
+    TriShade ts;
+    {
+        float p[9];
+        load_positions(sc.tri, item.t, p);
+        const float bmin[3] = { mp->bmin[0], mp->bmin[1], mp->bmin[2] }, bmax[3] = { mp->bmax[0], mp->bmax[1], mp->bmax[2] };
+        Geo g;
+        geo_setup(p, bmin, bmax, g);
+        tri_shade_setup(p, g, rs, mp, sc.tri.B0[item.t], sc.tri.B1[item.t], ts);
+    }
     for (uint32_t e0 = 0; e0 < n_here; e0 += kBlock) {
         const uint32_t e = e0 + threadIdx.x;
         if (e < n_here) {
             const uint2 en = entries[e];
             float4 rec[6];
-            shade_fragment(sc, en.x, (int)(en.y & 0xFFFFu), (int)(en.y >> 16), m, true, R, rec);
+            shade_from_tri(sc.tri, item.t, (int)(en.y & 0xFFFFu), (int)(en.y >> 16), mp, ts, rec);
 #pragma unroll
             for (int k = 0; k < 6; k++) stage[threadIdx.x * kStageStride + k] = rec[k];
         }
@@ -445,7 +456,7 @@ __global__ void __launch_bounds__(kBlock) k_emit_big(SceneDev sc, uint32_t R, co
         float4* __restrict__ dst = out + o0 * 6;
         for (uint32_t q = threadIdx.x; q < nrec * 6; q += kBlock) {
             const uint32_t r = q / 6, k = q - r * 6;
-            dst[q] = stage[r * kStageStride + k];
+            nt_store(&dst[q], stage[r * kStageStride + k]);
         }
         __syncthreads();
     }
