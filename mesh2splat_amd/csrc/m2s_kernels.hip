@@ -241,17 +241,41 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
                        n_start);
 }
 
+// GS + raster setup + the fragment stage's per-triangle constants of triangle t (mesh looked up per lane)
+__device__ __forceinline__ bool setup_full_for(const SceneDev& sc, uint32_t t, uint32_t R, Raster& rs, TriShade& ts) {
+    float p[9];
+    load_positions(sc.tri, t, p);
+    const uint32_t m = find_mesh(sc, sc.tri_first + t);
+    const MeshParams* mp = sc.meshes + m;
+    Geo g;
+    geo_setup(p, mp->bmin, mp->bmax, g);
+    if (!raster_setup(g, R, rs)) return false;
+    tri_shade_setup(p, g, rs, mp, sc.tri.B0[t], sc.tri.B1[t], ts);
+    ts.mesh |= m;
+    return true;
+}
+
 // ============================================================================================
 // K2: emit.  Workgroup b owns output records [b*kEmitF, (b+1)*kEmitF).
+//
+// The triangles that overlap a workgroup's slice are set up ONCE, in the expansion phase (one thread per
+// triangle), and their fragment constants (TriShade) kept in an LDS table of kEmitTab entries; the fragment
+// phase then runs only the per-fragment code.  With mid-size triangles (tens of fragments each: a coarse mesh
+// at high density) that removes the per-fragment repetition of the whole GS + raster setup, which was more than
+// half of this kernel's instructions.  A slice overlapped by more than kEmitTab triangles (tiny triangles) falls
+// back to per-fragment setup for the whole workgroup — those scenes run the fused kernel anyway.
 // ============================================================================================
+constexpr uint32_t kEmitTab = 128;
 __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                  const uint32_t* __restrict__ start,
                                                  const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                  float4* __restrict__ out) {
-    __shared__ uint2 entries[kEmitF];                 // (local triangle, y<<16 | x)
+    __shared__ uint2 entries[kEmitF];                 // (triangle, table slot << 24 | y << 12 | x)
     __shared__ float4 stage[kBlock * kStageStride];   // 28 KiB
     __shared__ uint32_t wrow_off[kBlock / 64][64];
     __shared__ int wrow_xa[kBlock / 64][64];
+    __shared__ float4 tstab[kEmitTab * 5];            // TriShade of the triangles overlapping this slice (10 KiB)
+    __shared__ uint32_t wact[kBlock / 64];            // active triangles per wave in the current batch
 
     const unsigned long long total = *total_p;
     const unsigned long long nw = total < limit ? total : limit;  // records actually stored
@@ -272,14 +296,30 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
     const uint32_t t_first = start[lblock];
     const uint32_t m0 = find_mesh(sc, sc.tri_first + t_first);
     uint32_t t_last_seen = t_first;
+    uint32_t n_tab = 0;   // triangles set up so far (workgroup-uniform); > kEmitTab = table overflow
     for (uint32_t tc = t_first;; tc += kBlock) {
         const uint32_t t = tc + threadIdx.x;
         uint32_t o0 = 0, o1 = 0;
         if (t < T) { o0 = off[t]; o1 = off[t + 1]; }
         const bool active = (o1 > o0) && (o0 < end) && (o1 > base);
         Raster rs;
+        TriShade ts;
         bool ok = false;
-        if (active) ok = setup_raster_for(sc, t, 0, false, R, rs);
+        if (active) ok = setup_full_for(sc, t, R, rs, ts);
+        // table slot = rank of this triangle among the slice's triangles
+        const unsigned long long okm = __ballot(ok);
+        if (lane == 0) wact[wave] = (uint32_t)__popcll(okm);
+        __syncthreads();
+        uint32_t slot = n_tab + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) slot += wact[w];
+        n_tab += wact[0] + wact[1] + wact[2] + wact[3];
+        __syncthreads();   // wact is rewritten by the next batch
+        if (ok && slot < kEmitTab) {
+            const float4* src4 = reinterpret_cast<const float4*>(&ts);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) tstab[slot * 5 + k] = src4[k];
+        }
+        const uint32_t stag = (slot & 0xFFu) << 24;
         const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
         if (ok && rows <= kRowsThread) {
             uint32_t k = o0;
@@ -289,7 +329,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
                 int xa, xb;
                 row_walker_next(rw, xa, xb);
                 for (int x = xa; x <= xb; ++x, ++k)
-                    if (k >= base && k < end) entries[k - base] = make_uint2(t, ((uint32_t)y << 16) | (uint32_t)x);
+                    if (k >= base && k < end) entries[k - base] = make_uint2(t, stag | ((uint32_t)y << 12) | (uint32_t)x);
             }
         }
         unsigned long long big = __ballot(ok && rows > kRowsThread);
@@ -297,7 +337,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
             const Raster b = shfl_raster(rs, src);
-            const uint32_t bt = __shfl(t, src);
+            const uint32_t bt = __shfl(t, src), btag = __shfl(stag, src);
             uint32_t acc = __shfl(o0, src);
             for (int yc = b.y0; yc <= b.y1 && acc < end; yc += 64) {
                 const int y = yc + lane;
@@ -319,7 +359,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
                         for (int step = 32; step >= 1; step >>= 1)
                             if (wrow_off[wave][r + step] <= k) r += step;
                         const int x = wrow_xa[wave][r] + (int)(k - wrow_off[wave][r]);
-                        entries[acc + k - base] = make_uint2(bt, ((uint32_t)(yc + r) << 16) | (uint32_t)x);
+                        entries[acc + k - base] = make_uint2(bt, btag | ((uint32_t)(yc + r) << 12) | (uint32_t)x);
                     }
                 }
                 acc += chunk;
@@ -335,12 +375,20 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, con
 
     // ---- phase B: one thread per Gaussian; records staged in LDS, then 16 B/lane coalesced stores ----
     const uint32_t n_here = end - base;
+    const bool use_tab = n_tab <= kEmitTab;   // workgroup-uniform
     for (uint32_t e0 = 0; e0 < n_here; e0 += kBlock) {
         const uint32_t e = e0 + threadIdx.x;
         if (e < n_here) {
             const uint2 en = entries[e];
+            const int px = (int)(en.y & 0xFFFu), py = (int)((en.y >> 12) & 0xFFFu);
             float4 rec[6];
-            shade_fragment(sc, en.x, (int)(en.y & 0xFFFFu), (int)(en.y >> 16), m0, uniform_mesh, R, rec);
+            if (use_tab) {
+                const TriShade& tsr = *reinterpret_cast<const TriShade*>(&tstab[(en.y >> 24) * 5]);
+                if (uniform_mesh) shade_from_tri(sc.tri, en.x, px, py, kConstMesh(sc.meshes + m0), tsr, rec);
+                else shade_from_tri(sc.tri, en.x, px, py, sc.meshes + (tsr.mesh & 0xFFFFFFu), tsr, rec);
+            } else {
+                shade_fragment(sc, en.x, px, py, m0, uniform_mesh, R, rec);
+            }
 #pragma unroll
             for (int k = 0; k < 6; k++) stage[threadIdx.x * kStageStride + k] = rec[k];
         }
