@@ -50,7 +50,8 @@ struct m2s_ctx {
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
     BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions
-    uint32_t multipass_R = 0;               // AUTO: R at which this scene turned out to be dominated by big triangles
+    uint32_t multipass_R = 0;               // AUTO: R at which this scene is converted by the multi-pass pipeline
+    uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
@@ -114,6 +115,7 @@ static void free_scene(m2s_ctx* c) {
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr;
     c->sized_R = 0;
     c->multipass_R = 0;
+    c->decided_R = 0;
     c->async_ok_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
@@ -462,9 +464,33 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
 
+    // ---- AUTO: which pipeline for this scene at this R? ---------------------------------------------
+    // The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
+    // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
+    // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
+    // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).  The exact count
+    // costs 0.02-0.06 ms and is taken once per (scene, R); the decision is remembered.
+    if (c->pipeline == M2S_PIPELINE_AUTO && c->decided_R != R) {
+        if (!counted) {
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+            launch_count(sc, R, c->d_cnt, c->d_partials, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+            HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (prof)
+                for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+            counted = true;
+        }
+        c->decided_R = R;
+        c->multipass_R = (c->h_total[0] >= 11ull * sc.n_tri) ? R : 0;
+    }
+
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
-    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !counted && c->multipass_R != R) {
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && c->multipass_R != R) {
+        counted = false;   // the fused kernel does its own counting; a count taken above only sized / decided
         // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
         // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
         // counter and its two status words straight into pinned host memory.
