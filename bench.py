@@ -237,8 +237,11 @@ def main():
     # for the record: the same loop with one blocking call per step (outside the timed region)
     sync()
     s0 = time.perf_counter()
+    per_step = []
     for _ in range(min(a.steps, 20)):
+        p0 = time.perf_counter()
         step_sync()
+        per_step.append((time.perf_counter() - p0) * 1e3)
     if pending:
         with torch.cuda.stream(side):
             for w in pending:
@@ -246,6 +249,23 @@ def main():
         pending.clear()
     sync()
     sync_ms = (time.perf_counter() - s0) / min(a.steps, 20) * 1e3
+    per_step.sort()
+    sync_stats = {"median": per_step[len(per_step) // 2], "p10": per_step[len(per_step) // 10], "p90": per_step[(len(per_step) * 9) // 10]}
+    # a second denominator for the roofline: what a plain device-to-device copy reaches on this box (read + write bytes)
+    copy_gbs = None
+    if rank == 0:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dstb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            dstb.copy_(src)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(10):
+            dstb.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * nbytes * 10 / (time.perf_counter() - c0) / 1e9
+        del src, dstb
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
@@ -300,12 +320,13 @@ def main():
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
                        "submission": "one blocking call per step" if a.sync_steps else
                                      "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
-            "sync_ms_per_step": sync_ms,
+            "sync_ms_per_step": sync_ms, "sync_ms_stats": sync_stats,
             "kernel_ms": {k: v / max(n_prof[0], 1) for k, v in kms.items()},
             "kernel_timing": f"HIP events on the launch stream around every {PROF_EVERY}th launch of the timed region ({n_prof[0]} launches)",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_" + dom,
-                         "algorithmic_bytes": b_alg,
+                         "algorithmic_bytes": b_alg, "measured_copy_peak": copy_gbs,
+                         "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "write_only_frac": (96.0 * total / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
         }
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
