@@ -52,6 +52,7 @@ struct m2s_ctx {
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions
     uint32_t multipass_R = 0;               // AUTO: R at which this scene is converted by the multi-pass pipeline
     uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
+    uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
@@ -116,6 +117,7 @@ static void free_scene(m2s_ctx* c) {
     c->sized_R = 0;
     c->multipass_R = 0;
     c->decided_R = 0;
+    c->mp_ready_R = 0;
     c->async_ok_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
@@ -540,6 +542,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     if (!done) {
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
         if (s != M2S_OK) return s;
+        c->mp_ready_R = R;
     }
     const uint64_t total = c->h_total[0];
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
@@ -578,7 +581,39 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     // host decision between kernels) and the output buffer needs no (re)allocation.
     const bool own_ready = d_records || (cap ? (c->d_records && c->records_cap == cap) : (c->d_records && c->sized_R == R));
     const bool fast = c->scene.n_tri > 0 && c->async_ok_R == R && c->pipeline != M2S_PIPELINE_MULTIPASS && c->multipass_R != R && own_ready;
+    // Multi-pass conversions have no host decision between their four kernels either; once this (scene, R) has been
+    // converted that way (work buffers sized, AUTO decision taken) they are enqueued without waiting as well.
+    // (With kernel timing on they run synchronously: the per-kernel events are shared.)
+    const bool fast_mp = !fast && c->scene.n_tri > 0 && own_ready && !c->profiling && c->mp_ready_R == R &&
+                         (c->pipeline == M2S_PIPELINE_MULTIPASS || (c->decided_R == R && c->multipass_R == R));
     sl.R = R;
+    if (fast_mp) {
+        HIPCHK(c, hipSetDevice(c->device));
+        uint64_t limit;
+        void* d_out;
+        if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
+        else { limit = cap ? cap : c->records_cap; d_out = c->d_records; }
+        if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
+        const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
+        if (c->start_cap >= n_blocks) {
+            unsigned long long* res = &c->h_total[2 + 2 * k];
+            res[0] = 0; res[1] = 0;
+            const SceneDev& sc = c->scene;
+            launch_count(sc, R, c->d_cnt, c->d_partials, st);
+            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+            launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
+            launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, (float4*)d_out, n_blocks, st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(&res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(sl.done, st));
+            sl.prof = false;
+            sl.sync_result = false;
+            sl.limit = limit;
+            sl.d_out = d_out;
+            ++c->slot_count;
+            return M2S_OK;
+        }
+    }
     if (!fast) {
         // first conversion of a (scene, R), or one that needs the second stage / the multi-pass pipeline: run it now
         uint64_t total = 0;

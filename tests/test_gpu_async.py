@@ -61,6 +61,24 @@ def test_submit_falls_back_for_deferred_triangles_and_multipass(hiplib, oracle):
     c.submit(128)
     assert c.wait() == ototal
     assert_records_match(c.download(), orec, "multipass via submit")
+    first = c.download()
+    for _ in range(3):               # from the second conversion on the four kernels are enqueued without waiting
+        c.submit(128); c.submit(128); c.submit(128)
+        assert c.wait() == ototal and c.wait() == ototal and c.wait() == ototal
+    assert np.array_equal(c.download().view(np.uint32), first.view(np.uint32))
+    c.close()
+    # AUTO deciding for the multi-pass pipeline (mid-size triangles) pipelines the same way
+    scene = synth.cube_sphere(20, tex_size=32)
+    R = 512
+    c = Converter(0)
+    c.upload_scene(scene)
+    ototal, orec, _ = oracle.convert(scene, R, cap=a_cap(scene, R))
+    assert ototal > 11 * scene.n_triangles
+    for _ in range(3):
+        c.submit(R); c.submit(R)
+        assert c.wait() == ototal and c.wait() == ototal
+    assert_records_match(c.download(), orec, "AUTO -> multipass via submit")
+    assert c.last_kernel_ms()["fused"] == 0.0
     c.close()
 
 
