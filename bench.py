@@ -118,6 +118,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        # librccl announces itself through C stdio ("Librccl path : ..."); push that out now so that the JSON line
+        # stays the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
 
     n, tex, R = WORKLOADS[a.workload]
     if n == "grid":
