@@ -69,7 +69,7 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(scene_one_mesh, R, budget_s):
+def cpu_baseline(scene_one_mesh, R, budget_s, gpu_total=None):
     """Oracle (CPU port of the reference path) on the host cores: same workload, same timed region as the
     GPU (geometry + textures + mip chains resident, output buffer allocated -> records + count)."""
     from oracle import oracle
@@ -89,11 +89,46 @@ def cpu_baseline(scene_one_mesh, R, budget_s):
         res[name] = (best, reps)
     prep.close()
     best, reps = res["all_cores"]
-    return {"value": total / best, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+    port = {"value": total / best, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"full workload ({total} Gaussians), oracle with OpenMP over triangles (count pass + emit pass), "
                       f"mip chains and output buffer prepared outside the timed region, best of {reps}",
             "ms_per_mesh": best * 1e3,
             "single_thread": {"value": total / res["one_core"][0], "ms_per_mesh": res["one_core"][0] * 1e3}}
+    port["counter_equals_gpu"] = None if gpu_total is None else bool(total == gpu_total)
+    ref = reference_baseline(scene_one_mesh, R, total if gpu_total is None else gpu_total)
+    if ref is None:
+        return port
+    ref["port"] = port          # the multi-core figure of our own CPU restatement, for scale
+    return ref
+
+
+def reference_baseline(scene_one_mesh, R, expect_total):
+    """The reference ITSELF on the host: oracle/_ref/ref_pipeline_check = the reference's SceneManager::loadModel,
+    ConversionPass::execute and converter{VS,GS,FS}.glsl (C++ through glm), compiled from /root/reference by
+    oracle/Makefile, on a minimal software GL (the GL driver is the one thing that cannot run here).  Timed: execute()
+    on the whole workload, one thread (the reference's host code is single-threaded).  None if the binary is absent."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_pipeline_check")
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        return None
+    from mesh2splat_amd import gltf_io
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            glb = os.path.join(d, "workload.glb")
+            gltf_io.write_glb(scene_one_mesh, glb, indexed=False)
+            r = subprocess.run([exe, glb, str(int(R)), "-"], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return None
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+    sec = info["execute_ms"] * 1e-3
+    return {"value": info["counter"] / sec, "unit": "Gaussians/s", "cores": 1, "kind": "reference",
+            "sample": f"full workload ({info['counter']} Gaussians): the reference's ConversionPass::execute + its three shaders "
+                      "(as C++ through glm) on oracle/ref_pipeline_check's software GL, single thread, one run",
+            "ms_per_mesh": info["execute_ms"], "counter": info["counter"],
+            "counter_equals_gpu": bool(info["counter"] == expect_total)}
 
 
 def main():
@@ -348,7 +383,7 @@ def main():
             res["gather"] = gather
         if not a.no_cpu_baseline and world == 1:
             one = scene if n == "grid" else synth.colocated_spheres(1, n, tex)
-            res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds, gpu_total=total)
         print(json.dumps(res), flush=True)
 
     if multi:

@@ -332,20 +332,24 @@ int main(int argc, char** argv) {
         SceneManager sm(rc);
         if (!sm.loadModel(argv[1], "")) return 2;
         ConversionPass pass;
+        const auto t_exec0 = std::chrono::steady_clock::now();
         pass.execute(rc);
+        const double exec_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_exec0).count();
 
         const uint32_t counter = rc.numberOfGaussians;
         const uint32_t cap = (uint32_t)swgl::uniform_i["u_maxGaussians"];
         const std::vector<uint8_t>& ssbo = swgl::buffers[rc.gaussianBuffer];
         const uint64_t ssbo_bytes = ssbo.size();
         const uint64_t stored = counter < cap ? counter : cap;
-        std::ofstream f(argv[3], std::ios::binary);
+        std::ofstream f(std::string(argv[3]) == "-" ? "/dev/null" : argv[3], std::ios::binary);
         f.write(reinterpret_cast<const char*>(&counter), 4);
         f.write(reinterpret_cast<const char*>(&cap), 4);
         f.write(reinterpret_cast<const char*>(&ssbo_bytes), 8);
         f.write(reinterpret_cast<const char*>(ssbo.data()), (std::streamsize)(stored * 96));
-        fprintf(stdout, "{\"counter\": %u, \"max_gaussians\": %u, \"ssbo_bytes\": %llu, \"draws\": %llu, \"meshes\": %zu}\n", counter, cap,
-                (unsigned long long)ssbo_bytes, (unsigned long long)swgl::n_draws, rc.dataMeshAndGlMesh.size());
+        // execute_ms: wall time of the reference's ConversionPass::execute on this CPU (one thread) — the reference-side
+        // number bench.py reports as cpu_baseline.kind = "reference"
+        fprintf(stdout, "{\"counter\": %u, \"max_gaussians\": %u, \"ssbo_bytes\": %llu, \"draws\": %llu, \"meshes\": %zu, \"execute_ms\": %.3f}\n",
+                counter, cap, (unsigned long long)ssbo_bytes, (unsigned long long)swgl::n_draws, rc.dataMeshAndGlMesh.size(), exec_ms);
 
         if (argc == 7) {
             const unsigned fmt = (unsigned)atoi(argv[5]);
