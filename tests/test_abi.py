@@ -60,3 +60,18 @@ def test_product_never_imports_oracle():
                     if f == "_lib.py" and re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_gfx950_has_no_image_sampling(tmp_path):
+    """the north star's 'bindless image sampling' cannot exist on MI355X — hipcc refuses tex2DLod for gfx950.
+    (Keeps that statement honest: if a future toolchain accepts it, this test fails and the design should be revisited.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "tools", "probe_image_support.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--offload-device-only", "-S", src, "-o", str(tmp_path / "x.s")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "image/texture API not supported" in r.stderr
