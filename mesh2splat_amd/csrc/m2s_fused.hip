@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                                                   unsigned long long limit, float4* __restrict__ out,
                                                   unsigned long long* __restrict__ total_out,
                                                   uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                  BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta) {
+                                                  BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
+                                                  uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */) {
     __shared__ WaveLds lds_all[kBlock / 64];
 #ifdef M2S_LDS_PAD   // debug: lower the occupancy artificially
     __shared__ volatile uint32_t lds_pad[M2S_LDS_PAD / 4];
@@ -190,12 +191,12 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     const uint32_t lb = ((round / kXcdRun) * 8u + xcd) * kXcdRun + (round % kXcdRun);
     // global wave id == chain index (made scalar explicitly: the compiler cannot prove threadIdx.x>>6 uniform)
     const uint32_t wid = lb * (kBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_waves = (sc.n_tri + 63u) / 64u;
+    const uint32_t n_waves = (sc.n_tri + tpw - 1u) / tpw;
     if (wid >= n_waves) return;
-    const uint32_t t0 = wid * 64u;
+    const uint32_t t0 = wid * tpw;
     const uint32_t t = t0 + lane;
-    const bool valid = t < sc.n_tri;
-    const uint32_t lastT = min(t0 + 64u, sc.n_tri) - 1;
+    const bool valid = (uint32_t)lane < tpw && t < sc.n_tri;
+    const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
     const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
     const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
 
@@ -454,10 +455,13 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
 
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
-    uint32_t nb = n_fused_blocks(sc.n_tri);
+    // Small scenes: fewer triangles per wave, so that there are enough waves to occupy the GPU (3072 wave slots) and
+    // each wave's serial chain of phases is shorter.  The fragment phase still runs full 64-lane strips.
+    const uint32_t tpw = fused_tpw(sc.n_tri);
+    uint32_t nb = (n_fused_waves(sc.n_tri) + kBlock / 64 - 1) / (kBlock / 64);
     if (!nb) return;
     nb = (nb + 8 * kXcdRun - 1) / (8 * kXcdRun) * (8 * kXcdRun);  // whole XCD runs; surplus workgroups exit at once
-    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status, epoch & 0xFFFFu, biglist, bigmeta);
+    hipLaunchKernelGGL(k_fused, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status, epoch & 0xFFFFu, biglist, bigmeta, tpw);
 }
 
 #ifdef M2S_TIMING
