@@ -231,10 +231,10 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         if (off + len > g.bin_len) { err = "image bufferView exceeds the binary chunk"; return false; }
         Image img;
         std::string perr;
-        if (!decode_png(g.bin + off, len, img, perr)) {
-            const std::string mime = im["mimeType"].string_or("?");
-            err = "image " + std::to_string(src) + " (" + mime + "): " + perr +
-                  (mime == "image/jpeg" ? " - JPEG decoding is not available in this build; re-export the asset with PNG textures" : "");
+        // like stb_image, go by the file signature, not by the declared mimeType
+        const bool is_jpeg = len >= 3 && g.bin[off] == 0xFF && g.bin[off + 1] == 0xD8 && g.bin[off + 2] == 0xFF;
+        if (!(is_jpeg ? decode_jpeg(g.bin + off, len, img, perr) : decode_png(g.bin + off, len, img, perr))) {
+            err = "image " + std::to_string(src) + " (" + im["mimeType"].string_or("?") + "): " + perr;
             return false;
         }
         scene.images.push_back(std::move(img));

@@ -17,6 +17,8 @@ struct Image {
 
 // PNG -> RGBA8 (tiny_gltf/stb_image behaviour: always 4 components).  false + err on failure.
 bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err);
+// JPEG (baseline / progressive Huffman, 8 bit, 1 or 3 components) -> RGBA8, bit-identical to stb_image's decoder.
+bool decode_jpeg(const uint8_t* data, size_t len, Image& img, std::string& err);
 
 // == utils::Mesh + its meshToTextureData entry after SceneManager::loadModel
 struct HostMesh {

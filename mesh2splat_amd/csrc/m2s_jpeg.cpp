@@ -1,0 +1,677 @@
+// m2s_jpeg.cpp — JPEG decoder of the scene loader (host code).
+//
+// The reference decodes glTF images with tiny_gltf -> stb_image 2.29 (vendored under thirdParty/, not copied here).
+// Entropy decoding is fixed by ITU-T T.81; what is implementation-defined — the inverse DCT, chroma upsampling and
+// the YCbCr -> RGB conversion — follows stb_image's published integer algorithms so that decoded texels are
+// bit-identical to what the reference uploads to GL (checked against the reference's own loader, compiled from where
+// it lies: tests/test_ref_host.py::test_jpeg_textures_match_reference_*):
+//   * IDCT: the IJG "jidctint" (Loeffler-Ligtenberg-Moschytz) factorisation with 12-bit constants, column pass kept at
+//     +2 fractional bits (rounding 512, >> 10), row pass rounding 65536 + (128 << 17), >> 17, clamped to [0,255];
+//   * upsampling: "fancy" triangle filters for the 2x1, 1x2 and 2x2 cases ((3a+b+2)>>2 and (3(3a+b)+(3c+d)+8)>>4),
+//     sample replication for every other ratio;
+//   * colour: 20-bit fixed point (y << 20) + (1 << 19) with the constants 1.40200, 0.71414, 0.34414, 1.77200 rounded
+//     at 12 bits, the Cb contribution to green truncated to its upper 16 bits.
+// Supported: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2) Huffman JPEG, 8 bits per sample,
+// 1 or 3 components, sampling factors 1..4, restart intervals, Adobe APP14 / component-id RGB detection.
+// Not supported (explicit error): arithmetic coding, lossless, 12-bit, 4-component (CMYK / YCCK) files.
+#include <cstring>
+
+#include "m2s_host.h"
+
+namespace m2s_host {
+namespace {
+
+const uint8_t kZigzag[64 + 15] = { 0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                   6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                   39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+                                   63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };  // tail: corrupt-stream guard
+
+struct Huff {
+    // canonical table: codes of length l are [first[l], first[l] + count[l]) ; values in code order
+    int count[17] = {};
+    int first_code[18] = {};
+    int first_index[17] = {};
+    uint8_t values[256] = {};
+    bool present = false;
+    bool build(const uint8_t* counts, const uint8_t* vals, int n_vals) {
+        int code = 0, idx = 0;
+        for (int l = 1; l <= 16; ++l) {
+            count[l] = counts[l - 1];
+            first_code[l] = code;
+            first_index[l] = idx;
+            code += count[l];
+            idx += count[l];
+            if (code > (1 << l)) return false;
+            code <<= 1;
+        }
+        if (idx != n_vals || idx > 256) return false;
+        std::memcpy(values, vals, (size_t)n_vals);
+        present = true;
+        return true;
+    }
+};
+
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int dc_pred = 0;
+    int x = 0, y = 0;            // size in samples
+    int w2 = 0, h2 = 0;          // size padded to whole MCUs
+    int bw = 0, bh = 0;          // size in blocks, padded to whole MCUs
+    std::vector<uint8_t> data;   // decoded samples, w2 x h2
+    std::vector<short> coeff;    // progressive: 64 coefficients per block
+};
+
+struct Decoder {
+    const uint8_t* p;
+    const uint8_t* end;
+    std::string* err;
+    // frame
+    bool progressive = false;
+    int img_x = 0, img_y = 0, n_comp = 0;
+    int h_max = 1, v_max = 1, mcu_w = 0, mcu_h = 0, mcu_x = 0, mcu_y = 0;
+    Component comp[4];
+    uint16_t dequant[4][64] = {};
+    bool have_q[4] = {};
+    Huff dc[4], ac[4];
+    int restart_interval = 0;
+    bool jfif = false;
+    int app14_transform = -1;
+    int rgb_ids = 0;
+    // scan
+    int scan_n = 0, order[4] = {};
+    int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;
+    // bit reader
+    uint32_t code_buffer = 0;
+    int code_bits = 0;
+    uint8_t marker = 0xFF;       // marker met inside the entropy-coded data (0xFF = none)
+    bool nomore = false;
+    int todo = 0;
+
+    bool fail(const char* m) { *err = m; return false; }
+    int get8() { return p < end ? *p++ : 0; }
+    int get16() { const int a = get8(); return (a << 8) | get8(); }
+
+    void grow() {
+        do {
+            unsigned b = nomore ? 0u : (unsigned)get8();
+            if (b == 0xFF) {
+                int c = get8();
+                while (c == 0xFF) c = get8();   // fill bytes
+                if (c != 0) { marker = (uint8_t)c; nomore = true; b = 0; }
+            }
+            code_buffer |= b << (24 - code_bits);
+            code_bits += 8;
+        } while (code_bits <= 24);
+    }
+    int get_bits(int n) {
+        if (n == 0) return 0;
+        if (code_bits < n) grow();
+        const int v = (int)(code_buffer >> (32 - n));
+        code_buffer <<= n;
+        code_bits -= n;
+        return v;
+    }
+    int get_bit() { return get_bits(1); }
+    int extend_receive(int n) {   // T.81 F.2.2.1 RECEIVE + EXTEND
+        if (n == 0) return 0;
+        const int v = get_bits(n);
+        return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v;
+    }
+    int decode_huff(const Huff& h) {
+        if (code_bits < 16) grow();
+        int code = 0;
+        for (int l = 1; l <= 16; ++l) {
+            code = (code << 1) | (int)(code_buffer >> 31);
+            code_buffer <<= 1;
+            --code_bits;
+            if (h.count[l] && code >= h.first_code[l] && code < h.first_code[l] + h.count[l])
+                return h.values[h.first_index[l] + code - h.first_code[l]];
+        }
+        return -1;
+    }
+    void reset_scan_state() {
+        code_bits = 0; code_buffer = 0; nomore = false; marker = 0xFF;
+        for (int i = 0; i < 4; ++i) comp[i].dc_pred = 0;
+        todo = restart_interval ? restart_interval : 0x7FFFFFFF;
+        eob_run = 0;
+    }
+
+    // ---- block decoders (T.81 F.2.2, G.1.2) ------------------------------------------------------------------
+    bool block_baseline(short data[64], Component& c) {
+        const Huff &hdc = dc[c.td], &hac = ac[c.ta];
+        const uint16_t* dq = dequant[c.tq];
+        std::memset(data, 0, 64 * sizeof(short));
+        const int t = decode_huff(hdc);
+        if (t < 0 || t > 15) return fail("bad JPEG Huffman code");
+        const int diff = t ? extend_receive(t) : 0;
+        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);   // (wraps instead of overflowing on corrupt streams)
+        data[0] = (short)((unsigned)c.dc_pred * dq[0]);
+        int k = 1;
+        do {
+            const int rs = decode_huff(hac);
+            if (rs < 0) return fail("bad JPEG Huffman code");
+            const int s = rs & 15, r = rs >> 4;
+            if (s == 0) {
+                if (rs != 0xF0) break;   // end of block
+                k += 16;
+            } else {
+                k += r;
+                const int zig = kZigzag[k++];
+                data[zig] = (short)(extend_receive(s) * dq[zig]);
+            }
+        } while (k < 64);
+        return true;
+    }
+    bool block_prog_dc(short data[64], Component& c) {
+        if (spec_end != 0) return fail("corrupt progressive JPEG");
+        if (succ_high == 0) {
+            std::memset(data, 0, 64 * sizeof(short));
+            const int t = decode_huff(dc[c.td]);
+            if (t < 0 || t > 15) return fail("bad JPEG Huffman code");
+            const int diff = t ? extend_receive(t) : 0;
+            c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);
+            data[0] = (short)((unsigned)c.dc_pred << succ_low);
+        } else if (get_bit()) {
+            data[0] = (short)(data[0] + (1 << succ_low));
+        }
+        return true;
+    }
+    bool block_prog_ac(short data[64], const Huff& hac) {
+        if (spec_start == 0) return fail("corrupt progressive JPEG");
+        if (succ_high == 0) {
+            const int shift = succ_low;
+            if (eob_run) { --eob_run; return true; }
+            int k = spec_start;
+            do {
+                const int rs = decode_huff(hac);
+                if (rs < 0) return fail("bad JPEG Huffman code");
+                const int s = rs & 15, r = rs >> 4;
+                if (s == 0) {
+                    if (r < 15) {
+                        eob_run = 1 << r;
+                        if (r) eob_run += get_bits(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    const int zig = kZigzag[k++];
+                    data[zig] = (short)(extend_receive(s) * (1 << shift));
+                }
+            } while (k <= spec_end);
+        } else {   // refinement scan
+            const short bit = (short)(1 << succ_low);
+            if (eob_run) {
+                --eob_run;
+                for (int k = spec_start; k <= spec_end; ++k) {
+                    short* q = &data[kZigzag[k]];
+                    if (*q != 0 && get_bit() && (*q & bit) == 0) *q = (short)(*q > 0 ? *q + bit : *q - bit);
+                }
+            } else {
+                int k = spec_start;
+                do {
+                    const int rs = decode_huff(hac);
+                    if (rs < 0) return fail("bad JPEG Huffman code");
+                    int s = rs & 15, r = rs >> 4;
+                    if (s == 0) {
+                        if (r < 15) {
+                            eob_run = (1 << r) - 1;
+                            if (r) eob_run += get_bits(r);
+                            r = 64;   // run to the end of the band
+                        }
+                    } else {
+                        if (s != 1) return fail("bad JPEG Huffman code");
+                        s = get_bit() ? bit : -bit;
+                    }
+                    while (k <= spec_end) {
+                        short* q = &data[kZigzag[k++]];
+                        if (*q != 0) {
+                            if (get_bit() && (*q & bit) == 0) *q = (short)(*q > 0 ? *q + bit : *q - bit);
+                        } else {
+                            if (r == 0) { *q = (short)s; break; }
+                            --r;
+                        }
+                    }
+                } while (k <= spec_end);
+            }
+        }
+        return true;
+    }
+
+    // ---- inverse DCT (see the header comment) ------------------------------------------------------------------
+    static inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
+    static inline uint8_t clamp8(long long x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
+    static void idct(uint8_t* out, int stride, const short d[64]) {
+        static const int c0541 = f2f(0.5411961), cm1847 = f2f(-1.847759065), c0765 = f2f(0.765366865), c1175 = f2f(1.175875602),
+                         c0298 = f2f(0.298631336), c2053 = f2f(2.053119869), c3072 = f2f(3.072711026), c1501 = f2f(1.501321110),
+                         cm0899 = f2f(-0.899976223), cm2562 = f2f(-2.562915447), cm1961 = f2f(-1.961570560), cm0390 = f2f(-0.390180644);
+        // 64-bit temporaries: identical results for every valid stream (the 32-bit reference arithmetic cannot overflow
+        // there) and no undefined behaviour on corrupt coefficients
+        long long val[64];
+#define M2S_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                    \
+        long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                  \
+        p2 = s2; p3 = s6;                                                              \
+        p1 = (p2 + p3) * c0541;                                                        \
+        t2 = p1 + p3 * cm1847;                                                         \
+        t3 = p1 + p2 * c0765;                                                          \
+        p2 = s0; p3 = s4;                                                              \
+        t0 = (p2 + p3) * 4096;                                                         \
+        t1 = (p2 - p3) * 4096;                                                         \
+        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                        \
+        t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                            \
+        p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                        \
+        p5 = (p3 + p4) * c1175;                                                        \
+        t0 = t0 * c0298; t1 = t1 * c2053; t2 = t2 * c3072; t3 = t3 * c1501;            \
+        p1 = p5 + p1 * cm0899; p2 = p5 + p2 * cm2562; p3 = p3 * cm1961; p4 = p4 * cm0390; \
+        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+        for (int i = 0; i < 8; ++i) {   // columns
+            const short* s = d + i;
+            long long* v = val + i;
+            if (s[8] == 0 && s[16] == 0 && s[24] == 0 && s[32] == 0 && s[40] == 0 && s[48] == 0 && s[56] == 0) {
+                const long long dcterm = s[0] * 4;
+                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
+            } else {
+                M2S_IDCT_1D(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56])
+                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+                v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
+                v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+                v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
+                v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+            }
+        }
+        for (int i = 0; i < 8; ++i) {   // rows
+            const long long* v = val + 8 * i;
+            uint8_t* o = out + (size_t)i * stride;
+            M2S_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+            x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17);
+            o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
+            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17);
+            o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+        }
+#undef M2S_IDCT_1D
+    }
+
+    // ---- markers ---------------------------------------------------------------------------------------------------
+    bool process_marker(int m) {
+        switch (m) {
+        case 0xDD: {
+            if (get16() != 4) return fail("bad DRI length");
+            restart_interval = get16();
+            return true;
+        }
+        case 0xDB: {
+            int L = get16() - 2;
+            while (L > 0) {
+                const int q = get8(), prec = q >> 4, t = q & 15;
+                if (prec > 1 || t > 3) return fail("bad DQT");
+                for (int i = 0; i < 64; ++i) dequant[t][kZigzag[i]] = (uint16_t)(prec ? get16() : get8());
+                have_q[t] = true;
+                L -= prec ? 129 : 65;
+            }
+            return L == 0 ? true : fail("bad DQT length");
+        }
+        case 0xC4: {
+            int L = get16() - 2;
+            while (L > 0) {
+                const int q = get8(), tc = q >> 4, th = q & 15;
+                if (tc > 1 || th > 3) return fail("bad DHT");
+                uint8_t counts[16];
+                int n = 0;
+                for (int i = 0; i < 16; ++i) { counts[i] = (uint8_t)get8(); n += counts[i]; }
+                if (n > 256) return fail("bad DHT");
+                uint8_t vals[256];
+                for (int i = 0; i < n; ++i) vals[i] = (uint8_t)get8();
+                if (!(tc ? ac[th] : dc[th]).build(counts, vals, n)) return fail("bad DHT code lengths");
+                L -= 17 + n;
+            }
+            return L == 0 ? true : fail("bad DHT length");
+        }
+        default: break;
+        }
+        if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE) {
+            int L = get16();
+            if (L < 2) return fail("bad APP/COM length");
+            L -= 2;
+            if (m == 0xE0 && L >= 5) {
+                static const char tag[5] = { 'J', 'F', 'I', 'F', 0 };
+                bool ok = true;
+                for (int i = 0; i < 5; ++i) if (get8() != tag[i]) ok = false;
+                L -= 5;
+                if (ok) jfif = true;
+            } else if (m == 0xEE && L >= 12) {
+                static const char tag[6] = { 'A', 'd', 'o', 'b', 'e', 0 };
+                bool ok = true;
+                for (int i = 0; i < 6; ++i) if (get8() != tag[i]) ok = false;
+                L -= 6;
+                if (ok) {
+                    get8(); get16(); get16();      // version, flags0, flags1
+                    app14_transform = get8();
+                    L -= 6;
+                }
+            }
+            if (p + L > end) return fail("truncated JPEG");
+            p += L;
+            return true;
+        }
+        return fail("unsupported JPEG marker");
+    }
+    int next_marker() {
+        if (marker != 0xFF) { const int m = marker; marker = 0xFF; return m; }
+        int x = get8();
+        if (x != 0xFF) return 0xFF;
+        while (x == 0xFF) x = get8();
+        return x;
+    }
+    bool frame_header(int sof) {
+        progressive = sof == 0xC2;
+        const int L = get16();
+        if (L < 11) return fail("bad SOF length");
+        if (get8() != 8) return fail("only 8-bit JPEG is supported");
+        img_y = get16();
+        img_x = get16();
+        if (img_y == 0 || img_x == 0) return fail("JPEG with zero size");
+        n_comp = get8();
+        if (n_comp != 1 && n_comp != 3) return fail("only 1- and 3-component JPEG is supported (no CMYK)");
+        if (L != 8 + 3 * n_comp) return fail("bad SOF length");
+        rgb_ids = 0;
+        for (int i = 0; i < n_comp; ++i) {
+            static const unsigned char rgb[3] = { 'R', 'G', 'B' };
+            comp[i].id = get8();
+            if (n_comp == 3 && comp[i].id == rgb[i]) ++rgb_ids;
+            const int q = get8();
+            comp[i].h = q >> 4; comp[i].v = q & 15;
+            if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) return fail("bad JPEG sampling factors");
+            comp[i].tq = get8();
+            if (comp[i].tq > 3) return fail("bad JPEG quantisation table index");
+        }
+        h_max = v_max = 1;
+        for (int i = 0; i < n_comp; ++i) { h_max = std::max(h_max, comp[i].h); v_max = std::max(v_max, comp[i].v); }
+        for (int i = 0; i < n_comp; ++i)
+            if (h_max % comp[i].h || v_max % comp[i].v) return fail("bad JPEG sampling factors");
+        mcu_w = h_max * 8; mcu_h = v_max * 8;
+        mcu_x = (img_x + mcu_w - 1) / mcu_w;
+        mcu_y = (img_y + mcu_h - 1) / mcu_h;
+        if ((uint64_t)mcu_x * mcu_w * (uint64_t)mcu_y * mcu_h > (1ull << 30)) return fail("JPEG too large");
+        for (int i = 0; i < n_comp; ++i) {
+            Component& c = comp[i];
+            c.x = (img_x * c.h + h_max - 1) / h_max;
+            c.y = (img_y * c.v + v_max - 1) / v_max;
+            c.w2 = mcu_x * c.h * 8;
+            c.h2 = mcu_y * c.v * 8;
+            c.bw = c.w2 / 8; c.bh = c.h2 / 8;
+            c.data.assign((size_t)c.w2 * c.h2, 0);
+            if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
+        }
+        return true;
+    }
+    bool scan_header() {
+        const int L = get16();
+        scan_n = get8();
+        if (scan_n < 1 || scan_n > 4 || scan_n > n_comp) return fail("bad SOS component count");
+        if (L != 6 + 2 * scan_n) return fail("bad SOS length");
+        for (int i = 0; i < scan_n; ++i) {
+            const int id = get8(), q = get8();
+            int which = 0;
+            while (which < n_comp && comp[which].id != id) ++which;
+            if (which == n_comp) return fail("SOS names an unknown component");
+            comp[which].td = q >> 4; comp[which].ta = q & 15;
+            if (comp[which].td > 3 || comp[which].ta > 3) return fail("bad SOS table index");
+            order[i] = which;
+        }
+        spec_start = get8();
+        spec_end = get8();
+        const int a = get8();
+        succ_high = a >> 4; succ_low = a & 15;
+        if (progressive) {
+            if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) return fail("bad SOS");
+        } else {
+            if (spec_start != 0 || succ_high != 0 || succ_low != 0) return fail("bad SOS");
+            spec_end = 63;
+        }
+        return true;
+    }
+    bool restart_if_due() {   // called after every MCU / block
+        if (--todo <= 0) {
+            if (code_bits < 24) grow();
+            if (!(marker >= 0xD0 && marker <= 0xD7)) return true;   // no RSTn: the scan ends here
+            reset_scan_state();
+        }
+        return true;
+    }
+    bool entropy_scan() {
+        reset_scan_state();
+        short block[64];
+        if (!progressive) {
+            if (scan_n == 1) {   // non-interleaved: the component's own block grid, without MCU padding
+                Component& c = comp[order[0]];
+                const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+                for (int j = 0; j < h; ++j)
+                    for (int i = 0; i < w; ++i) {
+                        if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return fail("JPEG table missing");
+                        if (!block_baseline(block, c)) return false;
+                        idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, block);
+                        if (--todo <= 0) {
+                            if (code_bits < 24) grow();
+                            if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
+                            reset_scan_state();
+                        }
+                    }
+                return true;
+            }
+            for (int j = 0; j < mcu_y; ++j)
+                for (int i = 0; i < mcu_x; ++i) {
+                    for (int k = 0; k < scan_n; ++k) {
+                        Component& c = comp[order[k]];
+                        if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return fail("JPEG table missing");
+                        for (int y = 0; y < c.v; ++y)
+                            for (int x = 0; x < c.h; ++x) {
+                                const int x2 = (i * c.h + x) * 8, y2 = (j * c.v + y) * 8;
+                                if (!block_baseline(block, c)) return false;
+                                idct(c.data.data() + (size_t)c.w2 * y2 + x2, c.w2, block);
+                            }
+                    }
+                    if (--todo <= 0) {
+                        if (code_bits < 24) grow();
+                        if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
+                        reset_scan_state();
+                    }
+                }
+            return true;
+        }
+        // progressive
+        if (scan_n == 1) {
+            Component& c = comp[order[0]];
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) {
+                    short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.bw);
+                    if (spec_start == 0) {
+                        if (!dc[c.td].present) return fail("JPEG table missing");
+                        if (!block_prog_dc(data, c)) return false;
+                    } else {
+                        if (!ac[c.ta].present) return fail("JPEG table missing");
+                        if (!block_prog_ac(data, ac[c.ta])) return false;
+                    }
+                    if (--todo <= 0) {
+                        if (code_bits < 24) grow();
+                        if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
+                        reset_scan_state();
+                    }
+                }
+            return true;
+        }
+        for (int j = 0; j < mcu_y; ++j)
+            for (int i = 0; i < mcu_x; ++i) {
+                for (int k = 0; k < scan_n; ++k) {
+                    Component& c = comp[order[k]];
+                    if (!dc[c.td].present) return fail("JPEG table missing");
+                    for (int y = 0; y < c.v; ++y)
+                        for (int x = 0; x < c.h; ++x) {
+                            const int x2 = i * c.h + x, y2 = j * c.v + y;
+                            short* data = c.coeff.data() + 64 * ((size_t)x2 + (size_t)y2 * c.bw);
+                            if (!block_prog_dc(data, c)) return false;   // interleaved progressive scans are DC scans
+                        }
+                }
+                if (--todo <= 0) {
+                    if (code_bits < 24) grow();
+                    if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
+                    reset_scan_state();
+                }
+            }
+        return true;
+    }
+    void finish_progressive() {
+        for (int n = 0; n < n_comp; ++n) {
+            Component& c = comp[n];
+            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) {
+                    short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.bw);
+                    const uint16_t* dq = dequant[c.tq];
+                    for (int k = 0; k < 64; ++k) data[k] = (short)(data[k] * dq[k]);
+                    idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                }
+        }
+    }
+
+    bool decode() {
+        if (get8() != 0xFF || get8() != 0xD8) return fail("not a JPEG file");
+        int m = next_marker();
+        while (!(m == 0xC0 || m == 0xC1 || m == 0xC2)) {
+            if (m == 0xFF) { if (p >= end) return fail("no SOF marker"); m = next_marker(); continue; }
+            if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail("unsupported JPEG process (lossless / arithmetic)");
+            if (!process_marker(m)) return false;
+            m = next_marker();
+        }
+        if (!frame_header(m)) return false;
+        m = next_marker();
+        while (m != 0xD9) {
+            if (m == 0xDA) {
+                if (!scan_header()) return false;
+                if (!entropy_scan()) return false;
+                if (marker == 0xFF) {   // skip to the next marker (padding after the entropy-coded segment)
+                    while (p < end) {
+                        const int x = get8();
+                        if (x == 0xFF) { const int y = get8(); if (y != 0 && y != 0xFF) { marker = (uint8_t)y; break; } if (y == 0xFF) --p; }
+                    }
+                    if (marker == 0xFF && p >= end) break;   // missing EOI: decode what we have, like stb_image
+                }
+            } else if (m == 0xDC) {
+                const int L = get16(), nl = get16();
+                if (L != 4 || nl != img_y) return fail("bad DNL");
+            } else if (m == 0xFF) {
+                if (p >= end) break;
+            } else if (!process_marker(m)) {
+                return false;
+            }
+            m = next_marker();
+        }
+        if (progressive) finish_progressive();
+        return true;
+    }
+};
+
+// ---- upsampling (see the header comment) ----------------------------------------------------------------------------
+typedef uint8_t* (*ResampleFn)(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int hs);
+uint8_t* resample_1(uint8_t*, const uint8_t* in_near, const uint8_t*, int, int) { return const_cast<uint8_t*>(in_near); }
+uint8_t* resample_v2(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int) {
+    for (int i = 0; i < w; ++i) out[i] = (uint8_t)((3 * in_near[i] + in_far[i] + 2) >> 2);
+    return out;
+}
+uint8_t* resample_h2(uint8_t* out, const uint8_t* in_near, const uint8_t*, int w, int) {
+    const uint8_t* in = in_near;
+    if (w == 1) { out[0] = out[1] = in[0]; return out; }
+    out[0] = in[0];
+    out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+    int i;
+    for (i = 1; i < w - 1; ++i) {
+        const int n = 3 * in[i] + 2;
+        out[i * 2 + 0] = (uint8_t)((n + in[i - 1]) >> 2);
+        out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2);
+    }
+    out[i * 2 + 0] = (uint8_t)((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
+    out[i * 2 + 1] = in[w - 1];
+    return out;
+}
+uint8_t* resample_hv2(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int) {
+    if (w == 1) { out[0] = out[1] = (uint8_t)((3 * in_near[0] + in_far[0] + 2) >> 2); return out; }
+    int t1 = 3 * in_near[0] + in_far[0];
+    out[0] = (uint8_t)((t1 + 2) >> 2);
+    for (int i = 1; i < w; ++i) {
+        const int t0 = t1;
+        t1 = 3 * in_near[i] + in_far[i];
+        out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+        out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+    }
+    out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+    return out;
+}
+uint8_t* resample_generic(uint8_t* out, const uint8_t* in_near, const uint8_t*, int w, int hs) {
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < hs; ++j) out[i * hs + j] = in_near[i];
+    return out;
+}
+
+inline int float2fixed(double x) { return ((int)(x * 4096.0 + 0.5)) << 8; }
+
+}  // namespace
+
+bool decode_jpeg(const uint8_t* data, size_t len, Image& img, std::string& err) {
+    Decoder d;
+    d.p = data; d.end = data + len; d.err = &err;
+    if (!d.decode()) return false;
+    const int W = d.img_x, H = d.img_y;
+    img.width = (uint32_t)W; img.height = (uint32_t)H;
+    img.rgba.assign((size_t)W * H * 4, 255);
+
+    struct Res { ResampleFn fn; const uint8_t *line0, *line1; int hs, vs, w_lores, ystep, ypos; std::vector<uint8_t> buf; } res[3];
+    for (int k = 0; k < d.n_comp; ++k) {
+        Res& r = res[k];
+        const Component& c = d.comp[k];
+        r.hs = d.h_max / c.h; r.vs = d.v_max / c.v;
+        r.ystep = r.vs >> 1;
+        r.w_lores = (W + r.hs - 1) / r.hs;
+        r.ypos = 0;
+        r.line0 = r.line1 = c.data.data();
+        r.buf.assign((size_t)W + 3 + 16, 0);
+        r.fn = (r.hs == 1 && r.vs == 1) ? resample_1 : (r.hs == 1 && r.vs == 2) ? resample_v2 : (r.hs == 2 && r.vs == 1) ? resample_h2
+               : (r.hs == 2 && r.vs == 2) ? resample_hv2 : resample_generic;
+    }
+    const bool is_rgb = d.n_comp == 3 && (d.rgb_ids == 3 || (d.app14_transform == 0 && !d.jfif));
+    const int k_cr_r = float2fixed(1.40200), k_cr_g = -float2fixed(0.71414), k_cb_g = -float2fixed(0.34414), k_cb_b = float2fixed(1.77200);
+    for (int j = 0; j < H; ++j) {
+        const uint8_t* row[3] = { nullptr, nullptr, nullptr };
+        for (int k = 0; k < d.n_comp; ++k) {
+            Res& r = res[k];
+            const Component& c = d.comp[k];
+            const bool y_bot = r.ystep >= (r.vs >> 1);
+            row[k] = r.fn(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs);
+            if (++r.ystep >= r.vs) {
+                r.ystep = 0;
+                r.line0 = r.line1;
+                if (++r.ypos < c.y) r.line1 += c.w2;
+            }
+        }
+        uint8_t* out = img.rgba.data() + (size_t)j * W * 4;
+        if (d.n_comp == 1) {
+            for (int i = 0; i < W; ++i) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = row[0][i]; out[4 * i + 3] = 255; }
+        } else if (is_rgb) {
+            for (int i = 0; i < W; ++i) { out[4 * i] = row[0][i]; out[4 * i + 1] = row[1][i]; out[4 * i + 2] = row[2][i]; out[4 * i + 3] = 255; }
+        } else {
+            for (int i = 0; i < W; ++i) {
+                const int y_fixed = (row[0][i] << 20) + (1 << 19);
+                const int cr = row[2][i] - 128, cb = row[1][i] - 128;
+                int r = y_fixed + cr * k_cr_r;
+                int g = y_fixed + cr * k_cr_g + (int)(((unsigned)(cb * k_cb_g)) & 0xffff0000u);
+                int b = y_fixed + cb * k_cb_b;
+                r >>= 20; g >>= 20; b >>= 20;
+                out[4 * i] = Decoder::clamp8(r); out[4 * i + 1] = Decoder::clamp8(g); out[4 * i + 2] = Decoder::clamp8(b); out[4 * i + 3] = 255;
+            }
+        }
+    }
+    return true;
+}
+
+}  // namespace m2s_host

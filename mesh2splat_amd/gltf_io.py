@@ -131,7 +131,7 @@ def write_glb(scene: Scene, path: str, indexed: bool = True, with_normals: bool 
         ident = (key if png_override and key in png_override else None, id(img))
         if ident not in image_of:
             data = png_override[key] if png_override and key in png_override else encode_png(img)
-            images.append({"bufferView": add_view(data), "mimeType": "image/png"})
+            images.append({"bufferView": add_view(data), "mimeType": "image/jpeg" if data[:2] == b"\xff\xd8" else "image/png"})
             textures.append({"source": len(images) - 1})
             image_of[ident] = len(textures) - 1
         return image_of[ident]

@@ -45,6 +45,19 @@ def scene_cases():
     yield "mixed_materials_u32", mixed, dict(index_type="u32")
 
 
+def jpeg_cases():
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    y, x = np.mgrid[0:40, 0:56]
+    a = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 5.0 + y / 9.0), 128 + 80 * np.sin((x + y) / 13.0)], -1)
+    img = np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)
+    for name, kw in (("jpeg_baseline_420", dict(quality=80, subsampling=2)), ("jpeg_progressive_422", dict(quality=70, subsampling=1, progressive=True))):
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", **kw)
+        yield name, b.getvalue()
+
+
 def glsl_cases():
     """(name, scene, R, FS samples per triangle) for the shader-level fixtures."""
     yield "sphere", synth.cube_sphere(4, tex_size=16), 64, 3
@@ -88,6 +101,12 @@ def main():
     for name, scene, kw in scene_cases():
         glb = os.path.join(OUT, name + ".glb")
         gltf_io.write_glb(scene, glb, **kw)
+        refhost.load_scene(glb, tmp)
+        shutil.copy(os.path.join(tmp, "ref_scene.bin"), os.path.join(OUT, name + ".scene.bin"))
+    # JPEG-textured scenes (decoded by stb_image in the reference)
+    for name, jpg in jpeg_cases():
+        glb = os.path.join(OUT, name + ".glb")
+        gltf_io.write_glb(synth.cube_sphere(2, tex_size=8), glb, png_override={"baseColorTexture": jpg, "metallicRoughnessTexture": jpg})
         refhost.load_scene(glb, tmp)
         shutil.copy(os.path.join(tmp, "ref_scene.bin"), os.path.join(OUT, name + ".scene.bin"))
     rec = sample_records()

@@ -170,10 +170,13 @@ def test_loader_errors(tmp_path, hiplib):
     bad.write_bytes(b"not a glb at all, definitely")
     with pytest.raises(M2SError, match="not a binary glTF"):
         gltf_io.load_glb(str(bad))
-    # JPEG payload -> explicit, actionable error (no silent texture loss)
+    # broken image payloads -> explicit error naming the image (no silent texture loss)
     scene = synth.unit_quad({"baseColorTexture": np.zeros((2, 2, 4), np.uint8)})
     p = str(tmp_path / "jpg.glb")
     gltf_io.write_glb(scene, p, png_override={"baseColorTexture": b"\xff\xd8\xff\xe0" + b"\0" * 64})
+    with pytest.raises(M2SError, match="image 0 .image/jpeg."):
+        gltf_io.load_glb(p)
+    gltf_io.write_glb(scene, p, png_override={"baseColorTexture": b"GIF89a" + b"\0" * 64})
     with pytest.raises(M2SError, match="not a PNG"):
         gltf_io.load_glb(p)
 

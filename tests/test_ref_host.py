@@ -108,3 +108,70 @@ def test_ply_matches_reference_live(tmp_path, hiplib, oracle, fmt):
         r, rp = refhost.read_ply(b, str(tmp_path))
         m, mp = gltf_io.read_ply(b)
         assert rp == mp and np.array_equal(r.view(np.uint32), m.view(np.uint32))
+
+
+# ---- JPEG textures (stb_image through tiny_gltf in the reference; mesh2splat_amd/csrc/m2s_jpeg.cpp here) -----------
+def _jpeg_cases():
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(12)
+
+    def smooth(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 5.0 + y / 9.0), 128 + 80 * np.sin((x + y) / 13.0)], -1)
+        return np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)
+
+    def enc(arr, **kw):
+        b = io.BytesIO()
+        PIL.fromarray(arr).save(b, "JPEG", **kw)
+        return b.getvalue()
+
+    yield "q90_444", enc(smooth(64, 48), quality=90, subsampling=0)
+    yield "q75_420_odd", enc(smooth(67, 45), quality=75, subsampling=2)
+    yield "q60_422", enc(smooth(33, 70), quality=60, subsampling=1)
+    yield "progressive_420", enc(smooth(100, 60), quality=80, subsampling=2, progressive=True)
+    yield "progressive_444", enc(smooth(37, 29), quality=95, subsampling=0, progressive=True)
+    yield "grayscale", enc(smooth(50, 50)[..., 0], quality=85)
+    yield "noise_420_q50", enc(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), quality=50, subsampling=2)
+    yield "restart_markers", enc(smooth(128, 96), quality=85, subsampling=2, restart_marker_blocks=3)
+    yield "one_pixel", enc(smooth(1, 1), quality=90)
+    yield "one_column_420", enc(smooth(1, 17), quality=90, subsampling=2)
+    yield "optimized_huffman", enc(smooth(80, 80), quality=70, optimize=True, subsampling=2)
+    yield "large_progressive", enc(smooth(512, 384), quality=88, subsampling=2, progressive=True, optimize=True)
+    yield "q100", enc(smooth(40, 40), quality=100, subsampling=0)
+    yield "q5", enc(smooth(96, 64), quality=5, subsampling=2)
+
+
+@live
+def test_jpeg_textures_match_reference_live(tmp_path, hiplib):
+    """Every decoded texel equals what the reference's loader (tiny_gltf -> stb_image) produces: baseline and
+    progressive, 4:4:4 / 4:2:2 / 4:2:0, grayscale, restart markers, odd sizes, extreme qualities."""
+    n = 0
+    for name, jpg in _jpeg_cases():
+        scene = synth.cube_sphere(2, tex_size=8)
+        glb = str(tmp_path / (name + ".glb"))
+        gltf_io.write_glb(scene, glb, png_override={"baseColorTexture": jpg, "normalTexture": jpg})
+        ref = refhost.load_scene(glb, str(tmp_path))
+        mine = gltf_io.load_glb(glb)
+        for key in ("baseColorTexture", "normalTexture"):
+            a, b = ref[0]["textures"][key], mine.meshes[0].textures[key]
+            assert a.shape == b.shape and np.array_equal(a, b), (name, key)
+        n += 1
+    assert n >= 14
+
+
+@pytest.mark.parametrize("name", ["jpeg_baseline_420", "jpeg_progressive_422"])
+def test_jpeg_textures_match_reference_golden(hiplib, name):
+    with open(os.path.join(GOLD, name + ".scene.bin"), "rb") as f:
+        ref = refhost.parse_scene_dump(f.read())
+    assert_scene_equal(ref, gltf_io.load_glb(os.path.join(GOLD, name + ".glb")))
+
+
+def test_jpeg_errors(tmp_path, hiplib):
+    from mesh2splat_amd._lib import M2SError
+    scene = synth.cube_sphere(2, tex_size=8)
+    for bad in (b"\xff\xd8\xff\xe0\x00\x02", b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x08\x00\x08\x01\x01\x11\x00"):
+        glb = str(tmp_path / "bad.glb")
+        gltf_io.write_glb(scene, glb, png_override={"baseColorTexture": bad})
+        with pytest.raises(M2SError):
+            gltf_io.load_glb(glb)
