@@ -153,6 +153,37 @@ void read_uv(const Accessor& a, size_t i, float out[2]) {
     out[0] = out[1] = 0.0f;
 }
 
+bool base64_decode(const char* s, size_t n, std::vector<uint8_t>& out) {
+    out.clear();
+    out.reserve(n / 4 * 3);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const char c = s[i];
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=' || c == '\n' || c == '\r' || c == ' ') continue;
+        else return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return true;
+}
+std::string uri_decode(const std::string& u) {   // %XX escapes
+    std::string r;
+    for (size_t i = 0; i < u.size(); ++i) {
+        auto hex = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+        if (u[i] == '%' && i + 2 < u.size() && hex(u[i + 1]) >= 0 && hex(u[i + 2]) >= 0) { r.push_back((char)(hex(u[i + 1]) * 16 + hex(u[i + 2]))); i += 2; }
+        else r.push_back(u[i]);
+    }
+    return r;
+}
+
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -224,16 +255,40 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         if (src < 0 || !im.is_object()) return true;
         auto it = image_slot.find(src);
         if (it != image_slot.end()) { out_slot = it->second; return true; }
+        // the encoded image: a bufferView of the binary chunk, or (like tiny_gltf) a data: URI / a file next to the .glb
+        const uint8_t* enc = nullptr;
+        size_t len = 0;
+        std::vector<uint8_t> ext;
         const long long bvi = im["bufferView"].int_or(-1);
         const auto& bv = doc["bufferViews"][(size_t)bvi];
-        if (bvi < 0 || !bv.is_object()) { err = "image " + std::to_string(src) + " is not embedded (external URIs are not supported in .glb mode)"; return false; }
-        const size_t off = (size_t)bv["byteOffset"].int_or(0), len = (size_t)bv["byteLength"].int_or(0);
-        if (off + len > g.bin_len) { err = "image bufferView exceeds the binary chunk"; return false; }
+        if (bvi >= 0 && bv.is_object()) {
+            const size_t off = (size_t)bv["byteOffset"].int_or(0);
+            len = (size_t)bv["byteLength"].int_or(0);
+            if (off + len > g.bin_len) { err = "image bufferView exceeds the binary chunk"; return false; }
+            enc = g.bin + off;
+        } else {
+            const std::string uri = im["uri"].string_or("");
+            if (uri.empty()) { err = "image " + std::to_string(src) + " has neither a bufferView nor a uri"; return false; }
+            if (uri.compare(0, 5, "data:") == 0) {
+                const size_t comma = uri.find(',');
+                if (comma == std::string::npos || uri.find(";base64") == std::string::npos || uri.find(";base64") > comma) {
+                    err = "image " + std::to_string(src) + ": only base64 data URIs are supported";
+                    return false;
+                }
+                if (!base64_decode(uri.c_str() + comma + 1, uri.size() - comma - 1, ext)) { err = "image " + std::to_string(src) + ": bad base64 data"; return false; }
+            } else {
+                const size_t slash = path.find_last_of("/\\");
+                const std::string file = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + uri_decode(uri);
+                if (!read_file(file, ext)) { err = "image " + std::to_string(src) + ": cannot read " + file; return false; }
+            }
+            enc = ext.data();
+            len = ext.size();
+        }
         Image img;
         std::string perr;
         // like stb_image, go by the file signature, not by the declared mimeType
-        const bool is_jpeg = len >= 3 && g.bin[off] == 0xFF && g.bin[off + 1] == 0xD8 && g.bin[off + 2] == 0xFF;
-        if (!(is_jpeg ? decode_jpeg(g.bin + off, len, img, perr) : decode_png(g.bin + off, len, img, perr))) {
+        const bool is_jpeg = len >= 3 && enc[0] == 0xFF && enc[1] == 0xD8 && enc[2] == 0xFF;
+        if (!(is_jpeg ? decode_jpeg(enc, len, img, perr) : decode_png(enc, len, img, perr))) {
             err = "image " + std::to_string(src) + " (" + im["mimeType"].string_or("?") + "): " + perr;
             return false;
         }

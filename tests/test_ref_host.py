@@ -175,3 +175,35 @@ def test_jpeg_errors(tmp_path, hiplib):
         gltf_io.write_glb(scene, glb, png_override={"baseColorTexture": bad})
         with pytest.raises(M2SError):
             gltf_io.load_glb(glb)
+
+
+def _rewrite_glb_json(path, fn):
+    """Apply fn(doc) to the JSON chunk of a .glb (test helper)."""
+    import json
+    import struct
+    raw = open(path, "rb").read()
+    jlen = struct.unpack_from("<I", raw, 12)[0]
+    doc = json.loads(raw[20:20 + jlen].decode())
+    rest = raw[20 + jlen:]
+    fn(doc)
+    js = json.dumps(doc, separators=(",", ":")).encode()
+    js += b" " * ((4 - len(js) % 4) % 4)
+    out = struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(js) + len(rest)) + struct.pack("<II", len(js), 0x4E4F534A) + js + rest
+    open(path, "wb").write(out)
+
+
+@live
+def test_image_uris_match_reference_live(tmp_path, hiplib):
+    """Images referenced by a base64 data: URI or by a file next to the .glb (tiny_gltf resolves both)."""
+    import base64
+    scene = synth.cube_sphere(2, tex_size=8)
+    png = gltf_io.encode_png(scene.meshes[0].textures["baseColorTexture"])
+    glb = str(tmp_path / "uri.glb")
+    gltf_io.write_glb(scene, glb)
+    (tmp_path / "my tex.png").write_bytes(png)
+
+    def edit(doc):
+        doc["images"][0] = {"uri": "data:image/png;base64," + base64.b64encode(png).decode()}
+        doc["images"][1] = {"uri": "my%20tex.png"}
+    _rewrite_glb_json(glb, edit)
+    assert_scene_equal(refhost.load_scene(glb, str(tmp_path)), gltf_io.load_glb(glb))
