@@ -186,7 +186,9 @@ const char* m2s_io_last_error(void);
  * DOMINATED by such triangles are handed to the multi-pass pipeline instead (decision remembered per scene, R).
  * MULTIPASS forces the count -> scan -> offsets -> emit pipeline (output-range balanced, any triangle size).
  * Both produce bit-identical output. */
-enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1 };
+enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
+       M2S_PIPELINE_WAVE = 2 /* AUTO, but the single-pass kernel in its one-wave-per-batch form (k_fused) */,
+       M2S_PIPELINE_TEAM = 3 /* AUTO, but the single-pass kernel in its producer/consumer form (k_fused2) */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

@@ -53,6 +53,7 @@ struct m2s_ctx {
     uint32_t multipass_R = 0;               // AUTO: R at which this scene is converted by the multi-pass pipeline
     uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
     uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
+    uint32_t team_off_R = 0;                // R at which k_fused2 reported a workgroup that did not fit its LDS stream
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
@@ -118,6 +119,7 @@ static void free_scene(m2s_ctx* c) {
     c->multipass_R = 0;
     c->decided_R = 0;
     c->mp_ready_R = 0;
+    c->team_off_R = 0;
     c->async_ok_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
@@ -371,6 +373,15 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     return M2S_OK;
 }
 
+// Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless the scene is too
+// small to fill the GPU with 64-triangle batches (k_fused then runs 32 / 16 triangles per wave) or a workgroup's
+// fragments did not fit its LDS stream at this R before.
+static bool use_team(const m2s_ctx* c, uint32_t R) {
+    if (c->pipeline == M2S_PIPELINE_WAVE || c->team_off_R == R) return false;
+    if (c->pipeline == M2S_PIPELINE_TEAM) return true;
+    return fused_tpw(c->scene.n_tri) == 64u;
+}
+
 static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     if (c->cap_policy == 0) return 0;
     if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
@@ -472,7 +483,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
     // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).  The exact count
     // costs 0.02-0.06 ms and is taken once per (scene, R); the decision is remembered.
-    if (c->pipeline == M2S_PIPELINE_AUTO && c->decided_R != R) {
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && c->decided_R != R) {
         if (!counted) {
             if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
             launch_count(sc, R, c->d_cnt, c->d_partials, st);
@@ -496,16 +507,26 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
         // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
         // counter and its two status words straight into pinned host memory.
-        c->h_total[0] = 0;
-        c->h_total[1] = 0;
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-        launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
-                     c->d_biglist, c->d_bigmeta, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
-        if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
-        const uint32_t any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[1] >> 32);
+        uint32_t any_big = 0, err = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool team = use_team(c, R);
+            c->h_total[0] = 0;
+            c->h_total[1] = 0;
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
+            (team ? launch_fused2 : launch_fused)(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]),
+                                                  ++c->epoch, c->d_biglist, c->d_bigmeta, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+            if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
+            any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
+            err = (uint32_t)(c->h_total[1] >> 32);
+            if (!(err && team)) break;
+            // a workgroup's fragments did not fit the team kernel's LDS stream (or a wait timed out): the one-wave-per-batch
+            // form has no such limit.  Remember it for this scene and R, forget what the aborted launch listed, try again.
+            c->team_off_R = R;
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
+        }
         done = true;
         // a clean single-kernel conversion: the same scene at the same R can be submitted asynchronously from now on
         c->async_ok_R = (!err && !any_big) ? R : 0;
@@ -637,8 +658,8 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     res[0] = 0; res[1] = 0;
     sl.prof = c->profiling;
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
-    launch_fused(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
-                 c->d_biglist, c->d_bigmeta, st);
+    (use_team(c, R) ? launch_fused2 : launch_fused)(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]),
+                                                 ++c->epoch, c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
@@ -783,7 +804,7 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
 
 m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (!c) return M2S_ERR_INVALID;
-    if (pipeline != M2S_PIPELINE_AUTO && pipeline != M2S_PIPELINE_MULTIPASS) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_TEAM) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
     c->pipeline = pipeline;
     return M2S_OK;
 }

@@ -1,0 +1,412 @@
+// m2s_fused2.hip — single-pass conversion kernel, workgroup-cooperative ("team") form (gfx950).
+//
+// Same work and same output as k_fused (m2s_fused.hip).  There, every WAVE runs alone: triangle phase for its 64
+// triangles, look-back, then strips of 64 of ITS OWN fragments — and the last strip of every wave is partial: on
+// the C3 workload 64 triangles give 9..452 fragments, so only 85 % of the fragment lanes do useful work, and every
+// wave pays its own look-back round trip.  Here the four waves of a workgroup still run the triangle phase
+// independently (one batch of 64 triangles each, aggregates published as early as in k_fused), but their fragments go
+// into ONE entry stream for the workgroup (LDS), in canonical order, and the fragment phase takes strips of 64 from
+// that stream (an LDS atomic hands them out): only the workgroup's last strip is partial (96 % useful lanes), the
+// look-back is needed once per workgroup — record index = workgroup base + stream position — and a wave whose batch
+// was light helps with the fragments of a heavy one.
+//
+// Synchronisation inside the workgroup is LDS-only: per-wave "counted" and "expanded" flags (release stores / acquire
+// loads); a wave waits for the COUNTS of the waves before it (to know where its entries go) and, per strip, for the
+// EXPANSION of the waves whose entries the strip contains.  No __syncthreads.  Every wait is bounded and raises the
+// error flag instead of hanging; so does a workgroup whose fragments do not fit the LDS stream (kEntries) — the host
+// then repeats the conversion with k_fused (m2s_api.cpp, run_pass) and remembers that for the scene and R.
+#include "m2s_fused_common.h"
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+constexpr uint32_t kEntries = 4096;        // entry stream capacity per workgroup (16 KiB)
+constexpr uint32_t kInvalidEntry = 0xFFFFFFFFu;
+constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
+constexpr int kTeam = kBlock / 64;         // waves (= batches) per workgroup
+
+#ifdef M2S_TIMING
+// debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
+//   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup
+constexpr int kF2TimingSlots = 16, kF2TimingBlocks = 8192;
+__device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
+#define F2_T(slot, v) do { if (wave == 0 && lane == 0 && blockIdx.x < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + blockIdx.x] = (v); } while (0)
+#define F2_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define F2_T(slot, v) do {} while (0)
+#define F2_NOW() 0ull
+#endif
+
+struct F2Lds {
+    float4 tri[kTeam][64 * 5];             // TriShade of the four batches
+    uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
+    uint32_t entries[kEntries];            // wave << 30 | lane << 24 | y << 12 | x
+    float4 stage[kTeam][32 * 6];           // half-wave record staging, one per wave
+    unsigned long long base;               // record index of stream position 0
+    unsigned long long total_w[kTeam];     // fragments (all kinds) per batch
+    uint32_t total_c[kTeam];               // entries per batch
+    uint32_t counted[kTeam];               // 1: total_w / total_c of that wave are valid
+    uint32_t expanded[kTeam];              // 1: that wave's TriShade, tskip and entries are in place
+    uint32_t claimed;                      // next strip to hand out
+    uint32_t base_state;                   // 0 unknown, 1 being resolved, 2 known
+    uint32_t irregular;                    // 1: record index != base + stream position somewhere (deferred triangles)
+    uint32_t error;
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// The workgroup's base: sum of the totals of all batches before its first one.  Whoever needs it first resolves it.
+__device__ __forceinline__ bool f2_get_base(F2Lds& S, const unsigned long long* chain, unsigned long long* chain_w, uint32_t b0, int lane,
+                                            uint32_t epoch, uint32_t* status, unsigned long long& base) {
+    uint32_t st = lds_load(&S.base_state);
+    if (st != 2) {
+        uint32_t got = 1;
+        if (lane == 0) {
+            uint32_t expect = 0;
+            got = __hip_atomic_compare_exchange_strong(&S.base_state, &expect, 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0u : 1u;
+        }
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got == 0) {   // this wave resolves
+            const unsigned long long b = b0 == 0 ? 0ull : lookback(chain, b0, lane, epoch, status);
+            if (lane == 0) {
+                S.base = b;
+                // the first batch's inclusive prefix: successors' look-backs stop here
+                chain_store(&chain_w[b0], kFlagPrefix | ((unsigned long long)epoch << kEpochShift) | ((b + S.total_w[0]) & kValMask));
+            }
+            lds_store(&S.base_state, 2u);
+        } else {
+            uint32_t spins = 0;
+            while (lds_load(&S.base_state) != 2) {
+                if (++spins > kWaitLimit) { if (lane == 0) lds_store(&S.error, 1u); return false; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    base = S.base;
+    return true;
+}
+
+__global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+                                                      unsigned long long limit, float4* __restrict__ out,
+                                                      unsigned long long* __restrict__ total_out,
+                                                      uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
+                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta) {
+    __shared__ F2Lds S;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
+    const uint32_t b0 = blockIdx.x * kTeam;            // the workgroup's first batch
+    if (b0 >= n_batches) return;
+    const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
+    const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
+    const bool has_batch = wave < nb_here;
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    const unsigned long long tk0 = F2_NOW();
+    unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0;
+
+    // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
+    // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed
+    if (lane == 0) {
+        S.counted[wave] = 0;
+        S.expanded[wave] = 0;
+    }
+    // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
+    // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
+    if (wave == 0 && lane == 0) { S.claimed = 0; S.base_state = b0 == 0 ? 2u : 0u; S.irregular = 0; S.error = 0; S.base = 0; }
+    __syncthreads();
+
+    // ======================= triangle phase: one batch per wave (as in k_fused) =======================
+    const uint32_t t0 = b * 64u, t = t0 + lane;
+    const bool valid = has_batch && t < sc.n_tri;
+    float p[9];
+    Geo g;
+    Raster rs;
+    rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
+    bool ok = false;
+    uint32_t m = 0;
+    float4 uvb0 = make_float4(0, 0, 0, 0);
+    float2 uvb1 = make_float2(0, 0);
+    if (has_batch) {
+        const uint32_t lastT = min(t0 + 64u, sc.n_tri) - 1;
+        const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
+        const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+        m = m0;
+        if (valid) {
+            load_positions(sc.tri, t, p);
+            uvb0 = sc.tri.B0[t];
+            uvb1 = sc.tri.B1[t];
+            if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
+            geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+            ok = raster_setup(g, R, rs);
+        }
+    }
+    const int w = rs.x1 - rs.x0 + 1, rows = rs.y1 - rs.y0 + 1;
+    int kind = kNone;
+    unsigned long long mask = 0;
+    uint32_t cnt = 0;
+    if (ok) {
+        if (w <= 8 && rows <= 8 && rs.ext <= 2304) {
+            kind = kSmall;
+            const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+            int e0 = (int)((long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0]) + ((rs.bias >> 0) & 1) - 1;
+            int e1 = (int)((long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1]) + ((rs.bias >> 1) & 1) - 1;
+            int e2 = (int)((long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2]) + ((rs.bias >> 2) & 1) - 1;
+            const int ax0 = rs.a[0] * 256, ax1 = rs.a[1] * 256, ax2 = rs.a[2] * 256;
+            const int by0 = rs.b[0] * 256, by1 = rs.b[1] * 256, by2 = rs.b[2] * 256;
+            for (int dy = 0; dy < rows; ++dy) {
+                int r0 = e0, r1 = e1, r2 = e2;
+                for (int dx = 0; dx < w; ++dx) {
+                    if ((r0 | r1 | r2) >= 0) mask |= 1ull << (dy * 8 + dx);
+                    r0 += ax0; r1 += ax1; r2 += ax2;
+                }
+                e0 += by0; e1 += by1; e2 += by2;
+            }
+            cnt = (uint32_t)__popcll(mask);
+        } else if (rows <= kRowsCount) {
+            kind = rows <= kFusedRows ? kMedium : kBig;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
+            for (int y = rs.y0; y <= rs.y1; ++y) {
+                int xa, xb;
+                row_walker_next(rw, xa, xb);
+                cnt += (uint32_t)max(xb - xa + 1, 0);
+            }
+            if (cnt > kBigCount) kind = kBig;
+        } else {
+            kind = kBig;
+        }
+    }
+    {
+        unsigned long long bigm = __ballot(kind == kBig && rows > kRowsCount);
+        while (bigm) {
+            const int src = __ffsll((long long)bigm) - 1;
+            bigm &= bigm - 1;
+            const Raster br = shfl_raster(rs, src);
+            uint32_t part = 0;
+            for (int y = br.y0 + lane; y <= br.y1; y += 64) {
+                int xa, xb;
+                row_span(br, y, xa, xb);
+                part += (uint32_t)max(xb - xa + 1, 0);
+            }
+            part = wave_sum(part);
+            if (lane == src) cnt = part;
+        }
+    }
+    if (cnt == 0) kind = kNone;
+    const uint32_t cntc = (kind == kSmall || kind == kMedium) ? cnt : 0;
+    const bool anybig = __ballot(kind == kBig) != 0ull;
+
+    const unsigned long long incl = wave_incl_scan64(cnt, lane);
+    const uint32_t inclc = wave_incl_scan(cntc, lane);
+    const uint32_t tw_lo = __builtin_amdgcn_readlane((uint32_t)incl, 63), tw_hi = __builtin_amdgcn_readlane((uint32_t)(incl >> 32), 63);
+    const unsigned long long total_w = ((unsigned long long)tw_hi << 32) | tw_lo;
+    const uint32_t total_c = __builtin_amdgcn_readlane(inclc, 63);
+    const unsigned long long toff = incl - cnt;
+    const uint32_t ctoff = inclc - cntc;
+
+    // publish: the chain word of this batch (global batch 0 knows its prefix) and the counts for the team
+    if (has_batch && lane == 0) chain_store(&chain[b], (b == 0 ? kFlagPrefix : kFlagAgg) | etag | (total_w & kValMask));
+    if (lane == 0) { S.total_w[wave] = total_w; S.total_c[wave] = total_c; }
+    lds_store(&S.counted[wave], 1u);
+
+    // ======================= where do my entries go?  counts of the waves before me =======================
+    uint32_t stream0 = 0;              // stream position of my first entry
+    unsigned long long out0 = 0;       // fragments (all kinds) of the batches before mine in this workgroup
+    bool alive = true;
+    {
+        const unsigned long long tw0 = F2_NOW();
+        for (uint32_t k = 0; k < wave && alive; ++k) {
+            uint32_t spins = 0;
+            while (lds_load(&S.counted[k]) == 0) {
+                if (++spins > kWaitLimit) { alive = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            stream0 += S.total_c[k];
+            out0 += S.total_w[k];
+        }
+        tk_cnt = F2_NOW() - tw0;
+    }
+    if (alive && (unsigned long long)stream0 + total_c > kEntries) alive = false;   // does not fit the LDS stream
+    if (!alive && lane == 0) lds_store(&S.error, 1u);
+
+    // ======================= my TriShade, tskip and entries =======================
+    if (alive) {
+        if (cntc) {
+            TriShade ts;
+            tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
+            ts.mesh |= m;
+            const float4* src = reinterpret_cast<const float4*>(&ts);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) S.tri[wave][lane * 5 + k] = src[k];
+            S.tskip[wave][lane] = (uint32_t)((out0 + toff) - ((unsigned long long)stream0 + ctoff));
+        }
+        if (anybig) {   // deferred triangles: reserve their slice of the output, list them for k_emit_big
+            unsigned long long base;
+            if (f2_get_base(S, chain, chain, b0, lane, epoch, status, base)) {
+                if (kind == kBig) {
+                    const uint32_t slot = atomicAdd(&bigmeta[0], 1u);
+                    atomicMax(&bigmeta[1], cnt);
+                    atomicAdd(&bigmeta[2], cnt);
+                    BigItem it;
+                    it.t = t; it.cnt = cnt; it.off = base + out0 + toff;
+                    biglist[slot] = it;
+                }
+                if (lane == 0) {
+                    lds_store(&S.irregular, 1u);
+                    __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else alive = false;
+        }
+        const uint32_t tag = (wave << 30) | ((uint32_t)lane << 24);
+        if (kind == kSmall) {
+            const uint32_t org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;
+            unsigned long long mm = mask;
+            uint32_t ci = stream0 + ctoff;
+            while (mm) {
+                const int bit = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                S.entries[ci++] = tag + org + (((uint32_t)(bit >> 3) << 12) | (uint32_t)(bit & 7));
+            }
+        } else if (kind == kMedium) {
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
+            uint32_t ci = stream0 + ctoff;
+            for (int y = rs.y0; y <= rs.y1; ++y) {
+                int xa, xb;
+                row_walker_next(rw, xa, xb);
+                for (int x = xa; x <= xb; ++x) S.entries[ci++] = tag | ((uint32_t)y << 12) | (uint32_t)x;
+            }
+        }
+    }
+    lds_store(&S.expanded[wave], 1u);   // release: TriShade, tskip, entries (set even on error so that nobody waits for it)
+
+    // ======================= fragment phase: strips of the workgroup's stream =======================
+    // the stream's length needs every wave's count
+    uint32_t stream_total = 0;
+    unsigned long long out_total = 0;
+    uint32_t cum[kTeam + 1];
+    cum[0] = 0;
+    {
+        const unsigned long long tw0 = F2_NOW();
+        for (uint32_t k = 0; k < (uint32_t)kTeam; ++k) {
+            uint32_t spins = 0;
+            while (lds_load(&S.counted[k]) == 0) {
+                if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&S.error, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            stream_total += S.total_c[k];
+            out_total += S.total_w[k];
+            cum[k + 1] = stream_total;
+        }
+        tk_cnt += F2_NOW() - tw0;
+    }
+    float4* stage = S.stage[wave];
+    unsigned long long base = 0;
+    bool have_base = false;
+    while (alive && lds_load(&S.error) == 0) {
+        uint32_t s = 0;
+        if (lane == 0) s = __hip_atomic_fetch_add(&S.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s = __builtin_amdgcn_readfirstlane(s);
+        const uint32_t pos0 = s * 64u;
+        if (pos0 >= stream_total) break;
+        const uint32_t n = min(64u, stream_total - pos0);
+        {   // the waves whose entries this strip contains must have expanded them
+            const unsigned long long tw0 = F2_NOW();
+            for (uint32_t k = 0; k < (uint32_t)kTeam && alive; ++k) {
+                if (cum[k + 1] <= pos0 || cum[k] >= pos0 + n) continue;
+                uint32_t spins = 0;
+                while (lds_load(&S.expanded[k]) == 0) {
+                    if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&S.error, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            tk_ent += F2_NOW() - tw0;
+        }
+        if (!alive || lds_load(&S.error)) break;
+        ++n_strips;
+        uint32_t en = kInvalidEntry;
+        if ((uint32_t)lane < n) en = S.entries[pos0 + lane];
+        const bool have = en != kInvalidEntry;
+        const uint32_t ow = en >> 30, tl = (en >> 24) & 63u;
+        float4 rec[6];
+        uint32_t skip = 0;
+        if (have) {
+            const TriShade& ts = *reinterpret_cast<const TriShade*>(&S.tri[ow][tl * 5]);
+            const uint32_t tt = (b0 + ow) * 64u + tl;
+            skip = S.tskip[ow][tl];
+            // one mesh per scene is the common case: wave-uniform descriptor pointer in the constant address space
+            if (sc.n_meshes == 1) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes), ts, rec);
+            else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + (ts.mesh & 0xFFFFFFu), ts, rec);
+        }
+        if (!have_base) {
+            const unsigned long long tb0 = F2_NOW();
+            if (!f2_get_base(S, chain, chain, b0, lane, epoch, status, base)) break;
+            have_base = true;
+            tk_base += F2_NOW() - tb0;
+        }
+        if (lds_load(&S.irregular) == 0) {
+            const unsigned long long o0 = base + pos0;
+            uint32_t nvalid = n;
+            if (o0 + 64ull > limit) {
+                if (o0 >= limit) nvalid = 0;
+                else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
+            }
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                if (have && (lane >> 5) == half) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) stage[(lane & 31) * 6 + k] = rec[k];
+                }
+                wave_lds_sync();
+                float4* __restrict__ dsto = out + (o0 + 32u * half) * 6;
+                const uint32_t nv = nvalid > 32u * half ? min(32u, nvalid - 32u * half) : 0u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t q = (uint32_t)lane + 64u * j;
+                    const uint32_t r = q / 6u;
+                    if (r < nv) nt_store(&dsto[q], stage[q]);
+                }
+                wave_lds_sync();
+            }
+        } else if (have) {
+            const unsigned long long oidx = base + skip + pos0 + lane;
+            if (oidx < limit) {
+                float4* __restrict__ dsto = out + oidx * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nt_store(&dsto[k], rec[k]);
+            }
+        }
+    }
+    // ======================= epilogue: the workgroup's inclusive prefix / the counter =======================
+    // (by the wave of the last batch; the base is resolved here if no strip needed it, e.g. a workgroup without fragments)
+    if (alive && wave == nb_here - 1 && lds_load(&S.error) == 0) {
+        if (!have_base) have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+        if (have_base && lane == 0) {
+            chain_store(&chain[b0 + nb_here - 1], kFlagPrefix | etag | ((base + out_total) & kValMask));
+            if (b0 + nb_here == n_batches) *total_out = base + out_total;
+        }
+    }
+    if (lds_load(&S.error) && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    F2_T(0, F2_NOW() - tk0); F2_T(1, tk_cnt); F2_T(2, tk_ent); F2_T(3, tk_base); F2_T(4, n_strips); F2_T(5, (unsigned long long)stream_total);
+}
+
+void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
+                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
+    const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
+    if (!n_batches) return;
+    const uint32_t nb = (n_batches + kTeam - 1) / kTeam;
+    hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
+                       epoch & 0xFFFFu, biglist, bigmeta);
+}
+
+#ifdef M2S_TIMING
+extern "C" int m2s_debug_read_timing2(unsigned long long* dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_f2_timing), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+}  // namespace m2s
