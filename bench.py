@@ -342,6 +342,7 @@ def main():
 
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
+        kname = {"team": "k_fused2", "wave": "k_fused"}.get(conv.last_pipeline, "k_emit")
         emit_ms = kms[dom] / max(n_prof[0], 1)
         # algorithmic bytes of one emit launch: 96 B per Gaussian written + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
@@ -365,7 +366,7 @@ def main():
             "kernel_ms": {k: v / max(n_prof[0], 1) for k, v in kms.items()},
             "kernel_timing": f"HIP events on the launch stream around every {PROF_EVERY}th launch of the timed region ({n_prof[0]} launches)",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_" + dom,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                          "algorithmic_bytes": b_alg, "measured_copy_peak": copy_gbs,
                          "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "write_only_frac": (96.0 * total / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
@@ -376,7 +377,7 @@ def main():
                 with open(tr) as f:
                     t = json.load(f)
                 if t.get("workload") == a.workload:
-                    res["roofline"]["traffic"] = t.get("k_" + dom + "_hbm_bytes_per_launch")
+                    res["roofline"]["traffic"] = t.get(kname + "_hbm_bytes_per_launch")
             except Exception:
                 pass
         if gather:

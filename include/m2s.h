@@ -190,6 +190,8 @@ enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
        M2S_PIPELINE_WAVE = 2 /* AUTO, but the single-pass kernel in its one-wave-per-batch form (k_fused) */,
        M2S_PIPELINE_TEAM = 3 /* AUTO, but the single-pass kernel in its producer/consumer form (k_fused2) */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
+/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused) or _TEAM (k_fused2); 0 before any. */
+int m2s_last_pipeline(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_FUSED = 4, M2S_K_N = 5 };

@@ -162,6 +162,11 @@ class Converter:
         single-pass kernel pinned to one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, producer/consumer)."""
         self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1, "wave": 2, "team": 3}[name]))
 
+    @property
+    def last_pipeline(self) -> str:
+        """What the last conversion ran: 'multipass', 'wave' (k_fused) or 'team' (k_fused2)."""
+        return {0: "none", 1: "multipass", 2: "wave", 3: "team"}[self._L.m2s_last_pipeline(self._h)]
+
     # -- measurement --------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._check(self._L.m2s_set_profiling(self._h, 1 if on else 0))

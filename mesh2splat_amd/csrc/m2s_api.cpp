@@ -53,6 +53,7 @@ struct m2s_ctx {
     uint32_t multipass_R = 0;               // AUTO: R at which this scene is converted by the multi-pass pipeline
     uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
     uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
+    int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     uint32_t team_off_R = 0;                // R at which k_fused2 reported a workgroup that did not fit its LDS stream
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
@@ -521,6 +522,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
+            c->last_pipeline = team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
             if (!(err && team)) break;
             // a workgroup's fragments did not fit the team kernel's LDS stream (or a wait timed out): the one-wave-per-batch
             // form has no such limit.  Remember it for this scene and R, forget what the aborted launch listed, try again.
@@ -564,6 +566,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
         if (s != M2S_OK) return s;
         c->mp_ready_R = R;
+        c->last_pipeline = M2S_PIPELINE_MULTIPASS;
     }
     const uint64_t total = c->h_total[0];
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
@@ -627,6 +630,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(&res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipEventRecord(sl.done, st));
+            c->last_pipeline = M2S_PIPELINE_MULTIPASS;
             sl.prof = false;
             sl.sync_result = false;
             sl.limit = limit;
@@ -658,6 +662,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     res[0] = 0; res[1] = 0;
     sl.prof = c->profiling;
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
+    c->last_pipeline = use_team(c, R) ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
     (use_team(c, R) ? launch_fused2 : launch_fused)(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]),
                                                  ++c->epoch, c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
@@ -808,6 +813,8 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     c->pipeline = pipeline;
     return M2S_OK;
 }
+
+int m2s_last_pipeline(const m2s_ctx* c) { return c ? c->last_pipeline : 0; }
 
 m2s_status m2s_last_kernel_ms(const m2s_ctx* c, float out_ms[M2S_K_N]) {
     if (!c || !out_ms) return M2S_ERR_INVALID;

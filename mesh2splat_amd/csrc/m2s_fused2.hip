@@ -334,13 +334,18 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, u
         const uint32_t ow = en >> 30, tl = (en >> 24) & 63u;
         float4 rec[6];
         uint32_t skip = 0;
+        // do all fragments of the strip belong to one mesh?
+        uint32_t my_mesh = 0;
+        if (have) my_mesh = reinterpret_cast<const uint32_t*>(&S.tri[ow][tl * 5 + 4])[3] & 0xFFFFFFu;
+        const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
+        const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
         if (have) {
             const TriShade& ts = *reinterpret_cast<const TriShade*>(&S.tri[ow][tl * 5]);
             const uint32_t tt = (b0 + ow) * 64u + tl;
             skip = S.tskip[ow][tl];
-            // one mesh per scene is the common case: wave-uniform descriptor pointer in the constant address space
-            if (sc.n_meshes == 1) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes), ts, rec);
-            else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + (ts.mesh & 0xFFFFFFu), ts, rec);
+            // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
+            if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
+            else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
         }
         if (!have_base) {
             const unsigned long long tb0 = F2_NOW();

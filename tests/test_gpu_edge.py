@@ -126,3 +126,44 @@ def test_convert_into_user_buffer_and_capacity(hiplib, oracle):
     assert_records_match(h[: total // 2], orec[: total // 2], "capacity")
     assert np.all(h[total // 2:] == -1.0)              # nothing written past the capacity
     c.close()
+
+
+def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, oracle):
+    """k_fused2 keeps a workgroup's fragments in a 4096-entry LDS stream.  A scene whose AVERAGE is small (AUTO picks the
+    single-pass kernel) but that has a cluster of 256 consecutive triangles with ~80 fragments each overflows it: the
+    host must repeat the conversion with k_fused, return the right answer and remember the decision."""
+    import numpy as np
+    from mesh2splat_amd import synth
+    from mesh2splat_amd.converter import Converter
+    from mesh2splat_amd.scene import Mesh, Scene
+    from parity import assert_records_match
+    base = synth.cube_sphere(130, tex_size=64)              # 202 800 small triangles: fills the GPU with 64-triangle batches
+    v = base.meshes[0].vertices.copy().reshape(-1, 3, base.meshes[0].vertices.shape[1])
+    # blow up 256 consecutive triangles (4 batches = one workgroup) around their centroids
+    sel = slice(64 * 400, 64 * 404)
+    cen = v[sel, :, 0:3].mean(axis=1, keepdims=True)
+    v[sel, :, 0:3] = cen + (v[sel, :, 0:3] - cen) * 4.0
+    m = base.meshes[0]
+    scene = Scene([Mesh(name=m.name, vertices=v.reshape(-1, v.shape[2]), base_color=m.base_color, textures=m.textures)])
+    R = 512
+    ototal, orec, _ = oracle.convert(scene, R, cap=0)
+    assert ototal < 11 * scene.n_triangles                   # AUTO -> single pass
+    cnt = oracle.count_per_triangle(scene, R)
+    assert cnt[sel].sum() > 4096                              # ... but this workgroup does not fit
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    for _ in range(2):
+        assert c.convert(R) == ototal
+        assert c.last_pipeline == "wave"                      # the team form gave up, the wave form answered
+    assert_records_match(c.download(), orec, "fallback to k_fused")
+    # an ordinary scene runs the team form, several meshes included
+    grid = synth.colocated_spheres(3, 150, 64)
+    c.upload_scene(grid)
+    c.set_max_gaussians(0)
+    total = c.convert(512)
+    assert c.last_pipeline == "team"
+    ototal, orec, _ = oracle.convert(grid, 512, cap=0)
+    assert total == ototal
+    assert_records_match(c.download(), orec, "team form, three meshes")
+    c.close()
