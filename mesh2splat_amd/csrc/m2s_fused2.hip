@@ -25,13 +25,17 @@ constexpr uint32_t kEntries = 4096;        // entry stream capacity per workgrou
 constexpr uint32_t kInvalidEntry = 0xFFFFFFFFu;
 constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
 constexpr int kTeam = kBlock / 64;         // waves (= batches) per workgroup
+#ifndef M2S_XCD_RUN2
+#define M2S_XCD_RUN2 1
+#endif
+constexpr uint32_t kXcdRun2 = M2S_XCD_RUN2;
 
 #ifdef M2S_TIMING
 // debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
 //   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup
 constexpr int kF2TimingSlots = 16, kF2TimingBlocks = 8192;
 __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
-#define F2_T(slot, v) do { if (wave == 0 && lane == 0 && blockIdx.x < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + blockIdx.x] = (v); } while (0)
+#define F2_T(slot, v) do { if (wave == 0 && lane == 0 && lb < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + lb] = (v); } while (0)
 #define F2_NOW() __builtin_amdgcn_s_memtime()
 #else
 #define F2_T(slot, v) do {} while (0)
@@ -97,7 +101,11 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, u
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
-    const uint32_t b0 = blockIdx.x * kTeam;            // the workgroup's first batch
+    // hardware workgroup h runs on XCD h % 8 (private L2 each); runs of kXcdRun2 consecutive LOGICAL workgroups
+    // (= consecutive triangles = neighbouring texture regions) go to one XCD (1 = plain round-robin)
+    const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
+    const uint32_t lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
+    const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
     if (b0 >= n_batches) return;
     const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
     const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
@@ -307,6 +315,15 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, u
     float4* stage = S.stage[wave];
     unsigned long long base = 0;
     bool have_base = false;
+    // The look-back (one round trip through memory shared by all XCDs, ~5 k cycles) is taken by ONE wave, now, while
+    // the other three are already shading: by the time they reach their first store the base is there.  The strips
+    // are handed out dynamically, so the resolving wave simply takes fewer of them.
+    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&S.error) == 0) {
+        const unsigned long long tb0 = F2_NOW();
+        have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+        if (!have_base) alive = false;
+        tk_base += F2_NOW() - tb0;
+    }
     while (alive && lds_load(&S.error) == 0) {
         uint32_t s = 0;
         if (lane == 0) s = __hip_atomic_fetch_add(&S.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -403,7 +420,8 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
     const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
     if (!n_batches) return;
-    const uint32_t nb = (n_batches + kTeam - 1) / kTeam;
+    uint32_t nb = (n_batches + kTeam - 1) / kTeam;
+    nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta);
 }
