@@ -21,10 +21,16 @@
 
 namespace m2s {
 
-constexpr uint32_t kEntries = 4096;        // entry stream capacity per workgroup (16 KiB)
+// Four waves = one per SIMD.  (Six, -DM2S_TEAM_WAVES=6: 98 % strip fill and two workgroups per CU by LDS, but the six
+// waves of a workgroup land 2/2/1/1 on the four SIMDs and the kernel takes 0.197 ms instead of 0.135.)
+#ifndef M2S_TEAM_WAVES
+#define M2S_TEAM_WAVES 4
+#endif
+constexpr int kTeam = M2S_TEAM_WAVES;      // waves (= batches of 64 triangles) per workgroup
+constexpr int kTeamThreads = kTeam * 64;
+constexpr uint32_t kEntries = 1024u * kTeam;   // entry stream capacity per workgroup (4 B each)
 constexpr uint32_t kInvalidEntry = 0xFFFFFFFFu;
 constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
-constexpr int kTeam = kBlock / 64;         // waves (= batches) per workgroup
 #ifndef M2S_XCD_RUN2
 #define M2S_XCD_RUN2 1
 #endif
@@ -45,7 +51,7 @@ __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
-    uint32_t entries[kEntries];            // wave << 30 | lane << 24 | y << 12 | x
+    uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
     float4 stage[kTeam][32 * 6];           // half-wave record staging, one per wave
     unsigned long long base;               // record index of stream position 0
     unsigned long long total_w[kTeam];     // fragments (all kinds) per batch
@@ -92,7 +98,7 @@ __device__ __forceinline__ bool f2_get_base(F2Lds& S, const unsigned long long* 
     return true;
 }
 
-__global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+__global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                       unsigned long long limit, float4* __restrict__ out,
                                                       unsigned long long* __restrict__ total_out,
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
@@ -269,7 +275,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, u
                 }
             } else alive = false;
         }
-        const uint32_t tag = (wave << 30) | ((uint32_t)lane << 24);
+        const uint32_t tag = (uint32_t)lane << 24;
         if (kind == kSmall) {
             const uint32_t org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;
             unsigned long long mm = mask;
@@ -348,7 +354,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_fused2(SceneDev sc, uint32_t R, u
         uint32_t en = kInvalidEntry;
         if ((uint32_t)lane < n) en = S.entries[pos0 + lane];
         const bool have = en != kInvalidEntry;
-        const uint32_t ow = en >> 30, tl = (en >> 24) & 63u;
+        uint32_t ow = 0;                                   // owner wave of my entry: cum[ow] <= pos < cum[ow + 1]
+#pragma unroll
+        for (int k = 1; k < kTeam; ++k) ow += (pos0 + (uint32_t)lane >= cum[k]) ? 1u : 0u;
+        const uint32_t tl = (en >> 24) & 63u;
         float4 rec[6];
         uint32_t skip = 0;
         // do all fragments of the strip belong to one mesh?
@@ -422,7 +431,7 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
-    hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kBlock), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
+    hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta);
 }
 
