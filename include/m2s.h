@@ -187,8 +187,9 @@ const char* m2s_io_last_error(void);
  * MULTIPASS forces the count -> scan -> offsets -> emit pipeline (output-range balanced, any triangle size).
  * Both produce bit-identical output. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
-       M2S_PIPELINE_WAVE = 2 /* AUTO, but the single-pass kernel in its one-wave-per-batch form (k_fused) */,
-       M2S_PIPELINE_TEAM = 3 /* AUTO, but the single-pass kernel in its producer/consumer form (k_fused2) */ };
+       M2S_PIPELINE_WAVE = 2 /* always the single-pass kernel, one-wave-per-batch form (k_fused); multi-pass only if it hands off */,
+       M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2), k_fused where a workgroup
+                                does not fit its LDS stream */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
 /* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused) or _TEAM (k_fused2); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);

@@ -158,8 +158,8 @@ class Converter:
         return float(self._L.m2s_last_sort_ms(self._h))
 
     def set_pipeline(self, name: str):
-        """'auto' (single-pass kernel or multi-pass pipeline, chosen per scene and R), 'multipass', or AUTO with the
-        single-pass kernel pinned to one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, producer/consumer)."""
+        """'auto' (single-pass kernel or multi-pass pipeline, chosen per scene and R), 'multipass', or the single-pass
+        kernel forced, in one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, workgroup-cooperative)."""
         self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1, "wave": 2, "team": 3}[name]))
 
     @property

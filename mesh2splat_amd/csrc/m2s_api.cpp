@@ -484,7 +484,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
     // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).  The exact count
     // costs 0.02-0.06 ms and is taken once per (scene, R); the decision is remembered.
-    if (c->pipeline != M2S_PIPELINE_MULTIPASS && c->decided_R != R) {
+    if (c->pipeline == M2S_PIPELINE_AUTO && c->decided_R != R) {
         if (!counted) {
             if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
             launch_count(sc, R, c->d_cnt, c->d_partials, st);

@@ -45,7 +45,7 @@ def test_nonfinite_and_out_of_range_geometry(hiplib, oracle):
     v[6:9, 0:3] *= 1e6          # far outside the bbox -> guard band
     v[9:12, 0:3] += 3.0         # outside the bbox but inside the guard band: clipped to the viewport
     scene = Scene([Mesh("m", v, bbox_min=np.float32([-1, -1, -1]), bbox_max=np.float32([1, 1, 1]))])
-    for pipe in ("auto", "multipass"):
+    for pipe in ("auto", "multipass", "wave", "team"):
         assert both(oracle, scene, 64, pipeline=pipe) > 0
 
 
@@ -73,7 +73,7 @@ def test_many_small_meshes_straddling_waves(hiplib, oracle):
         m.base_color = (0.2 + 0.02 * k, 0.5, 1.0 - 0.02 * k, 1.0)
         meshes.append(m)
     scene = Scene(meshes)
-    for pipe in ("auto", "multipass"):
+    for pipe in ("auto", "multipass", "wave", "team"):
         both(oracle, scene, 200, pipeline=pipe)
 
 
