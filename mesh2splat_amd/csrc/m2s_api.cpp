@@ -810,6 +810,10 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
 m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (!c) return M2S_ERR_INVALID;
     if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_TEAM) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
+        c->decided_R = 0; c->multipass_R = 0; c->team_off_R = 0; c->async_ok_R = 0; c->mp_ready_R = 0;
+    }
     c->pipeline = pipeline;
     return M2S_OK;
 }
