@@ -379,8 +379,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
 // fragments did not fit its LDS stream at this R before.
 static bool use_team(const m2s_ctx* c, uint32_t R) {
     if (c->pipeline == M2S_PIPELINE_WAVE || c->team_off_R == R) return false;
-    if (c->pipeline == M2S_PIPELINE_TEAM) return true;
-    return fused_tpw(c->scene.n_tri) == 64u;
+    return true;
 }
 
 static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {

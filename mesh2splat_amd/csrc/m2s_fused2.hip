@@ -102,11 +102,12 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
                                                       unsigned long long limit, float4* __restrict__ out,
                                                       unsigned long long* __restrict__ total_out,
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta) {
+                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
+                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */) {
     __shared__ F2Lds S;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
+    const uint32_t n_batches = (sc.n_tri + tpw - 1u) / tpw;
     // hardware workgroup h runs on XCD h % 8 (private L2 each); runs of kXcdRun2 consecutive LOGICAL workgroups
     // (= consecutive triangles = neighbouring texture regions) go to one XCD (1 = plain round-robin)
     const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
@@ -132,8 +133,8 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     __syncthreads();
 
     // ======================= triangle phase: one batch per wave (as in k_fused) =======================
-    const uint32_t t0 = b * 64u, t = t0 + lane;
-    const bool valid = has_batch && t < sc.n_tri;
+    const uint32_t t0 = b * tpw, t = t0 + lane;
+    const bool valid = has_batch && (uint32_t)lane < tpw && t < sc.n_tri;
     float p[9];
     Geo g;
     Raster rs;
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     float4 uvb0 = make_float4(0, 0, 0, 0);
     float2 uvb1 = make_float2(0, 0);
     if (has_batch) {
-        const uint32_t lastT = min(t0 + 64u, sc.n_tri) - 1;
+        const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
         const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
         const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
         m = m0;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
         const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
         if (have) {
             const TriShade& ts = *reinterpret_cast<const TriShade*>(&S.tri[ow][tl * 5]);
-            const uint32_t tt = (b0 + ow) * 64u + tl;
+            const uint32_t tt = (b0 + ow) * tpw + tl;
             skip = S.tskip[ow][tl];
             // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
             if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
@@ -427,12 +428,13 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
-    const uint32_t n_batches = (sc.n_tri + 63u) / 64u;
+    const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
+    const uint32_t n_batches = n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta);
+                       epoch & 0xFFFFu, biglist, bigmeta, tpw);
 }
 
 #ifdef M2S_TIMING
