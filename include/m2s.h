@@ -180,12 +180,15 @@ void m2s_free_records(m2s_gaussian* records);
 const char* m2s_io_last_error(void);
 
 /* ---- pipeline selection ------------------------------------------------------------------------ */
-/* AUTO (default): the single-pass fused kernel (k_fused) emits every triangle that fits its in-workgroup
- * budget (<= 16 pixel rows and <= 96 fragments); larger triangles only reserve their slice of the ordered
- * output there and are emitted by a second kernel (k_emit_big, one workgroup per 1024-fragment chunk); scenes
- * DOMINATED by such triangles are handed to the multi-pass pipeline instead (decision remembered per scene, R).
- * MULTIPASS forces the count -> scan -> offsets -> emit pipeline (output-range balanced, any triangle size).
- * Both produce bit-identical output. */
+/* AUTO (default) decides once per (scene, R), from an exact fragment count taken at the first conversion:
+ *   - fewer than 11 fragments per triangle on average: the SINGLE-PASS kernel (k_fused2; k_fused where a workgroup's
+ *     fragments do not fit k_fused2's LDS stream).  It emits every triangle of <= 16 pixel rows and <= 96 fragments
+ *     itself; larger triangles only reserve their slice of the ordered output there and are emitted by a second
+ *     kernel (k_emit_big, one workgroup per 1024-fragment chunk); a scene DOMINATED by such triangles falls through
+ *     to the multi-pass pipeline;
+ *   - otherwise the MULTI-PASS pipeline count -> scan -> offsets -> emit (output-range balanced, any triangle size).
+ * MULTIPASS forces the latter, WAVE / TEAM force the single-pass kernel in one of its two forms.  Every setting produces
+ * bit-identical output.  Changing the setting forgets the remembered decisions. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
        M2S_PIPELINE_WAVE = 2 /* always the single-pass kernel, one-wave-per-batch form (k_fused); multi-pass only if it hands off */,
        M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2), k_fused where a workgroup

@@ -1,29 +1,30 @@
-// m2s_fused.hip — single-pass conversion kernel (gfx950).
+// m2s_fused.hip — single-pass conversion kernel, one-wave-per-batch form (gfx950).  (m2s_fused2.hip is the
+// workgroup-cooperative form of the same kernel and the default; this one has no per-workgroup capacity limit and
+// takes over when a workgroup's fragments do not fit there.)
 //
 // One launch does what the reference's VS+GS+rasteriser+FS draw does (converterGS.glsl:326-443,
-// converterFS.glsl:44-104, ConversionPass.cpp:114-116) for triangles whose fragments fit the
-// in-workgroup budget:
+// converterFS.glsl:44-104, ConversionPass.cpp:114-116) for triangles whose fragments fit the in-wave budget.
+// Every WAVE owns 64 (32 / 16 for small scenes) consecutive triangles from load to store:
 //
-//   triangle phase  (1 thread / triangle, 256 triangles / workgroup)
+//   triangle phase  (1 lane / triangle)
 //       coalesced 36 B position load -> GS setup -> exact coverage:
 //         * bbox <= 8x8 px : 64-bit coverage mask from incremental int32 edge functions
-//         * <= 16 rows, <= 96 fragments : closed-form row spans
-//         * larger         : counted wave-cooperatively, emission deferred ("big" triangles)
+//         * <= 16 rows, <= 96 fragments : row spans from the division-free row walker
+//         * larger         : counted (row walker up to 128 rows, else wave-cooperatively), emission deferred
 //       per-triangle fragment constants (edge functions, 1/area, Scale, Quaternion, LODs) -> LDS
-//   ordering        workgroup scan of the counts + decoupled look-back over a chain of 64-bit
-//                   {flag,value} words: the workgroup learns the index of its first record in the
-//                   global, canonically ordered output WITHOUT a second pass and without atomics
-//                   on a shared cursor (the reference: one atomicCounterIncrement per fragment,
-//                   converterFS.glsl:46).
-//   fragment phase  (1 thread / Gaussian) expansion masks/spans -> LDS entry list, shading from the
-//                   LDS triangle record, records staged per wave in LDS and written as contiguous
-//                   6 KiB runs with 16 B/lane stores.
+//   ordering        wave scan of the counts + decoupled look-back over a chain of 64-bit {flag, epoch, value}
+//                   words: the wave learns the index of its first record in the global, canonically ordered
+//                   output WITHOUT a second pass and without atomics on a shared cursor (the reference: one
+//                   atomicCounterIncrement per fragment, converterFS.glsl:46).
+//   fragment phase  (1 lane / Gaussian) masks/spans -> LDS entry list, shading from the LDS triangle record,
+//                   records staged half a wave at a time in LDS and written as contiguous 3 KiB runs with
+//                   16 B/lane non-temporal stores.
 //
-// Inter-workgroup protocol (MI355X_MICROARCH.md "R2 granule"): each chain word is written by ONE
-// relaxed agent-scope 8-byte atomic store and read by relaxed agent-scope 8-byte atomic loads; the
-// word carries both the flag and the payload, so no fence is needed.  Workgroup b only ever waits for
-// workgroups < b (hardware dispatches a grid in increasing workgroup order per XCD); every spin is
-// bounded and sets an error flag instead of hanging.
+// Inter-wave protocol (MI355X_MICROARCH.md "R2 granule"): each chain word is written by ONE relaxed agent-scope
+// 8-byte atomic store and read by relaxed agent-scope 8-byte atomic loads; the word carries both the flag and the
+// payload, so no fence is needed.  A wave only ever waits for waves of workgroups dispatched before its own
+// (hardware dispatches a grid in increasing workgroup order); every spin is bounded and sets an error flag instead
+// of hanging.
 #include "m2s_fused_common.h"
 
 #pragma clang fp contract(off)
