@@ -2,6 +2,7 @@
 // pass driver (== ConversionPass::execute, src/renderer/renderPasses/ConversionPass.cpp:9-68) and
 // read-back.  Compiled with hipcc; no CPU compute path exists here.
 #include "../../include/m2s.h"
+#include <cstdlib>
 #include "m2s_device.h"
 
 #include <algorithm>
@@ -54,6 +55,8 @@ struct m2s_ctx {
     uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
     uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
+    BandInfo bands{};                       // XCD bands of k_fused2 for the scene at R == band_R (from the exact count)
+    uint32_t band_R = 0;
     uint32_t team_off_R = 0;                // R at which k_fused2 reported a workgroup that did not fit its LDS stream
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
@@ -121,6 +124,7 @@ static void free_scene(m2s_ctx* c) {
     c->decided_R = 0;
     c->mp_ready_R = 0;
     c->team_off_R = 0;
+    c->band_R = 0;
     c->async_ok_R = 0;
     c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->tex_mem.clear();
@@ -382,6 +386,12 @@ static bool use_team(const m2s_ctx* c, uint32_t R) {
     return true;
 }
 
+static BandInfo bands_for(const m2s_ctx* c, uint32_t R) {
+    if (c->band_R == R) return c->bands;
+    BandInfo none{};
+    return none;
+}
+
 static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     if (c->cap_policy == 0) return 0;
     if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
@@ -498,6 +508,27 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         }
         c->decided_R = R;
         c->multipass_R = (c->h_total[0] >= 11ull * sc.n_tri) ? R : 0;
+        // XCD bands for k_fused2: the same count tells where the output of each eighth of the triangle list starts
+        // (d_partials now holds the exclusive prefix per 1024 triangles = per 4 workgroups of 256)
+        c->band_R = 0;
+        if (!c->multipass_R && fused_tpw(sc.n_tri) == 64u && !std::getenv("M2S_NO_BANDS")) {
+            const uint32_t wgs = (n_fused_waves(sc.n_tri) + 3u) / 4u;
+            uint32_t bpb = (wgs + 7u) / 8u;
+            bpb = (bpb + 3u) & ~3u;
+            const uint32_t n_part = n_count_blocks(sc.n_tri);
+            uint32_t pre[8];
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t pi = (uint32_t)x * (bpb / 4u);
+                if (pi < n_part) HIPCHK(c, hipMemcpyAsync(&pre[x], c->d_partials + pi, 4, hipMemcpyDeviceToHost, st));
+            }
+            HIPCHK(c, hipStreamSynchronize(st));
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t pi = (uint32_t)x * (bpb / 4u);
+                c->bands.base[x] = pi < n_part ? (unsigned long long)pre[x] : c->h_total[0];
+            }
+            c->bands.workgroups_per_band = bpb;
+            c->band_R = R;
+        }
     }
 
     // ---- run ---------------------------------------------------------------------------------------
@@ -513,8 +544,10 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             c->h_total[0] = 0;
             c->h_total[1] = 0;
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-            (team ? launch_fused2 : launch_fused)(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]),
-                                                  ++c->epoch, c->d_biglist, c->d_bigmeta, st);
+            if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
+            else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
+                              c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
@@ -662,8 +695,10 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     sl.prof = c->profiling;
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
     c->last_pipeline = use_team(c, R) ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-    (use_team(c, R) ? launch_fused2 : launch_fused)(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]),
-                                                 ++c->epoch, c->d_biglist, c->d_bigmeta, st);
+    if (use_team(c, R)) launch_fused2(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+                                      c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
+    else launch_fused(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+                      c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
@@ -811,7 +846,7 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_TEAM) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
-        c->decided_R = 0; c->multipass_R = 0; c->team_off_R = 0; c->async_ok_R = 0; c->mp_ready_R = 0;
+        c->decided_R = 0; c->multipass_R = 0; c->team_off_R = 0; c->async_ok_R = 0; c->mp_ready_R = 0; c->band_R = 0;
     }
     c->pipeline = pipeline;
     return M2S_OK;

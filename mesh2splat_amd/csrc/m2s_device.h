@@ -84,8 +84,14 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
 
+// XCD bands of k_fused2 (see m2s_fused2.hip): workgroups_per_band == 0 switches banding off
+struct BandInfo {
+    unsigned long long base[8];       // record index at which each band's output starts
+    uint32_t workgroups_per_band;     // multiple of 4 (a band then starts on a k_count block boundary)
+};
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st);
+                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
+                   const BandInfo& bands, hipStream_t st);
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                   unsigned long long* total, uint32_t* status /* [0]=any big [1]=error */, uint32_t epoch, BigItem* biglist,
                   uint32_t* bigmeta /* [0]=count [1]=max fragments [2]=sum of fragments */, hipStream_t st);

@@ -103,15 +103,22 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
                                                       unsigned long long* __restrict__ total_out,
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
                                                       BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
-                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */) {
+                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
+                                                      BandInfo bands) {
     __shared__ F2Lds S;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_batches = (sc.n_tri + tpw - 1u) / tpw;
-    // hardware workgroup h runs on XCD h % 8 (private L2 each); runs of kXcdRun2 consecutive LOGICAL workgroups
-    // (= consecutive triangles = neighbouring texture regions) go to one XCD (1 = plain round-robin)
+    // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (the host knows, from an exact
+    // count taken once per scene and R, where the output of each eighth of the triangle list starts) XCD x converts
+    // the x-th eighth: neighbouring triangles — neighbouring texels — meet in ONE L2 instead of eight, and the look-back
+    // chain restarts at every band (a workgroup still only waits for workgroups dispatched before it: h - 8, h - 16, ...).
+    // Without bands: plain round-robin (or runs of kXcdRun2, which the chain does not like: see DESIGN.md).
     const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
-    const uint32_t lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
+    const uint32_t bpb = bands.workgroups_per_band;
+    if (bpb && round >= bpb) return;
+    const uint32_t lb = bpb ? xcd * bpb + round : ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
+    const bool band_first = bpb && round == 0;        // this workgroup's base is the band's base: known
     const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
     if (b0 >= n_batches) return;
     const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
@@ -129,7 +136,11 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     }
     // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
     // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
-    if (wave == 0 && lane == 0) { S.claimed = 0; S.base_state = b0 == 0 ? 2u : 0u; S.irregular = 0; S.error = 0; S.base = 0; }
+    if (wave == 0 && lane == 0) {
+        S.claimed = 0; S.irregular = 0; S.error = 0;
+        S.base_state = (b0 == 0 || band_first) ? 2u : 0u;
+        S.base = band_first ? bands.base[xcd] : 0ull;
+    }
     __syncthreads();
 
     // ======================= triangle phase: one batch per wave (as in k_fused) =======================
@@ -224,7 +235,12 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     const uint32_t ctoff = inclc - cntc;
 
     // publish: the chain word of this batch (global batch 0 knows its prefix) and the counts for the team
-    if (has_batch && lane == 0) chain_store(&chain[b], (b == 0 ? kFlagPrefix : kFlagAgg) | etag | (total_w & kValMask));
+    if (has_batch && lane == 0) {
+        // the first batch of the grid / of a band knows its inclusive prefix; everybody else publishes the aggregate
+        const bool knows = b == 0 || (band_first && wave == 0);
+        const unsigned long long before = band_first ? bands.base[xcd] : 0ull;
+        chain_store(&chain[b], (knows ? kFlagPrefix : kFlagAgg) | etag | (((knows ? before : 0ull) + total_w) & kValMask));
+    }
     if (lane == 0) { S.total_w[wave] = total_w; S.total_c[wave] = total_c; }
     lds_store(&S.counted[wave], 1u);
 
@@ -427,14 +443,18 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
 }
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, hipStream_t st) {
+                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
+                   const BandInfo& bands, hipStream_t st) {
     const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
     const uint32_t n_batches = n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
-    nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
+    BandInfo b = bands;
+    if (tpw != 64u || kTeam != 4) b.workgroups_per_band = 0;   // band bases come from 1024-triangle count blocks
+    if (b.workgroups_per_band) nb = 8u * b.workgroups_per_band;
+    else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta, tpw);
+                       epoch & 0xFFFFu, biglist, bigmeta, tpw, b);
 }
 
 #ifdef M2S_TIMING
