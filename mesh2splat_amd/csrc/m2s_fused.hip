@@ -183,12 +183,12 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
 
     M2S_STAMP(2);  // coverage counted
     // ---------------- ordering: wave scan + decoupled look-back ----------------
-    const unsigned long long incl = wave_incl_scan64(cnt, lane);
+    // (a triangle has at most 4096^2 = 2^24 fragments, so the wave's 64 counts sum to < 2^31: 32-bit scans)
+    const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t inclc = wave_incl_scan(cntc, lane);
-    const uint32_t tw_lo = __builtin_amdgcn_readlane((uint32_t)incl, 63), tw_hi = __builtin_amdgcn_readlane((uint32_t)(incl >> 32), 63);
-    const unsigned long long total_w = ((unsigned long long)tw_hi << 32) | tw_lo;  // wave-uniform, in SGPRs
+    const unsigned long long total_w = __builtin_amdgcn_readlane(incl, 63);  // wave-uniform, in SGPRs
     const uint32_t total_c = __builtin_amdgcn_readlane(inclc, 63);
-    const unsigned long long toff = incl - cnt;  // wave-local index of the first fragment (all kinds)
+    const unsigned long long toff = incl - cnt;     // wave-local index of the first fragment (all kinds)
     const uint32_t ctoff = inclc - cntc;         // same, counting only fragments emitted here
 
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;

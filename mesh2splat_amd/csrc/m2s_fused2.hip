@@ -226,12 +226,12 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     const uint32_t cntc = (kind == kSmall || kind == kMedium) ? cnt : 0;
     const bool anybig = __ballot(kind == kBig) != 0ull;
 
-    const unsigned long long incl = wave_incl_scan64(cnt, lane);
+    // (a triangle has at most 4096^2 = 2^24 fragments, so the wave's 64 counts sum to < 2^31: 32-bit scans)
+    const uint32_t incl = wave_incl_scan(cnt, lane);
     const uint32_t inclc = wave_incl_scan(cntc, lane);
-    const uint32_t tw_lo = __builtin_amdgcn_readlane((uint32_t)incl, 63), tw_hi = __builtin_amdgcn_readlane((uint32_t)(incl >> 32), 63);
-    const unsigned long long total_w = ((unsigned long long)tw_hi << 32) | tw_lo;
+    const unsigned long long total_w = __builtin_amdgcn_readlane(incl, 63);
     const uint32_t total_c = __builtin_amdgcn_readlane(inclc, 63);
-    const unsigned long long toff = incl - cnt;
+    const unsigned long long toff = incl - cnt;   
     const uint32_t ctoff = inclc - cntc;
 
     // publish: the chain word of this batch (global batch 0 knows its prefix) and the counts for the team
