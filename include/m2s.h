@@ -128,6 +128,12 @@ m2s_status m2s_convert_into(m2s_ctx* ctx, uint32_t R, void* d_records, uint64_t 
  * The first conversion of a scene at a given R, and any conversion that needs the second stage or the multi-pass
  * pipeline, is executed synchronously inside submit (same results, no overlap). */
 #define M2S_MAX_IN_FLIGHT 4
+/* lanes = 2: context-owned submissions alternate between two streams, each with its own look-back chain and record
+ * buffer, so consecutive single-kernel conversions OVERLAP (the tail of one, where the GPU drains, with the head of the
+ * next: C3 0.132 -> 0.108 ms per conversion at three in flight) instead of running back to back with ~8 us between
+ * dependent kernels.  Records then alternate between two buffers; m2s_device_records / m2s_download / m2s_export_ply
+ * follow the conversion last waited for.  Default 1 (one stream, one buffer). */
+m2s_status m2s_set_async_lanes(m2s_ctx* ctx, int lanes);
 m2s_status m2s_convert_submit(m2s_ctx* ctx, uint32_t R, void* d_records, uint64_t capacity_records, void* hip_stream);
 m2s_status m2s_convert_wait(m2s_ctx* ctx, uint64_t* out_total);
 /* Number of records actually stored by the last convert: min(total, cap[, capacity]). */

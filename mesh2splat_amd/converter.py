@@ -162,6 +162,10 @@ class Converter:
         kernel forced, in one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, workgroup-cooperative)."""
         self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1, "wave": 2, "team": 3}[name]))
 
+    def set_async_lanes(self, lanes: int):
+        """2: context-owned submissions alternate between two streams / chains / record buffers and overlap."""
+        self._check(self._L.m2s_set_async_lanes(self._h, int(lanes)))
+
     @property
     def last_pipeline(self) -> str:
         """What the last conversion ran: 'multipass', 'wave' (k_fused) or 'team' (k_fused2)."""

@@ -55,6 +55,14 @@ struct m2s_ctx {
     uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
     uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
+    // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
+    // and record buffer, so that consecutive single-kernel conversions overlap (the tail of one, where the GPU drains,
+    // with the head of the next) instead of paying ~8 us between dependent kernels on one stream
+    int lanes = 1;                          // m2s_set_async_lanes
+    hipStream_t stream_b = nullptr;
+    unsigned long long* d_chain_b = nullptr;
+    void* d_records_b = nullptr;
+    uint64_t records_b_cap = 0;
     BandInfo bands{};                       // XCD bands of k_fused2 for the scene at R == band_R (from the exact count)
     uint32_t band_R = 0;
     uint32_t team_off_R = 0;                // R at which k_fused2 reported a workgroup that did not fit its LDS stream
@@ -116,6 +124,8 @@ static void free_scene(m2s_ctx* c) {
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_chain) (void)hipFree(c->d_chain);
+    if (c->d_chain_b) (void)hipFree(c->d_chain_b);
+    c->d_chain_b = nullptr;
     if (c->d_biglist) (void)hipFree(c->d_biglist);
     if (c->d_bigmeta) (void)hipFree(c->d_bigmeta);
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr;
@@ -184,6 +194,8 @@ void m2s_destroy(m2s_ctx* c) {
     free_scene(c);
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
+    if (c->d_records_b) (void)hipFree(c->d_records_b);
+    if (c->stream_b) { (void)hipStreamSynchronize(c->stream_b); (void)hipStreamDestroy(c->stream_b); }
     if (c->d_sorted) (void)hipFree(c->d_sorted);
     if (c->d_sort_u32) (void)hipFree(c->d_sort_u32);
     if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
@@ -687,17 +699,39 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t limit;
     void* d_out;
+    unsigned long long* chain = c->d_chain;
     if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
-    else { limit = cap ? cap : c->records_cap; d_out = c->d_records; }
+    else {
+        limit = cap ? cap : c->records_cap;
+        d_out = c->d_records;
+        if ((k & 1u) && c->lanes == 2) {
+            // odd slots: the second lane (allocated on first use).  Records of consecutive conversions then alternate
+            // between two context-owned buffers; m2s_device_records / m2s_download follow the conversion last waited for.
+            if (!c->stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+            if (!c->d_chain_b) {
+                const size_t words = std::max<size_t>(n_fused_waves(c->scene.n_tri), 1);
+                HIPCHK(c, hipMalloc((void**)&c->d_chain_b, words * sizeof(unsigned long long)));
+                HIPCHK(c, hipMemsetAsync(c->d_chain_b, 0, words * sizeof(unsigned long long), c->stream_b));
+            }
+            if (c->records_b_cap != c->records_cap) {
+                if (c->d_records_b) { (void)hipFree(c->d_records_b); c->d_records_b = nullptr; c->records_b_cap = 0; }
+                HIPCHK(c, hipMalloc(&c->d_records_b, c->records_cap * sizeof(m2s_gaussian)));
+                c->records_b_cap = c->records_cap;
+            }
+            st = c->stream_b;
+            chain = c->d_chain_b;
+            d_out = c->d_records_b;
+        }
+    }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
     unsigned long long* res = &c->h_total[2 + 2 * k];
     res[0] = 0; res[1] = 0;
     sl.prof = c->profiling;
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
     c->last_pipeline = use_team(c, R) ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-    if (use_team(c, R)) launch_fused2(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+    if (use_team(c, R)) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
                                       c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
-    else launch_fused(c->scene, R, c->d_chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+    else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
@@ -853,6 +887,14 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
 }
 
 int m2s_last_pipeline(const m2s_ctx* c) { return c ? c->last_pipeline : 0; }
+
+m2s_status m2s_set_async_lanes(m2s_ctx* c, int lanes) {
+    if (!c) return M2S_ERR_INVALID;
+    if (lanes != 1 && lanes != 2) return fail(c, M2S_ERR_INVALID, "lanes must be 1 or 2");
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    c->lanes = lanes;
+    return M2S_OK;
+}
 
 m2s_status m2s_last_kernel_ms(const m2s_ctx* c, float out_ms[M2S_K_N]) {
     if (!c || !out_ms) return M2S_ERR_INVALID;
