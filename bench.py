@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
+    ap.add_argument("--overlap-extra", action="store_true",
+                    help="after the timed region, also measure two-lane overlapped submission (reported as 'overlapped'; off by "
+                         "default so that a rocprofv3 trace of the default command holds only isolated launches)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
@@ -294,7 +297,7 @@ def main():
     # consecutive conversions overlap.  Not the headline: overlapped launches have no meaningful individual duration,
     # and the roofline above is about the kernel.
     overlapped = None
-    if not multi and conv.last_pipeline in ("team", "wave"):
+    if a.overlap_extra and not multi and conv.last_pipeline in ("team", "wave"):
         conv.set_async_lanes(2)
         n_ov = max(min(a.steps, 60), 6)
         for _ in range(4):
