@@ -211,6 +211,9 @@ m2s_status m2s_set_profiling(m2s_ctx* ctx, int enabled);
 m2s_status m2s_last_kernel_ms(const m2s_ctx* ctx, float out_ms[M2S_K_N]);
 /* Scene facts for roofline accounting: triangles in range, meshes. */
 uint64_t m2s_num_triangles(const m2s_ctx* ctx);
+/* Test hook: sets the counter of single-pass launches (its low 16 bits tag the look-back chain words), so that a test
+ * can walk a context across the wrap of that tag without issuing 65 536 conversions.  Requires an idle context. */
+m2s_status m2s_debug_set_launch_counter(m2s_ctx* ctx, uint32_t value);
 
 #ifdef __cplusplus
 }

@@ -393,6 +393,20 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
 // Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless the scene is too
 // small to fill the GPU with 64-triangle batches (k_fused then runs 32 / 16 triangles per wave) or a workgroup's
 // fragments did not fit its LDS stream at this R before.
+// Chain words carry a 16-bit launch tag instead of being cleared per launch.  The two single-pass kernels use different
+// numbers of words, so a word one of them left behind could read as freshly published 65 536 launches later: when the
+// tag wraps, everything in flight is drained and both chains are cleared (once per ~10 s of back-to-back conversions).
+static hipError_t next_epoch(m2s_ctx* c, uint32_t* out) {
+    const uint32_t e = ++c->epoch;
+    *out = e;
+    if ((e & 0xFFFFu) != 0) return hipSuccess;
+    const size_t bytes = std::max<size_t>(n_fused_waves(c->scene.n_tri), 1) * sizeof(unsigned long long);
+    hipError_t r = hipDeviceSynchronize();
+    if (r == hipSuccess && c->d_chain) r = hipMemset(c->d_chain, 0, bytes);
+    if (r == hipSuccess && c->d_chain_b) r = hipMemset(c->d_chain_b, 0, bytes);
+    return r;
+}
+
 static bool use_team(const m2s_ctx* c, uint32_t R) {
     if (c->pipeline == M2S_PIPELINE_WAVE || c->team_off_R == R) return false;
     return true;
@@ -555,10 +569,12 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             const bool team = use_team(c, R);
             c->h_total[0] = 0;
             c->h_total[1] = 0;
+            uint32_t epoch;
+            HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-            if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
+            if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
-            else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), ++c->epoch,
+            else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
             HIPCHK(c, hipGetLastError());
@@ -727,11 +743,13 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     unsigned long long* res = &c->h_total[2 + 2 * k];
     res[0] = 0; res[1] = 0;
     sl.prof = c->profiling;
+    uint32_t epoch;
+    HIPCHK(c, next_epoch(c, &epoch));
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
     c->last_pipeline = use_team(c, R) ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-    if (use_team(c, R)) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+    if (use_team(c, R)) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                                       c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
-    else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), ++c->epoch,
+    else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
@@ -887,6 +905,13 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
 }
 
 int m2s_last_pipeline(const m2s_ctx* c) { return c ? c->last_pipeline : 0; }
+
+m2s_status m2s_debug_set_launch_counter(m2s_ctx* c, uint32_t value) {
+    if (!c) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    c->epoch = value;
+    return M2S_OK;
+}
 
 m2s_status m2s_set_async_lanes(m2s_ctx* c, int lanes) {
     if (!c) return M2S_ERR_INVALID;

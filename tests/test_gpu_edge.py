@@ -167,3 +167,35 @@ def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, or
     assert total == ototal
     assert_records_match(c.download(), orec, "team form, three meshes")
     c.close()
+
+
+def test_chain_tag_wrap_between_the_two_single_pass_forms(hiplib, oracle):
+    """Look-back chain words are tagged with the low 16 bits of a launch counter instead of being cleared.  The wave form
+    uses more chain words than the team form, so words it wrote keep their tag while only the team form runs; when the
+    counter comes round to the same tag 65 536 launches later they must not read as fresh.  Walk the counter across
+    the wrap with the test hook and alternate the forms around it."""
+    scene = synth.cube_sphere(60, tex_size=32)
+    R = 256
+    ototal, orec, _ = oracle.convert(scene, R, cap=0)
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    L = hiplib
+
+    def run(form):
+        c.set_pipeline(form)
+        assert c.convert(R) == ototal
+        assert c.last_pipeline == form
+        assert_records_match(c.download(), orec, "tag wrap, %s" % form)
+
+    for first, second in (("wave", "team"), ("team", "wave")):
+        assert L.m2s_debug_set_launch_counter(c._h, 0x10000 - 2) == 0
+        run(first)                    # tag 0xFFFF
+        run(second)                   # tag 0x0000: chains cleared
+        run(second)                   # 0x0001
+        run(first)                    # 0x0002 on every word this form uses
+        assert L.m2s_debug_set_launch_counter(c._h, 0x20000 - 2) == 0
+        for _ in range(3):
+            run(second)               # 0xFFFF, 0x0000 (cleared), 0x0001: overwrites only the words the other form uses
+        run(first)                    # 0x0002 again: without the clear it would meet its own words of one period ago
+    c.close()
