@@ -32,7 +32,7 @@ class _Mesh(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "m2s_oracle.c")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("m2s_oracle.c", "m2s_oracle_prepass.c")):
         subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -74,6 +74,8 @@ def lib():
         L.orc_debug_fs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_cast.restype = None
         L.orc_quat_cast.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_prepass.restype = C.c_uint64
+        L.orc_prepass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -215,3 +217,36 @@ def quat_cast(m_cols: np.ndarray) -> np.ndarray:
     q = np.zeros(4, np.float32)
     lib().orc_quat_cast(m.ctypes.data, q.ctypes.data)
     return q
+
+
+class _PrepassParams(C.Structure):
+    """== orc_prepass_params (m2s_oracle_prepass.h)"""
+    _fields_ = [("world_to_view", C.c_float * 16), ("view_to_clip", C.c_float * 16), ("model_to_world", C.c_float * 16),
+                ("resolution", C.c_float * 2), ("near_far", C.c_float * 2), ("gaussian_std", C.c_float),
+                ("resolution_target", C.c_uint32), ("render_mode", C.c_int32), ("format", C.c_uint32),
+                ("ply_has_pbr", C.c_uint32), ("depth_test_mesh", C.c_uint32),
+                ("depth", C.c_void_p), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32)]
+
+
+def prepass(p, records: np.ndarray):
+    """Viewer prepass over (n,24) records.  `p`: any object with the fields of mesh2splat_amd.prepass.PrepassParams.
+    -> (visible, quads (visible,24) f32, depths (visible,) f32), survivors in input order."""
+    c = _PrepassParams()
+    for name, m in (("world_to_view", p.view_mat), ("view_to_clip", p.proj_mat), ("model_to_world", p.model_mat)):
+        getattr(c, name)[:] = np.ascontiguousarray(m, np.float32).reshape(16).tolist()
+    c.resolution[:] = [float(int(p.renderer_resolution[0])), float(int(p.renderer_resolution[1]))]   # ivec2 -> vec2
+    c.near_far[:] = [float(np.float32(p.near_plane)), float(np.float32(p.far_plane))]
+    c.gaussian_std = float(np.float32(p.gaussian_std))
+    c.resolution_target = int(p.resolution_target)
+    c.render_mode, c.format = int(p.render_mode), int(p.format)
+    c.ply_has_pbr = 1 if p.ply_has_pbr else 0
+    c.depth_test_mesh = 1 if p.perform_mesh_depth_test else 0
+    d = None
+    if p.mesh_depth is not None:
+        d = np.ascontiguousarray(p.mesh_depth, np.float32)
+        c.depth, (c.depth_h, c.depth_w) = d.ctypes.data, d.shape
+    r = np.ascontiguousarray(records, np.float32).reshape(-1, 24)
+    quads = np.zeros((r.shape[0], 24), np.float32)
+    depths = np.zeros(r.shape[0], np.float32)
+    k = int(lib().orc_prepass(C.byref(c), r.ctypes.data, r.shape[0], quads.ctypes.data, depths.ctypes.data))
+    return k, quads[:k].copy(), depths[:k].copy()

@@ -8,8 +8,9 @@ real reference also runs where /root/reference does not exist.
 Inputs (.glb written by mesh2splat_amd.gltf_io.write_glb, records.bin from the oracle) and the reference's
 outputs (*.scene.bin = dump of SceneManager::loadModel's vertex upload / bbox / material / textures,
 ref_fmt*.ply = parsers::savePlyVector, ref_read_fmt*.bin = parsers::loadPlyFile, glsl_*.dump.bin = what the
-reference's converter{VS,GS,FS}.glsl computed when run as C++ through glm by oracle/_ref/ref_glsl_check) are all
-committed."""
+reference's converter{VS,GS,FS}.glsl computed when run as C++ through glm by oracle/_ref/ref_glsl_check,
+prepass_*.out.bin = what GaussiansPrepass::execute + gaussianSplattingPrepassCS.glsl produced for the parameter sets
+of tests/prepass_cases.py on prepass_records.bin, by oracle/_ref/ref_prepass_check) are all committed."""
 import json
 import os
 import shutil
@@ -133,6 +134,14 @@ def main():
         gltf_io.write_glb(scene, glb, **kw)
         ply = os.path.join(OUT, f"pipe_{name}_R{R}.ply") if name == "soup" else None   # SceneManager::exportPly, format 1
         refhost.run_pipeline(glb, R, tmp, ply_path=ply, fmt=1, std=0.65, out_path=os.path.join(OUT, f"pipe_{name}_R{R}.records.bin"))
+    # the reference's viewer prepass (GaussiansPrepass.cpp + gaussianSplattingPrepassCS.glsl) on the software GL
+    assert refhost.prepass_available()
+    import prepass_cases
+    prec = np.concatenate([prepass_cases.base_records(oracle, 3, 12), prepass_cases.hostile_records(128)])
+    prec.tofile(os.path.join(OUT, "prepass_records.bin"))
+    for name, p in prepass_cases.cases():
+        refhost.run_prepass(p, prec, tmp)
+        shutil.copy(os.path.join(tmp, "prepass_out.bin"), os.path.join(OUT, f"prepass_{name}.out.bin"))
     print("wrote", sorted(os.listdir(OUT)), sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT)), "bytes")
 
 

@@ -180,3 +180,48 @@ def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt:
         raise RuntimeError(f"ref_pipeline_check failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-400:]}")
     with open(out, "rb") as f:
         return parse_pipeline_dump(f.read())
+
+
+# ---- viewer prepass (oracle/_ref/ref_prepass_check: GaussiansPrepass.cpp + gaussianSplattingPrepassCS.glsl) ----------
+PREPASS_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_prepass_check")
+
+
+def prepass_available() -> bool:
+    return os.path.isfile(PREPASS_BIN) and os.access(PREPASS_BIN, os.X_OK)
+
+
+def pack_prepass_input(p, records: np.ndarray) -> bytes:
+    """`p`: mesh2splat_amd.prepass.PrepassParams; layout in oracle/ref_prepass_check.cpp."""
+    r = np.ascontiguousarray(records, np.float32).reshape(-1, 24)
+    d = np.zeros((0, 0), np.float32) if p.mesh_depth is None else np.ascontiguousarray(p.mesh_depth, np.float32)
+    out = [b"M2SP", struct.pack("<I", r.shape[0])]
+    for m in (p.view_mat, p.proj_mat, p.model_mat):
+        out.append(np.ascontiguousarray(m, np.float32).tobytes())
+    out.append(struct.pack("<iifffIiIIIII", int(p.renderer_resolution[0]), int(p.renderer_resolution[1]), p.near_plane, p.far_plane,
+                           p.gaussian_std, int(p.resolution_target), int(p.render_mode), int(p.format), 1 if p.ply_has_pbr else 0,
+                           1 if p.perform_mesh_depth_test else 0, d.shape[1] if d.size else 0, d.shape[0] if d.size else 0))
+    out.append(r.tobytes())
+    out.append(d.tobytes())
+    return b"".join(out)
+
+
+def parse_prepass_output(blob: bytes):
+    k = struct.unpack_from("<I", blob, 0)[0]
+    quads = np.frombuffer(blob, np.float32, k * 24, 4).reshape(k, 24).copy()
+    depths = np.frombuffer(blob, np.float32, k, 4 + k * 96).copy()
+    assert len(blob) == 4 + k * 100
+    return k, quads, depths
+
+
+def run_prepass(p, records: np.ndarray, tmp_dir: str):
+    """-> (counter, quads (k,24), depths (k,), info dict) from the REFERENCE's pass + shader."""
+    import json
+    fin, fout = os.path.join(tmp_dir, "prepass_in.bin"), os.path.join(tmp_dir, "prepass_out.bin")
+    with open(fin, "wb") as f:
+        f.write(pack_prepass_input(p, records))
+    r = subprocess.run([PREPASS_BIN, fin, fout], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        raise RuntimeError(f"ref_prepass_check rc={r.returncode}: {r.stdout[-400:]} {r.stderr[-400:]}")
+    with open(fout, "rb") as f:
+        k, quads, depths = parse_prepass_output(f.read())
+    return k, quads, depths, json.loads(r.stdout.strip().splitlines()[-1])
