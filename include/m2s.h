@@ -165,6 +165,53 @@ m2s_status m2s_download_sorted(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacit
 /* Duration (ms) of the last profiled sort (key build + radix sort + gather). */
 float m2s_last_sort_ms(const m2s_ctx* ctx);
 
+/* ---- viewer prepass == GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) ---------------------------- */
+/* What the reference's compute shader gaussianSplattingPrepassCS.glsl:58-204 (+ common.glsl) does to every Gaussian
+ * before it is drawn: transform, frustum cull (1.05 * w guard band), optional test against the mesh depth texture,
+ * 3D covariance -> 2D covariance (+0.3 low-pass) -> conic and the two quad axes in NDC, debug colour modes; survivors
+ * are appended to a QuadNdcTransformation array and a view-space depth array (the RadixSortPass key source).
+ * Fields mirror the RenderContext members the pass reads (RenderContext.hpp:34-111).  Matrices are column-major (glm). */
+typedef struct m2s_prepass_params {
+    float world_to_view[16];     /* viewMat   -> u_worldToView                                              */
+    float view_to_clip[16];      /* projMat   -> u_viewToClip                                               */
+    float model_to_world[16];    /* modelMat  -> u_modelToWorld                                             */
+    int32_t resolution[2];       /* rendererResolution (glm::ivec2) -> u_resolution                         */
+    float near_far[2];           /* nearPlane, farPlane -> u_nearFar                                        */
+    float gaussian_std;          /* gaussianStd;  u_stdDev = gaussianStd / float(resolutionTarget)          */
+    uint32_t resolution_target;  /* resolutionTarget                                                        */
+    int32_t render_mode;         /* renderMode: 0 colour, 1 depth, 2 normal, 3 geometry (per-invocation hash), 6 as 0; else black */
+    uint32_t format;             /* 0 mesh2splat, 1 classic 3DGS .ply, 2 compressed PBR (3 treated like 0)  */
+    uint32_t ply_has_pbr;        /* plyHasPbr                                                               */
+    uint32_t depth_test_mesh;    /* performMeshDepthTest: 1 = cull opaque (alpha > .95) format-0 Gaussians behind `depth` */
+    const float* depth;          /* meshDepthTexture: depth_w x depth_h window-space depth in [0,1], row 0 = bottom of the
+                                    window (GL texture orientation), sampled GL_NEAREST / CLAMP_TO_EDGE (renderer.cpp:290-296).
+                                    HOST memory unless depth_on_device; read only when depth_test_mesh == 1               */
+    uint32_t depth_w, depth_h;
+    uint32_t depth_on_device;    /* 1: `depth` is a device pointer on the context's device (no copy)        */
+} m2s_prepass_params;
+
+/* == QuadNdcTransformation (gaussianSplattingPrepassCS.glsl:17-24), 96 bytes */
+typedef struct m2s_quad {
+    float mean2d_ndc[4];     /* clip position, xyz divided by w; w kept                   */
+    float quad_scale_ndc[4]; /* major axis xy, minor axis xy, in NDC units                */
+    float color[4];          /* per render mode                                           */
+    float conic[4];          /* inverse 2D covariance (xx, xy, yy), view depth (-z)       */
+    float normal[4];         /* encoded normal xyz, metallic                              */
+    float ws_pos[4];         /* world position xyz, roughness                             */
+} m2s_quad;
+
+/* Runs the prepass over `n` records at device pointer `d_records` (96-byte m2s_gaussian each), or over the records of the
+ * context's last conversion when d_records is NULL (n ignored).  Survivors are stored in context-owned buffers in INPUT
+ * order (the reference appends through an atomic counter, i.e. in arrival order; RadixSortPass reorders them anyway).
+ * Synchronous, like the reference's dispatch + the counter read-back that follows it (RadixSortPass.cpp:18-22).
+ * *out_visible = number of survivors (the reference's atomic counter). */
+m2s_status m2s_prepass(m2s_ctx* ctx, const m2s_prepass_params* params, const void* d_records, uint64_t n, uint64_t* out_visible);
+const void* m2s_device_quads(const m2s_ctx* ctx);            /* m2s_quad[visible]  (perQuadTransformationsBuffer)   */
+const void* m2s_device_prepass_depths(const m2s_ctx* ctx);   /* float[visible]     (gaussianDepthPostFiltering)     */
+m2s_status m2s_download_prepass(m2s_ctx* ctx, m2s_quad* dst_quads, float* dst_depths, uint64_t capacity);
+/* Duration (ms) of the last profiled prepass kernel. */
+float m2s_last_prepass_ms(const m2s_ctx* ctx);
+
 /* ---- scene I/O == SceneManager::loadModel (minus GL) and parsers::loadPlyFile ------------------------ */
 /* Host-side scene loaded from a binary glTF file: scene-graph transforms applied, de-indexed 17-float
  * vertex buffers, fallback normals/tangents, cumulative bboxes, RGBA8 textures (PNG) — exactly what

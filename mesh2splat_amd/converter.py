@@ -157,6 +157,40 @@ class Converter:
     def last_sort_ms(self) -> float:
         return float(self._L.m2s_last_sort_ms(self._h))
 
+    def prepass(self, params, records=None, download: bool = True):
+        """GaussiansPrepass: cull + covariance projection of the last conversion's records (or of `records`, a CUDA torch
+        tensor of shape (n, 24) float32).  `params`: mesh2splat_amd.prepass.PrepassParams.
+        -> (visible, quads (visible,24) f32, depths (visible,) f32) in input order; with download=False only `visible`
+        (the results stay on the device: device_quads / device_prepass_depths)."""
+        from . import prepass as _pp
+        pc, keep = _pp.to_c(params)
+        ptr, n = None, 0
+        if records is not None:
+            if not (hasattr(records, "data_ptr") and records.is_cuda and records.is_contiguous()):
+                raise ValueError("records must be a contiguous CUDA tensor (n, 24) float32")
+            ptr, n = records.data_ptr(), int(records.shape[0])
+        vis = C.c_uint64()
+        self._check(self._L.m2s_prepass(self._h, C.byref(pc), ptr, n, C.byref(vis)))
+        del keep
+        if not download:
+            return vis.value
+        quads = np.empty((vis.value, 24), np.float32)
+        depths = np.empty(vis.value, np.float32)
+        self._check(self._L.m2s_download_prepass(self._h, quads.ctypes.data, depths.ctypes.data, vis.value))
+        return vis.value, quads, depths
+
+    @property
+    def device_quads(self) -> int:
+        return int(self._L.m2s_device_quads(self._h) or 0)
+
+    @property
+    def device_prepass_depths(self) -> int:
+        return int(self._L.m2s_device_prepass_depths(self._h) or 0)
+
+    @property
+    def last_prepass_ms(self) -> float:
+        return float(self._L.m2s_last_prepass_ms(self._h))
+
     def set_pipeline(self, name: str):
         """'auto' (single-pass kernel or multi-pass pipeline, chosen per scene and R), 'multipass', or the single-pass
         kernel forced, in one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, workgroup-cooperative)."""

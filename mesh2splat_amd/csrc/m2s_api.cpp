@@ -94,6 +94,16 @@ struct m2s_ctx {
     size_t sort_temp_cap = 0;
     uint64_t sort_u32_cap = 0;
     float last_sort_ms = 0.0f;
+    // viewer prepass (m2s_prepass): survivors, their depths, the look-back chain of its kernel, a copy of the depth image
+    void* d_quads = nullptr;
+    float* d_pp_depths = nullptr;
+    uint64_t pp_cap = 0, pp_visible = 0;
+    unsigned long long* d_pp_chain = nullptr;
+    uint64_t pp_chain_words = 0;
+    uint32_t pp_epoch = 0;
+    float* d_pp_depthtex = nullptr;
+    uint64_t pp_depthtex_cap = 0;
+    float last_prepass_ms = 0.0f;
 
     // measurement
     bool profiling = false;
@@ -171,7 +181,7 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->h_total, (2 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void**)&c->h_total, (4 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -197,6 +207,10 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_records_b) (void)hipFree(c->d_records_b);
     if (c->stream_b) { (void)hipStreamSynchronize(c->stream_b); (void)hipStreamDestroy(c->stream_b); }
     if (c->d_sorted) (void)hipFree(c->d_sorted);
+    if (c->d_quads) (void)hipFree(c->d_quads);
+    if (c->d_pp_depths) (void)hipFree(c->d_pp_depths);
+    if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
+    if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
     if (c->d_sort_u32) (void)hipFree(c->d_sort_u32);
     if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
     if (c->d_total) (void)hipFree(c->d_total);
@@ -886,6 +900,88 @@ m2s_status m2s_download_sorted(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_
 }
 
 float m2s_last_sort_ms(const m2s_ctx* c) { return c ? c->last_sort_ms : 0.0f; }
+
+// GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) + the counter read-back that follows it (RadixSortPass.cpp:18-22).
+m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {
+    if (!c || !p) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    if (!d_records) {
+        if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run and no records were passed");
+        d_records = c->last_records;
+        n = c->last_stored;
+    }
+    if (p->resolution_target == 0) return fail(c, M2S_ERR_INVALID, "resolution_target is 0");
+    if (p->depth_test_mesh == 1 && p->format == 0 && (!p->depth || !p->depth_w || !p->depth_h))
+        return fail(c, M2S_ERR_INVALID, "depth_test_mesh is set but no depth image was passed");
+    if (n > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 records");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->pp_visible = 0;
+    if (out_visible) *out_visible = 0;
+    if (!n) return M2S_OK;
+    if (c->pp_cap < n) {
+        if (c->d_quads) { (void)hipFree(c->d_quads); c->d_quads = nullptr; }
+        if (c->d_pp_depths) { (void)hipFree(c->d_pp_depths); c->d_pp_depths = nullptr; }
+        c->pp_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_quads, n * sizeof(m2s_quad)));
+        HIPCHK(c, hipMalloc((void**)&c->d_pp_depths, n * sizeof(float)));
+        c->pp_cap = n;
+    }
+    const uint64_t words = (n + 63) / 64;
+    // the chain is tagged with the low 16 bits of a launch counter instead of being cleared per launch; cleared when
+    // it is (re)allocated and when the tag wraps (see next_epoch)
+    bool clear_chain = false;
+    if (c->pp_chain_words < words) {
+        if (c->d_pp_chain) { (void)hipFree(c->d_pp_chain); c->d_pp_chain = nullptr; c->pp_chain_words = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_pp_chain, words * sizeof(unsigned long long)));
+        c->pp_chain_words = words;
+        clear_chain = true;
+    }
+    const uint32_t epoch = ++c->pp_epoch;
+    if (clear_chain || (epoch & 0xFFFFu) == 0)
+        HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, c->pp_chain_words * sizeof(unsigned long long), c->stream));
+    PrepassK k;
+    prepass_prepare(*p, n, &k);
+    if (p->depth_test_mesh == 1 && p->format == 0) {
+        if (p->depth_on_device) k.depth = p->depth;
+        else {
+            const uint64_t texels = (uint64_t)p->depth_w * p->depth_h;
+            if (c->pp_depthtex_cap < texels) {
+                if (c->d_pp_depthtex) { (void)hipFree(c->d_pp_depthtex); c->d_pp_depthtex = nullptr; c->pp_depthtex_cap = 0; }
+                HIPCHK(c, hipMalloc((void**)&c->d_pp_depthtex, texels * sizeof(float)));
+                c->pp_depthtex_cap = texels;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_pp_depthtex, p->depth, texels * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            k.depth = c->d_pp_depthtex;
+        }
+    } else k.depth_test = 0;
+    unsigned long long* res = &c->h_total[2 + 2 * M2S_MAX_IN_FLIGHT];
+    res[0] = 0; res[1] = 0;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)c->d_quads, c->d_pp_depths, c->d_pp_chain, epoch, &res[0],
+                             reinterpret_cast<uint32_t*>(&res[1]), c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_prepass_ms, c->ev[0], c->ev[1]));
+    if (reinterpret_cast<uint32_t*>(&res[1])[1]) return fail(c, M2S_ERR_HIP, "prepass: look-back chain timed out");
+    c->pp_visible = res[0];
+    if (out_visible) *out_visible = res[0];
+    return M2S_OK;
+}
+
+const void* m2s_device_quads(const m2s_ctx* c) { return c && c->pp_visible ? c->d_quads : nullptr; }
+const void* m2s_device_prepass_depths(const m2s_ctx* c) { return c && c->pp_visible ? c->d_pp_depths : nullptr; }
+
+m2s_status m2s_download_prepass(m2s_ctx* c, m2s_quad* dst_quads, float* dst_depths, uint64_t capacity) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->pp_visible) return M2S_OK;
+    if (capacity < c->pp_visible) return fail(c, M2S_ERR_CAPACITY, "destination holds fewer entries than survived the prepass");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (dst_quads) HIPCHK(c, hipMemcpy(dst_quads, c->d_quads, c->pp_visible * sizeof(m2s_quad), hipMemcpyDeviceToHost));
+    if (dst_depths) HIPCHK(c, hipMemcpy(dst_depths, c->d_pp_depths, c->pp_visible * sizeof(float), hipMemcpyDeviceToHost));
+    return M2S_OK;
+}
+
+float m2s_last_prepass_ms(const m2s_ctx* c) { return c ? c->last_prepass_ms : 0.0f; }
 
 m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
     if (!c) return M2S_ERR_INVALID;

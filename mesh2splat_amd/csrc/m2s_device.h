@@ -98,6 +98,27 @@ void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uin
 void launch_emit_big(const SceneDev& sc, uint32_t R, const BigItem* biglist, uint32_t n_big, uint32_t max_cnt, uint64_t limit,
                      float4* out, hipStream_t st);
 
+// ---- viewer prepass (m2s_prepass.hip) --------------------------------------------------------------------------
+// kernel-side uniforms: the shader's uniforms plus its per-dispatch invariants, prepared by prepass_prepare()
+struct PrepassK {
+    float M[16], V[16], P[16];   // u_modelToWorld, u_worldToView, u_viewToClip (column-major)
+    float MinvT[16];             // transpose(inverse(u_modelToWorld))
+    float mr_inv[9];             // inverse(mat3(u_modelToWorld)), [col*3 + row]
+    float ms2[3];                // (modelScale * modelScale)
+    float res[2], near_far[2], std_dev;
+    int32_t render_mode;
+    uint32_t format, ply_has_pbr, depth_test;
+    const float* depth;          // device pointer (window-space depth, row 0 = bottom) or nullptr
+    uint32_t depth_w, depth_h;
+    uint32_t global_w;           // width in invocations of the reference's dispatch (gl_GlobalInvocationID of a linear index)
+};
+}  // namespace m2s
+struct m2s_prepass_params;
+namespace m2s {
+void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out);
+hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
+                          uint32_t epoch, unsigned long long* total, uint32_t* status, hipStream_t st);
+
 size_t sort_temp_bytes(uint32_t n);
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st);

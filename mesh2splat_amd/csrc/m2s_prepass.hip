@@ -1,0 +1,335 @@
+// m2s_prepass.hip — the viewer prepass for gfx950: frustum / depth cull of the 96-byte records, 3D
+// covariance -> screen-space conic and quad axes, ordered append of the survivors.
+//
+// Replaces   GaussiansPrepass::execute            (src/renderer/renderPasses/GaussiansPrepass.cpp:8-56)
+//            gaussianSplattingPrepassCS.glsl:58-204 + common.glsl:12-92
+//
+// Shape of the work: stream 96 B in, <= 100 B out per Gaussian, ~300 flops in between: HBM-bound.
+//   load     a wave's 64 records are 6144 contiguous bytes: six fully coalesced 1 KiB loads, transposed through LDS
+//            (stride 7 float4 per record: conflict-free ds_read_b128) so that every lane ends up with ITS record
+//   math     one lane per Gaussian, fp32, the shader's operation order (one rounding per operation, no contraction),
+//            so that the cull decisions and every stored float equal the reference's (sin / exp of the two debug
+//            render modes excepted: library functions)
+//   append   the reference takes an atomic counter per survivor (arrival order, nondeterministic).  Here: ballot +
+//            popcount per wave, decoupled look-back over one chain word per wave (same word format and helper as the
+//            conversion kernels), survivors staged in LDS and written as contiguous float4 runs -> output in INPUT
+//            order, reproducible, and no same-address atomics at all.
+#include "../../include/m2s.h"
+#include "m2s_fused_common.h"
+
+#include <cmath>
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+namespace {
+
+struct M3 { float c[3][3]; };   // c[col][row], like the shader's mat3
+
+// mat3 * mat3 in the shader's (glm's) association: a0r*b_c0 + a1r*b_c1 + a2r*b_c2, left to right
+__device__ __forceinline__ M3 m3_mul(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r.c[c][i] = a.c[0][i] * b.c[c][0] + a.c[1][i] * b.c[c][1] + a.c[2][i] * b.c[c][2];
+    return r;
+}
+__device__ __forceinline__ M3 m3_transpose(const M3& a) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r.c[c][i] = a.c[i][c];
+    return r;
+}
+// mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*w)
+__device__ __forceinline__ float4 m4_mul(const float* m, float x, float y, float z, float w) {
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (m[0 + i] * x + m[4 + i] * y) + (m[8 + i] * z + m[12 + i] * w);
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+__device__ __forceinline__ float min_glsl(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float max_glsl(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float clamp01(float x) { return min_glsl(max_glsl(x, 0.0f), 1.0f); }
+
+// common.glsl:12-19
+__device__ __forceinline__ float random2d(float cx, float cy) {
+    const float a = 12.9898f, b = 78.233f, c = 43758.5453f;
+    const float dt = cx * a + cy * b;
+    const float sn = dt - 3.14f * floorf(dt / 3.14f);
+    const float v = sinf(sn) * c;
+    return v - floorf(v);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(kBlock) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
+                                                    float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
+                                                    unsigned long long* __restrict__ total, uint32_t* __restrict__ status) {
+    __shared__ float4 s_rec[kBlock / 64][64 * kStageStride];
+    __shared__ float s_depth[kBlock / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wid = blockIdx.x * (kBlock / 64) + wave, n_waves = (n + 63u) / 64u;
+    if (wid >= n_waves) return;                       // whole wave; nobody waits on a wave that does not exist
+    const uint32_t first = wid * 64u, have = min(64u, n - first);
+    float4* S = s_rec[wave];
+
+    // ---- load + transpose ------------------------------------------------------------------------------------
+    {
+        const float4* src = rec + (size_t)first * 6;
+        const uint32_t n4 = have * 6u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
+            if (idx < n4) {
+                const uint32_t r = idx / 6u;
+                S[r * kStageStride + (idx - r * 6u)] = src[idx];
+            }
+        }
+    }
+    wave_lds_sync();
+    const bool valid = (uint32_t)lane < have;
+    const int rl = valid ? lane : 0;
+    const float4 gpos = S[rl * kStageStride + 0], gcol = S[rl * kStageStride + 1], gscl = S[rl * kStageStride + 2];
+    const float4 gnrm = S[rl * kStageStride + 3], grot = S[rl * kStageStride + 4], gpbr = S[rl * kStageStride + 5];
+
+    // ---- the shader ------------------------------------------------------------------------------------------
+    bool vis = valid;
+    const float4 ws = m4_mul(k.M, gpos.x, gpos.y, gpos.z, 1.0f);                 // :67
+    const float4 vs = m4_mul(k.V, ws.x, ws.y, ws.z, 1.0f);                       // :69
+    float4 pos2d = m4_mul(k.P, vs.x, vs.y, vs.z, vs.w);                          // :71
+    const float clip = 1.05f * pos2d.w;                                          // :73
+    if (pos2d.z < -clip || pos2d.x < -clip || pos2d.x > clip || pos2d.y < -clip || pos2d.y > clip) vis = false;   // :75-77
+
+    if (k.depth_test == 1u && gcol.w > .95f && k.format == 0u && vis) {          // :80-92
+        const float u = (pos2d.x / pos2d.w) * 0.5f + 0.5f, v = (pos2d.y / pos2d.w) * 0.5f + 0.5f;
+        // GL_NEAREST, CLAMP_TO_EDGE (renderer.cpp:290-296): texel floor(u*W), clamped; NaN -> 0
+        const float fu = floorf(u * (float)k.depth_w), fv = floorf(v * (float)k.depth_h);
+        const uint32_t ti = fu >= 0.0f ? (fu < (float)k.depth_w ? (uint32_t)fu : k.depth_w - 1u) : 0u;
+        const uint32_t tj = fv >= 0.0f ? (fv < (float)k.depth_h ? (uint32_t)fv : k.depth_h - 1u) : 0u;
+        const float depth = k.depth[(size_t)tj * k.depth_w + ti];
+        const float my_depth = (pos2d.z / pos2d.w) * 0.5f + 0.5f;
+        if (my_depth > depth + 0.00002f) vis = false;
+    }
+
+    const float multiplier = (k.format == 0u || k.format == 3u) ? k.std_dev : 1.0f;   // :94
+    // :95-96  modelScale = (|M[0]|, |M[0]|, |M[1]|) as written; k.ms2 = its square (uniform, prepared on the host)
+    const float scale[3] = { (gscl.x * multiplier) * k.ms2[0], (gscl.y * multiplier) * k.ms2[1], (gscl.z * multiplier) * k.ms2[2] };
+
+    M3 rot;                                                                      // :100  castQuatToMat3 on the stored vec4
+    {
+        const float x = grot.x, y = grot.y, z = grot.z, w = grot.w;
+        rot.c[0][0] = 1.f - 2.f * (z * z + w * w);
+        rot.c[0][1] = 2.f * (y * z - x * w);
+        rot.c[0][2] = 2.f * (y * w + x * z);
+        rot.c[1][0] = 2.f * (y * z + x * w);
+        rot.c[1][1] = 1.f - 2.f * (y * y + w * w);
+        rot.c[1][2] = 2.f * (z * w - x * y);
+        rot.c[2][0] = 2.f * (y * w - x * z);
+        rot.c[2][1] = 2.f * (z * w + x * y);
+        rot.c[2][2] = 1.f - 2.f * (y * y + z * z);
+    }
+    M3 mri;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mri.c[c][i] = k.mr_inv[c * 3 + i];
+    rot = m3_mul(rot, mri);                                                      // :102-108
+    M3 cov3d;                                                                    // :110  computeCov3D
+    {
+        M3 sm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sm.c[c][i] = (c == i) ? scale[c] : 0.0f;
+        const M3 mm = m3_mul(sm, rot);
+        cov3d = m3_mul(m3_transpose(mm), mm);
+    }
+
+    float4 out_color = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nrm = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (k.format == 0u || (k.format == 1u && k.ply_has_pbr != 0u) || k.format == 3u) {   // :118-122
+        const float4 nw = m4_mul(k.MinvT, gnrm.x, gnrm.y, gnrm.z, 1.0f);
+        nrm = make_float4(nw.x * 0.5f + 0.5f, nw.y * 0.5f + 0.5f, nw.z * 0.5f + 0.5f, gcol.w);
+    } else if (k.format == 1u) {                                                 // :124-131
+        const uint32_t mi = (uint32_t)((gscl.y < gscl.z) && (gscl.y < gscl.x)) + (uint32_t)((gscl.z < gscl.y) && (gscl.z < gscl.x)) * 2u;
+        const float a0 = mi == 0u ? rot.c[0][0] : mi == 1u ? rot.c[1][0] : rot.c[2][0];
+        const float a1 = mi == 0u ? rot.c[0][1] : mi == 1u ? rot.c[1][1] : rot.c[2][1];
+        const float a2 = mi == 0u ? rot.c[0][2] : mi == 1u ? rot.c[1][2] : rot.c[2][2];
+        nrm = make_float4(a0 * 0.5f + 0.5f, a1 * 0.5f + 0.5f, a2 * 0.5f + 0.5f, gcol.w);
+    }
+    if (k.render_mode == 0 || k.render_mode == 6) out_color = gcol;               // :133-149
+    else if (k.render_mode == 1) {
+        const float nd = ((-vs.z) - k.near_far[0]) / (k.near_far[1] - k.near_far[0]);   // common.glsl:78-82
+        const float cd = clamp01(expf(-20.0f * clamp01(nd)));
+        out_color = make_float4(cd, cd, cd, gcol.w);
+    } else if (k.render_mode == 2) out_color = nrm;
+    if (k.render_mode == 3) {
+        // gl_GlobalInvocationID of the reference's dispatch (GaussiansPrepass.cpp:44-49; 16x16 local size)
+        const uint32_t gid = first + (uint32_t)lane;
+        const float fx = (float)(gid % k.global_w), fy = (float)(gid / k.global_w);
+        out_color = make_float4(random2d(fx, fy), random2d(fy, fx), random2d(fy * 1.234f, fx * 1.234f), 1.0f);
+    }
+
+    pos2d.x = pos2d.x / pos2d.w; pos2d.y = pos2d.y / pos2d.w; pos2d.z = pos2d.z / pos2d.w;   // :151
+
+    const float p00 = k.P[0], p11 = k.P[5], p32 = k.P[14];
+    const float tz_sq = vs.z * vs.z;                                             // :154-159
+    const float jsx = -(p00 * k.res[0]) / (2.0f * vs.z);
+    const float jsy = -(p11 * k.res[1]) / (2.0f * vs.z);
+    const float jtx = (p00 * vs.x * k.res[0]) / (2.0f * tz_sq);
+    const float jty = (p11 * vs.y * k.res[1]) / (2.0f * tz_sq);
+    const float jtz = ((k.near_far[1] - k.near_far[0]) * p32) / (2.0f * tz_sq);
+    M3 J, W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { J.c[c][i] = 0.0f; W.c[c][i] = k.V[c * 4 + i]; }   // :161-165
+    J.c[0][0] = jsx; J.c[1][1] = jsy; J.c[2][0] = jtx; J.c[2][1] = jty; J.c[2][2] = jtz;
+    const M3 JW = m3_mul(J, W);
+    const M3 Vp = m3_mul(m3_mul(JW, cov3d), m3_transpose(JW));                   // :168
+    float c00 = Vp.c[0][0];
+    const float c01 = Vp.c[0][1], c10 = Vp.c[1][0];
+    float c11 = Vp.c[1][1];                                                      // :170
+    c00 += 0.3f;                                                                 // :173-174
+    c11 += 0.3f;
+    const float mid = c00 + c11;
+    const float da = c00 - c11, db = 2.0f * c01;
+    const float delta = sqrtf(da * da + db * db);                                // :178
+    const float lambda1 = 0.5f * (mid + delta), lambda2 = 0.5f * (mid - delta);
+    if (lambda2 < 0.0f) vis = false;                                             // :183
+
+    const float dvy = (-c00 + c01 + lambda1) / (c01 - c11 + lambda1);            // :185
+    const float inv_len = 1.0f / sqrtf(1.0f * 1.0f + dvy * dvy);
+    const float dx = 1.0f * inv_len, dy = dvy * inv_len;
+    const float major_r = min_glsl(3.0f * sqrtf(lambda1), 1024.0f), minor_r = min_glsl(3.0f * sqrtf(lambda2), 1024.0f);
+    const float hx = k.res[0] * 0.5f, hy = k.res[1] * 0.5f;                      // :186-190
+    const float4 quad_scale = make_float4((major_r * dx) / hx, (major_r * dy) / hy, (minor_r * dy) / hx, (minor_r * (-dx)) / hy);
+    const float det = c00 * c11 - c01 * c10;                                     // common.glsl:61-76
+    float i00 = 0.0f, i01 = 0.0f, i11 = 0.0f;
+    if (det != 0.0f) { i00 = c11 / det; i01 = -c01 / det; i11 = c00 / det; }
+
+    // ---- ordered append ------------------------------------------------------------------------------------------
+    const unsigned long long mask = __ballot(vis);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    if (lane == 0 && wid + 1u < n_waves) chain_store(&chain[wid], kFlagAgg | etag | cnt);
+    // every lane holds its record in registers by now: the staging area can take the survivors
+    wave_lds_sync();
+    if (vis) {
+        float4* o = S + rank * kStageStride;
+        o[0] = pos2d;                                                            // :194-202
+        o[1] = quad_scale;
+        o[2] = out_color;
+        o[3] = make_float4(i00, i01, i11, -vs.z);
+        o[4] = make_float4(nrm.x, nrm.y, nrm.z, gpbr.x);
+        o[5] = make_float4(ws.x, ws.y, ws.z, gpbr.y);
+        s_depth[wave][rank] = vs.z;                                              // :204
+    }
+    const unsigned long long base = wid == 0u ? 0ull : lookback(chain, wid, lane, epoch, status);
+    if (lane == 0) {
+        if (wid + 1u < n_waves) chain_store(&chain[wid], kFlagPrefix | etag | ((base + cnt) & kValMask));
+        else __hip_atomic_store(total, base + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the counter read-back
+    }
+    wave_lds_sync();
+    float4* dst = quads + (size_t)base * 6;
+    const uint32_t n4 = cnt * 6u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
+        if (idx < n4) {
+            const uint32_t r = idx / 6u;
+            dst[idx] = S[r * kStageStride + (idx - r * 6u)];
+        }
+    }
+    if ((uint32_t)lane < cnt) depths[base + lane] = s_depth[wave][lane];
+}
+
+hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
+                          uint32_t epoch, unsigned long long* total, uint32_t* status, hipStream_t st) {
+    const uint32_t n_waves = (n + 63u) / 64u, nb = (n_waves + (kBlock / 64) - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kBlock), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, total, status);
+    return hipGetLastError();
+}
+
+// ---- host: the uniforms and loop invariants of the shader ----------------------------------------------------------
+// transpose(inverse(u_modelToWorld)) (:120) and inverse(mat3(u_modelToWorld)) (:102-108) do not depend on the Gaussian:
+// computed once here, with the operation order of the vendored glm 1.0.1 (glm/detail/func_matrix.inl:322-405) because the
+// reference's CPU-side execution of the shader — what the parity tests compare against — goes through glm.
+namespace {
+inline float M4(const float* m, int c, int r) { return m[c * 4 + r]; }
+}
+
+void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out) {
+    PrepassK& k = *out;
+    memcpy(k.M, p.model_to_world, sizeof k.M);
+    memcpy(k.V, p.world_to_view, sizeof k.V);
+    memcpy(k.P, p.view_to_clip, sizeof k.P);
+    const float* m = p.model_to_world;
+    {   // 4x4 inverse by cofactors, then transpose
+        const float C00 = M4(m, 2, 2) * M4(m, 3, 3) - M4(m, 3, 2) * M4(m, 2, 3), C02 = M4(m, 1, 2) * M4(m, 3, 3) - M4(m, 3, 2) * M4(m, 1, 3);
+        const float C03 = M4(m, 1, 2) * M4(m, 2, 3) - M4(m, 2, 2) * M4(m, 1, 3), C04 = M4(m, 2, 1) * M4(m, 3, 3) - M4(m, 3, 1) * M4(m, 2, 3);
+        const float C06 = M4(m, 1, 1) * M4(m, 3, 3) - M4(m, 3, 1) * M4(m, 1, 3), C07 = M4(m, 1, 1) * M4(m, 2, 3) - M4(m, 2, 1) * M4(m, 1, 3);
+        const float C08 = M4(m, 2, 1) * M4(m, 3, 2) - M4(m, 3, 1) * M4(m, 2, 2), C10 = M4(m, 1, 1) * M4(m, 3, 2) - M4(m, 3, 1) * M4(m, 1, 2);
+        const float C11 = M4(m, 1, 1) * M4(m, 2, 2) - M4(m, 2, 1) * M4(m, 1, 2), C12 = M4(m, 2, 0) * M4(m, 3, 3) - M4(m, 3, 0) * M4(m, 2, 3);
+        const float C14 = M4(m, 1, 0) * M4(m, 3, 3) - M4(m, 3, 0) * M4(m, 1, 3), C15 = M4(m, 1, 0) * M4(m, 2, 3) - M4(m, 2, 0) * M4(m, 1, 3);
+        const float C16 = M4(m, 2, 0) * M4(m, 3, 2) - M4(m, 3, 0) * M4(m, 2, 2), C18 = M4(m, 1, 0) * M4(m, 3, 2) - M4(m, 3, 0) * M4(m, 1, 2);
+        const float C19 = M4(m, 1, 0) * M4(m, 2, 2) - M4(m, 2, 0) * M4(m, 1, 2), C20 = M4(m, 2, 0) * M4(m, 3, 1) - M4(m, 3, 0) * M4(m, 2, 1);
+        const float C22 = M4(m, 1, 0) * M4(m, 3, 1) - M4(m, 3, 0) * M4(m, 1, 1), C23 = M4(m, 1, 0) * M4(m, 2, 1) - M4(m, 2, 0) * M4(m, 1, 1);
+        const float F[6][4] = { { C00, C00, C02, C03 }, { C04, C04, C06, C07 }, { C08, C08, C10, C11 },
+                                { C12, C12, C14, C15 }, { C16, C16, C18, C19 }, { C20, C20, C22, C23 } };
+        float Vv[4][4];
+        for (int r = 0; r < 4; ++r) { Vv[r][0] = M4(m, 1, r); Vv[r][1] = Vv[r][2] = Vv[r][3] = M4(m, 0, r); }
+        float inv[4][4];
+        for (int i = 0; i < 4; ++i) {
+            const float sa = (i & 1) ? -1.0f : 1.0f, sb = -sa;
+            inv[0][i] = (Vv[1][i] * F[0][i] - Vv[2][i] * F[1][i] + Vv[3][i] * F[2][i]) * sa;
+            inv[1][i] = (Vv[0][i] * F[0][i] - Vv[2][i] * F[3][i] + Vv[3][i] * F[4][i]) * sb;
+            inv[2][i] = (Vv[0][i] * F[1][i] - Vv[1][i] * F[3][i] + Vv[3][i] * F[5][i]) * sa;
+            inv[3][i] = (Vv[0][i] * F[2][i] - Vv[1][i] * F[4][i] + Vv[2][i] * F[5][i]) * sb;
+        }
+        const float d0 = M4(m, 0, 0) * inv[0][0], d1 = M4(m, 0, 1) * inv[1][0], d2 = M4(m, 0, 2) * inv[2][0], d3 = M4(m, 0, 3) * inv[3][0];
+        const float ood = 1.0f / ((d0 + d1) + (d2 + d3));
+        for (int c = 0; c < 4; ++c)
+            for (int i = 0; i < 4; ++i) k.MinvT[i * 4 + c] = inv[c][i] * ood;      // transposed on the way out
+    }
+    {   // 3x3 inverse of the upper-left block
+#define A(c_, r_) M4(m, c_, r_)
+        const float ood = 1.0f / (+A(0, 0) * (A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) - A(1, 0) * (A(0, 1) * A(2, 2) - A(2, 1) * A(0, 2)) +
+                                  A(2, 0) * (A(0, 1) * A(1, 2) - A(1, 1) * A(0, 2)));
+        float* r = k.mr_inv;   // r[c*3 + row]
+        r[0 * 3 + 0] = +(A(1, 1) * A(2, 2) - A(2, 1) * A(1, 2)) * ood;
+        r[1 * 3 + 0] = -(A(1, 0) * A(2, 2) - A(2, 0) * A(1, 2)) * ood;
+        r[2 * 3 + 0] = +(A(1, 0) * A(2, 1) - A(2, 0) * A(1, 1)) * ood;
+        r[0 * 3 + 1] = -(A(0, 1) * A(2, 2) - A(2, 1) * A(0, 2)) * ood;
+        r[1 * 3 + 1] = +(A(0, 0) * A(2, 2) - A(2, 0) * A(0, 2)) * ood;
+        r[2 * 3 + 1] = -(A(0, 0) * A(2, 1) - A(2, 0) * A(0, 1)) * ood;
+        r[0 * 3 + 2] = +(A(0, 1) * A(1, 2) - A(1, 1) * A(0, 2)) * ood;
+        r[1 * 3 + 2] = -(A(0, 0) * A(1, 2) - A(1, 0) * A(0, 2)) * ood;
+        r[2 * 3 + 2] = +(A(0, 0) * A(1, 1) - A(1, 0) * A(0, 1)) * ood;
+#undef A
+    }
+    // :95  vec3(length(M[0]), length(M[0]), length(M[1])) squared, vec4 lengths: (x*x + y*y) + (z*z + w*w)
+    const float l0 = sqrtf((m[0] * m[0] + m[1] * m[1]) + (m[2] * m[2] + m[3] * m[3]));
+    const float l1 = sqrtf((m[4] * m[4] + m[5] * m[5]) + (m[6] * m[6] + m[7] * m[7]));
+    k.ms2[0] = l0 * l0; k.ms2[1] = l0 * l0; k.ms2[2] = l1 * l1;
+    k.res[0] = (float)p.resolution[0]; k.res[1] = (float)p.resolution[1];         // glm::ivec2 -> vec2 (GaussiansPrepass.cpp:23)
+    k.near_far[0] = p.near_far[0]; k.near_far[1] = p.near_far[1];
+    k.std_dev = p.gaussian_std / (float)p.resolution_target;                      // GaussiansPrepass.cpp:18
+    k.render_mode = p.render_mode;
+    k.format = p.format;
+    k.ply_has_pbr = p.ply_has_pbr;
+    k.depth_test = p.depth_test_mesh;
+    k.depth = nullptr; k.depth_w = p.depth_w; k.depth_h = p.depth_h;
+    // GaussiansPrepass.cpp:44-49: groupsX = ceil(sqrt(groups of 256)), 16 invocations wide each
+    const uint32_t groups = (uint32_t)((n + 255u) / 256u);
+    const uint32_t gx = (uint32_t)std::ceil(std::sqrt((float)groups));
+    k.global_w = gx ? gx * 16u : 16u;
+}
+
+}  // namespace m2s

@@ -34,6 +34,25 @@ def test_struct_layouts_match_header():
     assert RECORD_FLOATS * 4 == 96
 
 
+def test_prepass_struct_layout_matches_header(tmp_path):
+    """m2s_prepass_params / m2s_quad as the C compiler lays them out == the ctypes mirror in mesh2splat_amd/prepass.py."""
+    import shutil
+    import subprocess
+    from mesh2splat_amd.prepass import PrepassParamsC
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    fields = [f[0] for f in PrepassParamsC._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "m2s.h"\nint main(void){\n'
+                   'printf("%zu %zu\\n", sizeof(m2s_prepass_params), sizeof(m2s_quad));\n' +
+                   "".join('printf("%%zu\\n", offsetof(m2s_prepass_params, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == C.sizeof(PrepassParamsC) and int(out[1]) == 96
+    assert [int(v) for v in out[2:]] == [getattr(PrepassParamsC, f).offset for f in fields]
+
+
 def test_no_cpu_fallback(hiplib):
     """Without a usable HIP device the product fails loudly instead of computing on the CPU."""
     h = C.c_void_p()
