@@ -169,6 +169,8 @@ class Converter:
             if not (hasattr(records, "data_ptr") and records.is_cuda and records.is_contiguous()):
                 raise ValueError("records must be a contiguous CUDA tensor (n, 24) float32")
             ptr, n = records.data_ptr(), int(records.shape[0])
+            if n == 0:                       # (a NULL pointer would mean "the last conversion" to the C entry point)
+                return (0, np.empty((0, 24), np.float32), np.empty(0, np.float32)) if download else 0
         vis = C.c_uint64()
         self._check(self._L.m2s_prepass(self._h, C.byref(pc), ptr, n, C.byref(vis)))
         del keep

@@ -956,6 +956,9 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     } else k.depth_test = 0;
     unsigned long long* res = &c->h_total[2 + 2 * M2S_MAX_IN_FLIGHT];
     res[0] = 0; res[1] = 0;
+#ifdef PP_BLOCKATOMIC
+    HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, 8, c->stream));
+#endif
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)c->d_quads, c->d_pp_depths, c->d_pp_chain, epoch, &res[0],
                              reinterpret_cast<uint32_t*>(&res[1]), c->stream));
