@@ -188,6 +188,8 @@ typedef struct m2s_prepass_params {
                                     HOST memory unless depth_on_device; read only when depth_test_mesh == 1               */
     uint32_t depth_w, depth_h;
     uint32_t depth_on_device;    /* 1: `depth` is a device pointer on the context's device (no copy)        */
+    uint32_t arrival_order;      /* 0: survivors in input order (reproducible).  1: in arrival order, as the reference's atomic
+                                    append leaves them (same set, nondeterministic order; ~1.6x faster)                  */
 } m2s_prepass_params;
 
 /* == QuadNdcTransformation (gaussianSplattingPrepassCS.glsl:17-24), 96 bytes */

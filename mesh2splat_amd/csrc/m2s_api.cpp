@@ -926,7 +926,7 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
         HIPCHK(c, hipMalloc((void**)&c->d_pp_depths, n * sizeof(float)));
         c->pp_cap = n;
     }
-    const uint64_t words = (n + 63) / 64;
+    const uint64_t words = (n + 63) / 64 + 1;          // [0] = the arrival-order counter, [1..] = the look-back chain
     // the chain is tagged with the low 16 bits of a launch counter instead of being cleared per launch; cleared when
     // it is (re)allocated and when the tag wraps (see next_epoch)
     bool clear_chain = false;
@@ -956,13 +956,12 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     } else k.depth_test = 0;
     unsigned long long* res = &c->h_total[2 + 2 * M2S_MAX_IN_FLIGHT];
     res[0] = 0; res[1] = 0;
-#ifdef PP_BLOCKATOMIC
-    HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, 8, c->stream));
-#endif
+    if (k.arrival_order) HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, sizeof(unsigned long long), c->stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)c->d_quads, c->d_pp_depths, c->d_pp_chain, epoch, &res[0],
-                             reinterpret_cast<uint32_t*>(&res[1]), c->stream));
+    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)c->d_quads, c->d_pp_depths, c->d_pp_chain + 1, epoch,
+                             c->d_pp_chain, &res[0], reinterpret_cast<uint32_t*>(&res[1]), c->stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (k.arrival_order) HIPCHK(c, hipMemcpyAsync(&res[0], c->d_pp_chain, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_prepass_ms, c->ev[0], c->ev[1]));
     if (reinterpret_cast<uint32_t*>(&res[1])[1]) return fail(c, M2S_ERR_HIP, "prepass: look-back chain timed out");

@@ -107,7 +107,7 @@ struct PrepassK {
     float ms2[3];                // (modelScale * modelScale)
     float res[2], near_far[2], std_dev;
     int32_t render_mode;
-    uint32_t format, ply_has_pbr, depth_test;
+    uint32_t format, ply_has_pbr, depth_test, arrival_order;
     const float* depth;          // device pointer (window-space depth, row 0 = bottom) or nullptr
     uint32_t depth_w, depth_h;
     uint32_t global_w;           // width in invocations of the reference's dispatch (gl_GlobalInvocationID of a linear index)
@@ -117,7 +117,7 @@ struct m2s_prepass_params;
 namespace m2s {
 void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out);
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
-                          uint32_t epoch, unsigned long long* total, uint32_t* status, hipStream_t st);
+                          uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st);
 
 size_t sort_temp_bytes(uint32_t n);
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,

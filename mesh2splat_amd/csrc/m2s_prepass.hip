@@ -17,6 +17,8 @@
 //            (One chain word per WAVE was 2x slower: nothing is known about a wave's survivors before its math is
 //            done, so all ~5000 resident waves publish at about the same time and each had to walk back over
 //            thousands of not-yet-prefixed words.  With 8 waves per word the walk is one 512-word poll.)
+//            m2s_prepass_params.arrival_order = 1 selects the reference's own semantics instead — survivors in arrival
+//            order — with one atomic per workgroup: no wait at all, the kernel then runs at the device's copy rate.
 #include "../../include/m2s.h"
 #include "m2s_fused_common.h"
 
@@ -70,18 +72,13 @@ __device__ __forceinline__ float random2d(float cx, float cy) {
 
 }  // namespace
 
-#ifndef PP_WAVES
-#define PP_WAVES 8
-#endif
-#ifndef PP_STAGE
-#define PP_STAGE 6
-#endif
-constexpr int kPPWaves = PP_WAVES;          // waves (= 64-record chunks) per workgroup and per chain word
+constexpr int kPPWaves = 8;                 // waves (= 64-record chunks) per workgroup and per chain word (4: -20 %, 16: -8 %)
 
 __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
                                                     float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
-                                                    unsigned long long* __restrict__ total, uint32_t* __restrict__ status) {
-    __shared__ float4 s_rec[kPPWaves][64 * PP_STAGE];   // survivors, staged for contiguous stores
+                                                    unsigned long long* __restrict__ counter, unsigned long long* __restrict__ total,
+                                                    uint32_t* __restrict__ status) {
+    __shared__ float4 s_rec[kPPWaves][64 * 6];   // survivors, staged for contiguous stores
     __shared__ float s_depth[kPPWaves][64];
     __shared__ uint32_t s_cnt[kPPWaves];
     __shared__ unsigned long long s_base;
@@ -95,18 +92,7 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     const bool valid = (uint32_t)lane < have;
     const int rl = valid ? lane : 0;
     const float4* gsrc = rec + (size_t)(first + rl) * 6;
-#ifdef PP_NT
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f* gv = reinterpret_cast<const v4f*>(gsrc);
-    v4f t_[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) t_[j] = __builtin_nontemporal_load(&gv[j]);
-#define F4(v) make_float4((v).x, (v).y, (v).z, (v).w)
-    const float4 gpos = F4(t_[0]), gcol = F4(t_[1]), gscl = F4(t_[2]), gnrm = F4(t_[3]), grot = F4(t_[4]), gpbr = F4(t_[5]);
-#undef F4
-#else
     const float4 gpos = gsrc[0], gcol = gsrc[1], gscl = gsrc[2], gnrm = gsrc[3], grot = gsrc[4], gpbr = gsrc[5];
-#endif
 
     // ---- the shader ------------------------------------------------------------------------------------------
     bool vis = valid;
@@ -127,11 +113,6 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
         if (my_depth > depth + 0.00002f) vis = false;
     }
 
-#ifdef PP_NOMATH
-    const float4 out_color = gcol, nrm = gnrm, quad_scale = gscl;
-    const float i00 = grot.x, i01 = grot.y, i11 = grot.z;
-    pos2d.x += gpbr.z;
-#else
     const float multiplier = (k.format == 0u || k.format == 3u) ? k.std_dev : 1.0f;   // :94
     // :95-96  modelScale = (|M[0]|, |M[0]|, |M[1]|) as written; k.ms2 = its square (uniform, prepared on the host)
     const float scale[3] = { (gscl.x * multiplier) * k.ms2[0], (gscl.y * multiplier) * k.ms2[1], (gscl.z * multiplier) * k.ms2[2] };
@@ -228,7 +209,6 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     const float det = c00 * c11 - c01 * c10;                                     // common.glsl:61-76
     float i00 = 0.0f, i01 = 0.0f, i11 = 0.0f;
     if (det != 0.0f) { i00 = c11 / det; i01 = -c01 / det; i11 = c00 / det; }
-#endif
 
     // ---- ordered append ------------------------------------------------------------------------------------------
     const unsigned long long mask = __ballot(vis);
@@ -236,9 +216,8 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     if (lane == 0) s_cnt[wave] = cnt;
-#ifndef PP_DIRECTST
     if (vis) {
-        float4* o = S + rank * PP_STAGE;
+        float4* o = S + rank * 6;
         o[0] = pos2d;                                                            // :194-202
         o[1] = quad_scale;
         o[2] = out_color;
@@ -247,43 +226,28 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
         o[5] = make_float4(ws.x, ws.y, ws.z, gpbr.y);
         s_depth[wave][rank] = vs.z;                                              // :204
     }
-#endif
     __syncthreads();
-    if (wave == 0) {                                   // one look-back per workgroup
+    if (wave == 0) {
         const uint32_t bid = blockIdx.x, last = gridDim.x - 1u;
         uint32_t tot = 0;
 #pragma unroll
         for (int w = 0; w < kPPWaves; ++w) tot += s_cnt[w];
-#ifdef PP_BLOCKATOMIC   // experiment: arrival order per workgroup (counter = chain[0], assumed zero at launch)
-        unsigned long long b = 0;
-        if (lane == 0) { b = atomicAdd(&chain[0], (unsigned long long)tot); s_base = b; }
-        (void)last; (void)etag;
-    }
-    if (false) {
-        const uint32_t bid = 1, last = 0; const uint32_t tot = 0; unsigned long long b = 0;
-#else
-        if (lane == 0 && bid != last) chain_store(&chain[bid], kFlagAgg | etag | tot);
-        const unsigned long long b = bid == 0u ? 0ull : lookback(chain, bid, lane, epoch, status);
-#endif
-        if (lane == 0) {
-            if (bid != last) chain_store(&chain[bid], kFlagPrefix | etag | ((b + tot) & kValMask));
-            else __hip_atomic_store(total, b + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the counter read-back
-            s_base = b;
+        if (k.arrival_order) {                         // the reference's append: one atomic per WORKGROUP (it takes one per Gaussian)
+            if (lane == 0) s_base = atomicAdd(counter, (unsigned long long)tot);
+        } else {                                       // input order: one look-back per workgroup
+            if (lane == 0 && bid != last) chain_store(&chain[bid], kFlagAgg | etag | tot);
+            const unsigned long long b = bid == 0u ? 0ull : lookback(chain, bid, lane, epoch, status);
+            if (lane == 0) {
+                if (bid != last) chain_store(&chain[bid], kFlagPrefix | etag | ((b + tot) & kValMask));
+                else __hip_atomic_store(total, b + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the counter read-back
+                s_base = b;
+            }
         }
     }
     __syncthreads();
     unsigned long long base = s_base;
 #pragma unroll
     for (int w = 0; w < kPPWaves; ++w) base += (w < wave) ? s_cnt[w] : 0u;
-#ifdef PP_DIRECTST
-    if (vis) {
-        float4* o = quads + (size_t)(base + rank) * 6;
-        o[0] = pos2d; o[1] = quad_scale; o[2] = out_color; o[3] = make_float4(i00, i01, i11, -vs.z);
-        o[4] = make_float4(nrm.x, nrm.y, nrm.z, gpbr.x); o[5] = make_float4(ws.x, ws.y, ws.z, gpbr.y);
-        depths[base + rank] = vs.z;
-    }
-}
-#else
     float4* dst = quads + (size_t)base * 6;
     const uint32_t n4 = cnt * 6u;
 #pragma unroll
@@ -291,17 +255,16 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
         const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
         if (idx < n4) {
             const uint32_t r = idx / 6u;
-            dst[idx] = S[r * PP_STAGE + (idx - r * 6u)];
+            dst[idx] = S[r * 6 + (idx - r * 6u)];
         }
     }
     if ((uint32_t)lane < cnt) depths[base + lane] = s_depth[wave][lane];
 }
-#endif
 
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
-                          uint32_t epoch, unsigned long long* total, uint32_t* status, hipStream_t st) {
+                          uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st) {
     const uint32_t n_waves = (n + 63u) / 64u, nb = (n_waves + kPPWaves - 1) / kPPWaves;
-    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, total, status);
+    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status);
     return hipGetLastError();
 }
 
@@ -373,6 +336,7 @@ void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out) {
     k.format = p.format;
     k.ply_has_pbr = p.ply_has_pbr;
     k.depth_test = p.depth_test_mesh;
+    k.arrival_order = p.arrival_order;
     k.depth = nullptr; k.depth_w = p.depth_w; k.depth_h = p.depth_h;
     // GaussiansPrepass.cpp:44-49: groupsX = ceil(sqrt(groups of 256)), 16 invocations wide each
     const uint32_t groups = (uint32_t)((n + 255u) / 256u);

@@ -28,6 +28,7 @@ class PrepassParams:
     format: int = 0                                          # 0 mesh2splat, 1 classic 3DGS .ply, 2 compressed PBR
     ply_has_pbr: bool = False
     perform_mesh_depth_test: bool = False
+    arrival_order: bool = False                              # True: survivors in arrival order (the reference's atomic append)
     mesh_depth: object = None                                # (h, w) float32 window-space depth, row 0 = bottom: numpy array
                                                              # (host) or a CUDA torch tensor (used in place)
 
@@ -38,7 +39,7 @@ class PrepassParamsC(C.Structure):
                 ("resolution", C.c_int32 * 2), ("near_far", C.c_float * 2), ("gaussian_std", C.c_float),
                 ("resolution_target", C.c_uint32), ("render_mode", C.c_int32), ("format", C.c_uint32),
                 ("ply_has_pbr", C.c_uint32), ("depth_test_mesh", C.c_uint32),
-                ("depth", C.c_void_p), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32), ("depth_on_device", C.c_uint32)]
+                ("depth", C.c_void_p), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32), ("depth_on_device", C.c_uint32), ("arrival_order", C.c_uint32)]
 
 
 def to_c(p: PrepassParams):
@@ -57,6 +58,7 @@ def to_c(p: PrepassParams):
     c.ply_has_pbr = 1 if p.ply_has_pbr else 0
     c.depth_test_mesh = 1 if p.perform_mesh_depth_test else 0
     c.depth_on_device = 0
+    c.arrival_order = 1 if p.arrival_order else 0
     if p.mesh_depth is not None and hasattr(p.mesh_depth, "data_ptr"):      # torch tensor on the device
         d = p.mesh_depth.contiguous().float()
         keep.append(d)

@@ -101,6 +101,30 @@ def test_prepass_of_the_last_conversion_and_device_depth(conv, oracle):
     assert conv.device_quads != 0 and conv.device_prepass_depths != 0
 
 
+def canonical_rows(q, d):
+    """Rows (quad + depth) as uint32 with every NaN set to one pattern, sorted lexicographically: order-free comparison."""
+    rows = np.concatenate([q, d[:, None]], axis=1).astype(np.float32)
+    u = rows.view(np.uint32).copy()
+    u[np.isnan(rows)] = 0x7FC00000
+    return u[np.lexsort(u.T[::-1])]
+
+
+@pytest.mark.parametrize("name", ["colour", "depth_test", "model_trs", "inside"])
+def test_prepass_arrival_order_yields_the_same_set(conv, oracle, name):
+    """arrival_order = 1 is the reference's own contract (atomic append): same survivors, same values, any order; quads
+    and depths stay paired."""
+    import torch
+    from dataclasses import replace
+    p = replace(dict(CASES)[name], arrival_order=True)
+    rec = np.concatenate([prepass_cases.base_records(oracle, 14, 64), prepass_cases.hostile_records(2048)])[:-13]
+    wk, wq, wd = oracle.prepass(p, rec)
+    d_rec = torch.from_numpy(rec).cuda()
+    for _ in range(3):
+        gk, gq, gd = conv.prepass(p, records=d_rec)
+        assert gk == wk
+        assert np.array_equal(canonical_rows(gq, gd), canonical_rows(wq, wd))
+
+
 def test_prepass_edge_cases(conv, oracle):
     import torch
     p = dict(CASES)["colour"]

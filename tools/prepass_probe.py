@@ -24,9 +24,10 @@ def main():
     total = c.convert(R)
     res = (1920, 1080)
     out = {"records": total}
-    for name, eye in (("outside", (1.6, 1.1, 2.3)), ("close", (0.9, 0.5, 0.9))):
+    for name, eye, arrival in (("outside", (1.6, 1.1, 2.3), False), ("close", (0.9, 0.5, 0.9), False),
+                               ("outside_arrival_order", (1.6, 1.1, 2.3), True), ("close_arrival_order", (0.9, 0.5, 0.9), True)):
         p = PrepassParams(view_mat=camera.look_at(eye, (0.1, 0.0, -0.1)), proj_mat=camera.perspective(45.0, res[0] / res[1], 0.01, 100.0),
-                          renderer_resolution=res, resolution_target=R)
+                          renderer_resolution=res, resolution_target=R, arrival_order=arrival)
         c.set_profiling(True)
         ms = []
         for _ in range(30):
