@@ -214,6 +214,16 @@ m2s_status m2s_download_prepass(m2s_ctx* ctx, m2s_quad* dst_quads, float* dst_de
 /* Duration (ms) of the last profiled prepass kernel. */
 float m2s_last_prepass_ms(const m2s_ctx* ctx);
 
+/* == RadixSortPass::execute (RadixSortPass.cpp:8-90) on the output of the last m2s_prepass: key = the raw bits of the
+ * view-space depths (radixSortPrepass.glsl:23-33), ascending, stable (LSD radix like glu::RadixSort); the quads are gathered
+ * into a second context-owned buffer in that order (radixSortGather.glsl:30-49).  *out_n = number sorted = what the
+ * reference writes to drawElementsIndirectCommand.instanceCount (count = 6, first = baseInstance = 0). */
+m2s_status m2s_sort_prepass(m2s_ctx* ctx, uint64_t* out_n);
+const void* m2s_device_sorted_quads(const m2s_ctx* ctx);     /* m2s_quad[n]  (perQuadTransformationBufferSorted) */
+m2s_status m2s_download_sorted_quads(m2s_ctx* ctx, m2s_quad* dst, uint64_t capacity);
+/* Duration (ms) of the last profiled m2s_sort_prepass (radix sort + gather). */
+float m2s_last_sort_prepass_ms(const m2s_ctx* ctx);
+
 /* ---- scene I/O == SceneManager::loadModel (minus GL) and parsers::loadPlyFile ------------------------ */
 /* Host-side scene loaded from a binary glTF file: scene-graph transforms applied, de-indexed 17-float
  * vertex buffers, fallback normals/tangents, cumulative bboxes, RGBA8 textures (PNG) — exactly what

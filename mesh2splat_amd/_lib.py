@@ -28,6 +28,7 @@ EXPORTS = (
     "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
     "m2s_io_last_error", "m2s_sort_by_depth", "m2s_device_sorted_records", "m2s_download_sorted", "m2s_last_sort_ms",
     "m2s_prepass", "m2s_device_quads", "m2s_device_prepass_depths", "m2s_download_prepass", "m2s_last_prepass_ms",
+    "m2s_sort_prepass", "m2s_device_sorted_quads", "m2s_download_sorted_quads", "m2s_last_sort_prepass_ms",
 )
 
 
@@ -111,6 +112,10 @@ def load():
         "m2s_device_prepass_depths": (vp, [vp]),
         "m2s_download_prepass": (C.c_int, [vp, vp, vp, u64]),
         "m2s_last_prepass_ms": (C.c_float, [vp]),
+        "m2s_sort_prepass": (C.c_int, [vp, C.POINTER(u64)]),
+        "m2s_device_sorted_quads": (vp, [vp]),
+        "m2s_download_sorted_quads": (C.c_int, [vp, vp, u64]),
+        "m2s_last_sort_prepass_ms": (C.c_float, [vp]),
         "m2s_last_pipeline": (C.c_int, [vp]),
         "m2s_debug_set_launch_counter": (C.c_int, [vp, u32]),
         "m2s_set_async_lanes": (C.c_int, [vp, C.c_int]),

@@ -193,6 +193,21 @@ class Converter:
     def last_prepass_ms(self) -> float:
         return float(self._L.m2s_last_prepass_ms(self._h))
 
+    def sort_prepass(self, download: bool = True):
+        """RadixSortPass on the last prepass: quads ordered by the raw bits of their view-space depth (ascending, stable).
+        -> (n, 24) float32 quads, or just n with download=False."""
+        n = C.c_uint64()
+        self._check(self._L.m2s_sort_prepass(self._h, C.byref(n)))
+        if not download:
+            return n.value
+        out = np.empty((n.value, 24), np.float32)
+        self._check(self._L.m2s_download_sorted_quads(self._h, out.ctypes.data, n.value))
+        return out
+
+    @property
+    def last_sort_prepass_ms(self) -> float:
+        return float(self._L.m2s_last_sort_prepass_ms(self._h))
+
     def set_pipeline(self, name: str):
         """'auto' (single-pass kernel or multi-pass pipeline, chosen per scene and R), 'multipass', or the single-pass
         kernel forced, in one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, workgroup-cooperative)."""

@@ -104,6 +104,9 @@ struct m2s_ctx {
     float* d_pp_depthtex = nullptr;
     uint64_t pp_depthtex_cap = 0;
     float last_prepass_ms = 0.0f;
+    void* d_sorted_quads = nullptr;          // m2s_sort_prepass
+    uint64_t sq_cap = 0, sq_n = 0;
+    float last_sort_prepass_ms = 0.0f;
 
     // measurement
     bool profiling = false;
@@ -208,6 +211,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->stream_b) { (void)hipStreamSynchronize(c->stream_b); (void)hipStreamDestroy(c->stream_b); }
     if (c->d_sorted) (void)hipFree(c->d_sorted);
     if (c->d_quads) (void)hipFree(c->d_quads);
+    if (c->d_sorted_quads) (void)hipFree(c->d_sorted_quads);
     if (c->d_pp_depths) (void)hipFree(c->d_pp_depths);
     if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
     if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
@@ -916,6 +920,7 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     if (n > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 records");
     HIPCHK(c, hipSetDevice(c->device));
     c->pp_visible = 0;
+    c->sq_n = 0;
     if (out_visible) *out_visible = 0;
     if (!n) return M2S_OK;
     if (c->pp_cap < n) {
@@ -984,6 +989,55 @@ m2s_status m2s_download_prepass(m2s_ctx* c, m2s_quad* dst_quads, float* dst_dept
 }
 
 float m2s_last_prepass_ms(const m2s_ctx* c) { return c ? c->last_prepass_ms : 0.0f; }
+
+// RadixSortPass::execute (RadixSortPass.cpp:8-90) on what the last m2s_prepass left behind.
+m2s_status m2s_sort_prepass(m2s_ctx* c, uint64_t* out_n) {
+    if (!c) return M2S_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->pp_visible;          // the atomic counter the reference reads back (RadixSortPass.cpp:18-22)
+    c->sq_n = 0;
+    if (out_n) *out_n = n;
+    if (!n) return M2S_OK;
+    if (c->sq_cap < n) {
+        if (c->d_sorted_quads) { (void)hipFree(c->d_sorted_quads); c->d_sorted_quads = nullptr; c->sq_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_sorted_quads, n * sizeof(m2s_quad)));
+        c->sq_cap = n;
+    }
+    if (c->sort_u32_cap < n) {
+        if (c->d_sort_u32) { (void)hipFree(c->d_sort_u32); c->d_sort_u32 = nullptr; c->sort_u32_cap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_sort_u32, n * 4 * sizeof(uint32_t)));
+        c->sort_u32_cap = n;
+    }
+    const size_t tb = sort_prepass_temp_bytes((uint32_t)n);
+    if (c->sort_temp_cap < tb) {
+        if (c->d_sort_temp) { (void)hipFree(c->d_sort_temp); c->d_sort_temp = nullptr; c->sort_temp_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_sort_temp, std::max<size_t>(tb, 256)));
+        c->sort_temp_cap = tb;
+    }
+    uint32_t* u = c->d_sort_u32;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, sort_prepass(c->d_pp_depths, (const float4*)c->d_quads, (uint32_t)n, u, u + n, c->d_sort_temp, c->sort_temp_cap,
+                           (float4*)c->d_sorted_quads, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_sort_prepass_ms, c->ev[0], c->ev[1]));
+    c->sq_n = n;
+    return M2S_OK;
+}
+
+const void* m2s_device_sorted_quads(const m2s_ctx* c) { return c && c->sq_n ? c->d_sorted_quads : nullptr; }
+
+m2s_status m2s_download_sorted_quads(m2s_ctx* c, m2s_quad* dst, uint64_t capacity) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!c->sq_n) return M2S_OK;
+    if (!dst) return fail(c, M2S_ERR_INVALID, "dst is NULL");
+    if (capacity < c->sq_n) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer quads than were sorted");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->d_sorted_quads, c->sq_n * sizeof(m2s_quad), hipMemcpyDeviceToHost));
+    return M2S_OK;
+}
+
+float m2s_last_sort_prepass_ms(const m2s_ctx* c) { return c ? c->last_sort_prepass_ms : 0.0f; }
 
 m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
     if (!c) return M2S_ERR_INVALID;

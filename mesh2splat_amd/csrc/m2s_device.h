@@ -119,6 +119,9 @@ void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out);
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
                           uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st);
 
+size_t sort_prepass_temp_bytes(uint32_t n);
+hipError_t sort_prepass(const float* depths, const float4* quads, uint32_t n, uint32_t* keys_out, uint32_t* vals_out, void* temp,
+                        size_t temp_bytes, float4* sorted, hipStream_t st);
 size_t sort_temp_bytes(uint32_t n);
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st);

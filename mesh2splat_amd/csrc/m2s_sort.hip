@@ -7,6 +7,7 @@
 // device radix sort (a plain library primitive, like the reference's third-party glu::RadixSort).
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "m2s_device.h"
 
@@ -50,6 +51,28 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
     if (e != hipSuccess) return e;
     const size_t nq = (size_t)n * 6;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
+    return hipGetLastError();
+}
+
+// RadixSortPass::execute proper (RadixSortPass.cpp:8-90), on the prepass output: keys are the raw bits of
+// gaussianDepthPostFiltering (radixSortPrepass.glsl:23-33 copies them and writes val = gid: here the key buffer IS the
+// depth buffer and the values come from a counting iterator, so that kernel disappears), then the gather of the
+// six-vec4 QuadNdcTransformations (radixSortGather.glsl:30-49).
+size_t sort_prepass_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+                                    (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t sort_prepass(const float* depths, const float4* quads, uint32_t n, uint32_t* keys_out, uint32_t* vals_out, void* temp,
+                        size_t temp_bytes, float4* sorted, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t*>(depths), keys_out,
+                                             rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
+    if (e != hipSuccess) return e;
+    const size_t nq = (size_t)n * 6;
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, quads, vals_out, n, sorted);
     return hipGetLastError();
 }
 

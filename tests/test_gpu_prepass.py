@@ -125,6 +125,34 @@ def test_prepass_arrival_order_yields_the_same_set(conv, oracle, name):
         assert np.array_equal(canonical_rows(gq, gd), canonical_rows(wq, wd))
 
 
+def test_sort_prepass_is_radix_sort_pass(conv, oracle):
+    """RadixSortPass (RadixSortPass.cpp:8-90) on the prepass output: key = raw bits of the view-space depth, ascending,
+    stable (LSD radix), six-vec4 gather.  Against numpy's stable argsort of the same keys on the oracle's prepass."""
+    import torch
+    p = dict(CASES)["colour"]
+    rec = np.concatenate([prepass_cases.base_records(oracle, 20, 96), prepass_cases.hostile_records(4096)])
+    rec = np.concatenate([rec, rec[:5000]])                       # duplicates: equal keys exercise stability
+    wk, wq, wd = oracle.prepass(p, rec)
+    gk, gq, gd = conv.prepass(p, records=torch.from_numpy(rec).cuda())
+    assert gk == wk
+    order = np.argsort(wd.view(np.uint32), kind="stable")
+    conv.set_profiling(True)
+    sq = conv.sort_prepass()
+    conv.set_profiling(False)
+    assert sq.shape == (wk, 24)
+    assert same_bits(sq, wq[order]).all()
+    assert conv.last_sort_prepass_ms > 0.0
+    # negative view-space z (in front of the camera) has the sign bit set: raw-bit ascending order puts the positive
+    # (behind the camera but inside the guard band) depths first, then the negative ones from nearest (-0.0...) to farthest
+    keys = sq[:, 15].copy()                                       # conic.w = -z
+    assert (np.diff((-keys).view(np.uint32).astype(np.int64)) >= 0).all()
+    # a new prepass invalidates the sorted buffer; nothing to sort -> n = 0
+    far = rec.copy()
+    far[:, 0:3] = 1e6
+    assert conv.prepass(p, records=torch.from_numpy(far).cuda())[0] == 0
+    assert conv.sort_prepass(download=False) == 0
+
+
 def test_prepass_edge_cases(conv, oracle):
     import torch
     p = dict(CASES)["colour"]
