@@ -165,6 +165,13 @@ m2s_status m2s_download_sorted(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacit
 /* Duration (ms) of the last profiled sort (key build + radix sort + gather). */
 float m2s_last_sort_ms(const m2s_ctx* ctx);
 
+/* ---- records from elsewhere == Renderer::updateGaussianBuffer after SceneManager::loadPly --------------- */
+/* Makes `n` host records (e.g. the output of m2s_read_ply) the context's current records, as the reference does with a
+ * loaded .ply (guiRendererConcreteMediator.cpp:30-34 -> glUtils::fillGaussianBufferSsbo, glUtils.cpp:676-684):
+ * m2s_num_stored / m2s_device_records / m2s_download / m2s_prepass / m2s_sort_by_depth then refer to them.  The next
+ * conversion replaces them.  (The viewer treats such records as format 1: set m2s_prepass_params.format accordingly.) */
+m2s_status m2s_upload_records(m2s_ctx* ctx, const m2s_gaussian* records, uint64_t n);
+
 /* ---- viewer prepass == GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) ---------------------------- */
 /* What the reference's compute shader gaussianSplattingPrepassCS.glsl:58-204 (+ common.glsl) does to every Gaussian
  * before it is drawn: transform, frustum cull (1.05 * w guard band), optional test against the mesh depth texture,

@@ -27,7 +27,7 @@ EXPORTS = (
     "m2s_num_triangles", "m2s_set_pipeline", "m2s_load_glb", "m2s_free_host_scene", "m2s_host_scene_num_meshes",
     "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
     "m2s_io_last_error", "m2s_sort_by_depth", "m2s_device_sorted_records", "m2s_download_sorted", "m2s_last_sort_ms",
-    "m2s_prepass", "m2s_device_quads", "m2s_device_prepass_depths", "m2s_download_prepass", "m2s_last_prepass_ms",
+    "m2s_upload_records", "m2s_prepass", "m2s_device_quads", "m2s_device_prepass_depths", "m2s_download_prepass", "m2s_last_prepass_ms",
     "m2s_sort_prepass", "m2s_device_sorted_quads", "m2s_download_sorted_quads", "m2s_last_sort_prepass_ms",
 )
 
@@ -107,6 +107,7 @@ def load():
         "m2s_convert_into": (C.c_int, [vp, u32, vp, u64, vp, C.POINTER(u64)]),
         "m2s_convert_submit": (C.c_int, [vp, u32, vp, u64, vp]),
         "m2s_convert_wait": (C.c_int, [vp, C.POINTER(u64)]),
+        "m2s_upload_records": (C.c_int, [vp, vp, u64]),
         "m2s_prepass": (C.c_int, [vp, vp, vp, u64, C.POINTER(u64)]),
         "m2s_device_quads": (vp, [vp]),
         "m2s_device_prepass_depths": (vp, [vp]),

@@ -157,6 +157,11 @@ class Converter:
     def last_sort_ms(self) -> float:
         return float(self._L.m2s_last_sort_ms(self._h))
 
+    def upload_records(self, records: np.ndarray):
+        """Renderer::updateGaussianBuffer after LoadPly: (n, 24) float32 host records become the context's current records."""
+        r = np.ascontiguousarray(records, np.float32).reshape(-1, RECORD_FLOATS)
+        self._check(self._L.m2s_upload_records(self._h, r.ctypes.data, r.shape[0]))
+
     def prepass(self, params, records=None, download: bool = True):
         """GaussiansPrepass: cull + covariance projection of the last conversion's records (or of `records`, a CUDA torch
         tensor of shape (n, 24) float32).  `params`: mesh2splat_amd.prepass.PrepassParams.

@@ -104,6 +104,8 @@ struct m2s_ctx {
     float* d_pp_depthtex = nullptr;
     uint64_t pp_depthtex_cap = 0;
     float last_prepass_ms = 0.0f;
+    void* d_loaded = nullptr;                // m2s_upload_records (a loaded .ply)
+    uint64_t loaded_cap = 0;
     void* d_sorted_quads = nullptr;          // m2s_sort_prepass
     uint64_t sq_cap = 0, sq_n = 0;
     float last_sort_prepass_ms = 0.0f;
@@ -212,6 +214,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_sorted) (void)hipFree(c->d_sorted);
     if (c->d_quads) (void)hipFree(c->d_quads);
     if (c->d_sorted_quads) (void)hipFree(c->d_sorted_quads);
+    if (c->d_loaded) (void)hipFree(c->d_loaded);
     if (c->d_pp_depths) (void)hipFree(c->d_pp_depths);
     if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
     if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
@@ -857,7 +860,7 @@ m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float g
 // RadixSortPass::execute (RadixSortPass.cpp:8-90) on the records of the last conversion.
 m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t* out_n) {
     if (!c || !world_to_view) return M2S_ERR_INVALID;
-    if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
+    if (!c->last_records) return fail(c, M2S_ERR_STATE, "no conversion has run and no records were uploaded");
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t n = c->last_stored;
     c->sorted_n = 0;
@@ -905,12 +908,32 @@ m2s_status m2s_download_sorted(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_
 
 float m2s_last_sort_ms(const m2s_ctx* c) { return c ? c->last_sort_ms : 0.0f; }
 
+// Renderer::updateGaussianBuffer after SceneManager::loadPly (guiRendererConcreteMediator.cpp:30-34; glUtils.cpp:676-684):
+// host records (e.g. from m2s_read_ply) become the context's current records.
+m2s_status m2s_upload_records(m2s_ctx* c, const m2s_gaussian* records, uint64_t n) {
+    if (!c || (!records && n)) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->loaded_cap < n) {
+        if (c->d_loaded) { (void)hipFree(c->d_loaded); c->d_loaded = nullptr; c->loaded_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_loaded, n * sizeof(m2s_gaussian)));
+        c->loaded_cap = n;
+    }
+    if (n) HIPCHK(c, hipMemcpy(c->d_loaded, records, n * sizeof(m2s_gaussian), hipMemcpyHostToDevice));
+    c->last_records = c->d_loaded ? c->d_loaded : c->d_records;
+    c->last_total = c->last_stored = n;
+    c->sorted_n = 0;
+    c->pp_visible = 0;
+    c->sq_n = 0;
+    return M2S_OK;
+}
+
 // GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) + the counter read-back that follows it (RadixSortPass.cpp:18-22).
 m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {
     if (!c || !p) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (!d_records) {
-        if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run and no records were passed");
+        if (!c->last_records) return fail(c, M2S_ERR_STATE, "no conversion has run, no records were uploaded and none were passed");
         d_records = c->last_records;
         n = c->last_stored;
     }

@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
     const bool has_batch = wave < nb_here;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
-    const unsigned long long tk0 = F2_NOW();
-    unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0;
+    [[maybe_unused]] const unsigned long long tk0 = F2_NOW();     // phase timers: live only in -DM2S_TIMING builds
+    [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0;
 
     // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
     // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed

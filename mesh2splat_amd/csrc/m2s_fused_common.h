@@ -44,7 +44,7 @@ enum : int { kNone = 0, kSmall = 1, kMedium = 2, kBig = 3 };
 
 // Rare path, deliberately NOT inlined: its closed-form span code (fp64 divisions) would otherwise add ~30
 // VGPRs of pressure to the fragment loop of every wave.  Re-derives the raster setup from global memory.
-static __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, const float* A2, const MeshParams* mp,
+[[maybe_unused]] static __device__ __noinline__ void expand_medium(const float4* A0, const float4* A1, const float* A2, const MeshParams* mp,
                                            uint32_t t, uint32_t R, uint32_t lane, uint32_t cto, uint32_t win, uint32_t wend,
                                            uint32_t* entries) {
     const float4 a0 = A0[t], a1 = A1[t];
@@ -71,7 +71,7 @@ static __device__ __noinline__ void expand_medium(const float4* A0, const float4
 // hundred entries back; a 64- or 256-entry reach cost 3-4 sequential round trips per wave.
 // Not inlined: runs once per wave.
 constexpr int kLbWindows = 8;
-static __device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t epoch,
+[[maybe_unused]] static __device__ __noinline__ unsigned long long lookback(const unsigned long long* chain, uint32_t wid, int lane, uint32_t epoch,
                                                     uint32_t* status) {
     const unsigned long long virt_prefix = kFlagPrefix | ((unsigned long long)epoch << kEpochShift);
     unsigned long long acc = 0;             // per-lane partial sum; reduced across the wave once, at the end
