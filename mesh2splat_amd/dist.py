@@ -110,3 +110,78 @@ def clamp_to_cap(counts: Sequence[int], cap: int) -> List[int]:
         out.append(k)
         left -= k
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# distributed depth sort of the merged splat buffer (SURVEY 8 f-2 at N GPUs; BASELINE config 5): sample sort
+# ---------------------------------------------------------------------------------------------------
+def depth_keys(records, world_to_view):
+    """RadixSortPass keys of (n, 24) records: the raw bits of view-space z = row 2 of world_to_view * (P, 1), as int64 in
+    [0, 2^32).  world_to_view: 16 floats, column-major (glm).  Same association as the device key kernel
+    (m2s_sort.hip k_depth_keys): ((v02*x + v12*y) + v22*z) + v32, every operation rounded separately."""
+    import torch
+    v = [float(np.float32(x)) for x in np.asarray(world_to_view, np.float32).reshape(16)]
+    x, y, z = records[:, 0], records[:, 1], records[:, 2]
+    zz = ((x * v[2] + y * v[6]) + z * v[10]) + v[14]
+    return zz.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+
+
+def _stable_sort(keys, payload):
+    import torch
+    k, order = torch.sort(keys, stable=True)
+    return k, payload.index_select(0, order)
+
+
+def sample_sort(keys, payload, local_sort=None, samples_per_rank: int = 256):
+    """Globally stable sort of (key, payload) pairs spread over the ranks of the default process group.
+
+    keys: (n_r,) int64 tensor; payload: (n_r, ...) tensor on the same device.  Afterwards rank r holds the r-th
+    contiguous slice of the sequence obtained by stably sorting the rank-major concatenation of all inputs (ties keep
+    (source rank, local position) order) — i.e. concatenating the results in rank order IS the single-GPU result.
+
+    Sample sort, one exchange: local sort -> `samples_per_rank` evenly spaced keys per rank, all-gathered -> world-1
+    splitters -> every key range goes to one rank (equal keys never straddle ranks) with ONE all-to-all of counts and
+    ONE all-to-all-v of keys and of payloads (RCCL point-to-point over xGMI: every rank talks to every other directly,
+    which is the pattern the links are built for) -> local stable sort of the received runs.
+    `local_sort(keys, payload) -> (keys, payload)` must be stable; default: torch.sort (rocPRIM radix sort on the GPU)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    local_sort = local_sort or _stable_sort
+    keys, payload = local_sort(keys, payload)
+    if world == 1:
+        return keys, payload
+    n = int(keys.shape[0])
+    dev = keys.device
+    s = int(samples_per_rank)
+    big = torch.iinfo(torch.int64).max
+    mine = torch.full((s + 1,), big, dtype=torch.int64, device=dev)
+    take = min(s, n)
+    if take:
+        pos = ((torch.arange(take, device=dev, dtype=torch.int64) + 1) * n) // (take + 1)
+        mine[:take] = keys[pos.clamp_(max=n - 1)]
+    mine[s] = take
+    allm = torch.empty(world * (s + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allm, mine)
+    allm = allm.view(world, s + 1)
+    valid = torch.cat([allm[r, : int(allm[r, s])] for r in range(world)])
+    valid, _ = torch.sort(valid)
+    m = int(valid.shape[0])
+    if m:
+        cut = (torch.arange(1, world, device=dev, dtype=torch.int64) * m) // world
+        splitters = valid[cut.clamp_(max=m - 1)]
+    else:
+        splitters = torch.full((world - 1,), big, dtype=torch.int64, device=dev)
+    # keys < splitters[0] -> rank 0; splitters[j-1] <= key < splitters[j] -> rank j
+    bounds = torch.searchsorted(keys, splitters, right=False)
+    edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), bounds.to(torch.int64),
+                       torch.tensor([n], dtype=torch.int64, device=dev)])
+    send_counts = (edges[1:] - edges[:-1]).contiguous()
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = [int(x) for x in send_counts.tolist()], [int(x) for x in recv_counts.tolist()]
+    rk = torch.empty(sum(rc), dtype=keys.dtype, device=dev)
+    dist.all_to_all_single(rk, keys.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+    rp = torch.empty((sum(rc),) + tuple(payload.shape[1:]), dtype=payload.dtype, device=dev)
+    dist.all_to_all_single(rp, payload.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+    return local_sort(rk, rp)      # runs arrive in source-rank order, each sorted: a stable sort keeps ties in that order

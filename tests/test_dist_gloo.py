@@ -74,3 +74,61 @@ def test_shard_ranges_are_contiguous_and_balanced(oracle):
     assert m2d.shard_ranges(np.zeros(0, np.float32), 4) == [(0, 0)] * 4
     assert m2d.offsets_from_counts([3, 0, 5]) == [0, 3, 3, 8]
     assert m2d.clamp_to_cap([3, 4, 5], 6) == [3, 3, 0] and m2d.clamp_to_cap([3, 4], 0) == [3, 4]
+
+
+def _sort_worker(rank, world, port, case, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, payload = _sort_inputs(case, world)[rank]
+        k, p = m2d.sample_sort(torch.from_numpy(keys), torch.from_numpy(payload), samples_per_rank=16)
+        np.save(os.path.join(result_dir, f"k_{rank}.npy"), k.numpy())
+        np.save(os.path.join(result_dir, f"p_{rank}.npy"), p.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _sort_inputs(case, world):
+    """per rank: (keys int64 (n,), payload float32 (n, 24)) — records with payload[:, 22:24] = (rank, local index)"""
+    rng = np.random.default_rng(7)
+    out = []
+    for r in range(world):
+        n = {"random": 3000 + 517 * r, "one_empty": 0 if r == 1 else 2000, "all_equal": 1500, "few_distinct": 4000,
+             "all_empty": 0}[case]
+        rec = rng.normal(size=(n, 24)).astype(np.float32)
+        if case == "all_equal":
+            rec[:, 0:3] = 0.25
+        if case == "few_distinct":
+            rec[:, 0:3] = rng.integers(0, 4, size=(n, 3)).astype(np.float32)
+        rec[:, 22] = r
+        rec[:, 23] = np.arange(n)
+        view = np.eye(4, dtype=np.float32)
+        view[3, 2] = -3.0                                     # column-major: translation z
+        keys = m2d.depth_keys(torch.from_numpy(rec), view.reshape(16)).numpy()
+        out.append((keys, rec))
+    return out
+
+
+@pytest.mark.parametrize("world,case", [(2, "random"), (3, "random"), (3, "one_empty"), (2, "all_equal"), (3, "few_distinct"),
+                                        (2, "all_empty")])
+def test_sample_sort_equals_single_stable_sort(tmp_path, world, case):
+    """Distributed depth sort (BASELINE config 5's final radix sort at N GPUs): concatenating the ranks' results gives
+    exactly the stable sort of the rank-major concatenation of the inputs — keys, payloads and tie order."""
+    port = _free_port()
+    mp.spawn(_sort_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    ins = _sort_inputs(case, world)
+    keys = np.concatenate([k for k, _ in ins])
+    rec = np.concatenate([p for _, p in ins])
+    order = np.argsort(keys, kind="stable")
+    got_k = np.concatenate([np.load(tmp_path / f"k_{r}.npy") for r in range(world)])
+    got_p = np.concatenate([np.load(tmp_path / f"p_{r}.npy") for r in range(world)])
+    assert np.array_equal(got_k, keys[order])
+    assert np.array_equal(got_p.view(np.uint32), rec[order].view(np.uint32))
+    if case == "random":                                       # the sample-based splitters balance the ranks
+        sizes = [np.load(tmp_path / f"k_{r}.npy").shape[0] for r in range(world)]
+        assert max(sizes) < 1.5 * sum(sizes) / world
+    # the key function itself: raw bits of fp32 view-space z, non-negative int64
+    assert keys.dtype == np.int64 and (keys >= 0).all() and (keys < 2 ** 32).all()
+    z = ((rec[:, 0] * np.float32(0) + rec[:, 1] * np.float32(0)) + rec[:, 2] * np.float32(1)) + np.float32(-3.0)
+    assert np.array_equal(keys, z.astype(np.float32).view(np.uint32).astype(np.int64))
