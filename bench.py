@@ -173,7 +173,14 @@ def viewer_extra(conv, R, total):
         m = float(np.median(ms[2:]))
         b = 96 * total + 100 * vis
         out[key] = {"visible": int(vis), "kernel_ms": m, "algorithmic_bytes": int(b), "GBps": b / m / 1e6,
-                    "frac_of_hbm_peak": b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "frac_of_hbm_peak": b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
+        try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_prepass.sh), same input and camera
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f)
+            if t.get("k_" + key + "_detail", {}).get("records") == int(total):
+                out[key]["traffic"] = t.get("k_" + key + "_hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
     sms = []
     for _ in range(6):
         conv.sort_prepass(download=False)

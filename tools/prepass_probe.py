@@ -18,6 +18,7 @@ from mesh2splat_amd.prepass import PrepassParams  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 289
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    only = sys.argv[3] if len(sys.argv) > 3 else ""          # "input" / "arrival": just that append order, whole sphere in view
     c = Converter(0)
     c.upload_scene(synth.cube_sphere(n, tex_size=2048 if n >= 200 else 256))
     c.set_max_gaussians(0)
@@ -26,6 +27,8 @@ def main():
     out = {"records": total}
     for name, eye, arrival in (("outside", (1.6, 1.1, 2.3), False), ("close", (0.9, 0.5, 0.9), False),
                                ("outside_arrival_order", (1.6, 1.1, 2.3), True), ("close_arrival_order", (0.9, 0.5, 0.9), True)):
+        if only and name != {"input": "outside", "arrival": "outside_arrival_order"}[only]:
+            continue
         p = PrepassParams(view_mat=camera.look_at(eye, (0.1, 0.0, -0.1)), proj_mat=camera.perspective(45.0, res[0] / res[1], 0.01, 100.0),
                           renderer_resolution=res, resolution_target=R, arrival_order=arrival)
         c.set_profiling(True)
