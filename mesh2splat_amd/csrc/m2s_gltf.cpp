@@ -222,6 +222,25 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
     catch (const std::exception& e) { err = e.what(); return false; }
     const auto& doc = g.doc;
 
+    // ---- extensions: the reference's loader (tiny_gltf + SceneManager.cpp) knows none.  Where geometry is stored in an
+    // extension's own encoding it would read garbage; refuse those files instead.  Extensions that only refine the
+    // appearance are ignored, as the reference ignores them, and reported.
+    {
+        const auto& req = doc["extensionsRequired"];
+        for (size_t i = 0; i < req.size(); ++i) {
+            const std::string e = req[i].string_or("");
+            if (e == "KHR_draco_mesh_compression" || e == "EXT_meshopt_compression" || e == "KHR_mesh_quantization") {
+                err = "required glTF extension " + e + " is not supported (geometry is not stored as plain accessors)";
+                return false;
+            }
+        }
+        const auto& used = doc["extensionsUsed"];
+        for (size_t i = 0; i < used.size(); ++i) {
+            const std::string e = used[i].string_or("");
+            if (!e.empty()) scene.warnings.push_back("glTF extension " + e + " is ignored (as by the reference's loader)");
+        }
+    }
+
     // ---- scene graph -> (mesh, world matrix) instances: SceneManager.cpp:211-281 ---------------------
     struct Inst { long long mesh; M4 world; };
     std::vector<Inst> insts;

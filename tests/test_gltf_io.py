@@ -227,3 +227,38 @@ def test_loader_transforms_match_glm():
         pytest.skip("oracle/_ref not built (reference tree absent on this machine)")
     r = subprocess.run([exe, "20000"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout
+
+
+def _patch_glb_json(src: str, dst: str, **extra):
+    """Rewrite a .glb with extra top-level JSON members (test helper)."""
+    import json
+    import struct
+    blob = open(src, "rb").read()
+    jlen = struct.unpack_from("<I", blob, 12)[0]
+    doc = json.loads(blob[20:20 + jlen])
+    doc.update(extra)
+    j = json.dumps(doc).encode()
+    j += b" " * (-len(j) % 4)
+    rest = blob[20 + jlen:]
+    out = struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(j) + len(rest)) + struct.pack("<II", len(j), 0x4E4F534A) + j + rest
+    open(dst, "wb").write(out)
+
+
+def test_gltf_extensions(tmp_path, hiplib):
+    """Geometry-encoding extensions the reference's loader would misread are refused with a clear message; appearance
+    extensions are ignored (as the reference ignores them) and reported."""
+    from mesh2splat_amd import _lib
+    scene = synth.cube_sphere(2, tex_size=8)
+    base = str(tmp_path / "base.glb")
+    gltf_io.write_glb(scene, base)
+    used = str(tmp_path / "used.glb")
+    _patch_glb_json(base, used, extensionsUsed=["KHR_texture_transform", "KHR_materials_emissive_strength"])
+    loaded = gltf_io.load_glb(used)
+    ref = gltf_io.load_glb(base)
+    assert np.array_equal(loaded.meshes[0].vertices, ref.meshes[0].vertices)
+    assert any("KHR_texture_transform" in w for w in loaded.warnings) and not any("KHR_" in w for w in ref.warnings)
+    for ext in ("KHR_draco_mesh_compression", "EXT_meshopt_compression", "KHR_mesh_quantization"):
+        bad = str(tmp_path / "bad.glb")
+        _patch_glb_json(base, bad, extensionsUsed=[ext], extensionsRequired=[ext])
+        with pytest.raises(_lib.M2SError, match=ext):
+            gltf_io.load_glb(bad)
