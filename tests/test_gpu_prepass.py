@@ -180,7 +180,7 @@ def test_prepass_edge_cases(conv, oracle):
     p = dict(CASES)["colour"]
     one = prepass_cases.base_records(oracle, 6, 24)[:1]
     # nothing / one record / exactly one wave / one wave + 1 / everything culled / nothing culled
-    for n in (1, 63, 64, 65, 257):
+    for n in (1, 63, 64, 65, 257, 511, 512, 513, 1024, 1537):       # around wave (64) and workgroup (512) boundaries
         rec = np.tile(one, (n, 1))
         rec[:, 0:3] += np.linspace(0, 0.05, n, dtype=np.float32)[:, None]
         assert_prepass_matches(conv.prepass(p, records=torch.from_numpy(rec).cuda()), oracle.prepass(p, rec), 0, f"n={n}")
