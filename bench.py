@@ -73,6 +73,17 @@ def usable_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene_one_mesh, R, budget_s, gpu_total=None):
     """Oracle (CPU port of the reference path) on the host cores: same workload, same timed region as the
     GPU (geometry + textures + mip chains resident, output buffer allocated -> records + count)."""
@@ -99,10 +110,13 @@ def cpu_baseline(scene_one_mesh, R, budget_s, gpu_total=None):
             "ms_per_mesh": best * 1e3,
             "single_thread": {"value": total / res["one_core"][0], "ms_per_mesh": res["one_core"][0] * 1e3}}
     port["counter_equals_gpu"] = None if gpu_total is None else bool(total == gpu_total)
+    host = {"cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": cores}
     ref = reference_baseline(scene_one_mesh, R, total if gpu_total is None else gpu_total)
     if ref is None:
+        port["host"] = host
         return port
     ref["port"] = port          # the multi-core figure of our own CPU restatement, for scale
+    ref["host"] = host
     return ref
 
 
