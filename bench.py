@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
+    ap.add_argument("--gather-direct", action="store_true", help="also time the exact-size all-pairs record exchange (dist.all_gather_records)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
     ap.add_argument("--no-viewer-extra", action="store_true", help="skip the prepass / depth-sort measurement after the timed region")
     ap.add_argument("--overlap-extra", action="store_true",
@@ -443,6 +444,21 @@ def main():
         dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
         gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
                   "what": "convert + padded RCCL all-gather of all records to every rank"}
+        if a.gather_direct:      # the exact-size all-pairs schedule of dist.all_gather_records (grouped isend / irecv)
+            from mesh2splat_amd import dist as m2d
+            cl = [int(x) for x in counts.tolist()]
+            for _ in range(2):
+                m2d.all_gather_records(out[: cl[rank]], cl)
+            sync()
+            g0 = time.perf_counter()
+            for _ in range(reps):
+                step_sync()
+                m2d.all_gather_records(out[: cl[rank]], cl)
+            sync()
+            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+            dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+            gather["direct"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()),
+                                "what": "convert + exact-size all-pairs exchange (isend/irecv group) into the merged buffer"}
 
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran

@@ -79,14 +79,33 @@ def offsets_from_counts(counts: Sequence[int]) -> List[int]:
     return off
 
 
-def all_gather_records(local, counts: Sequence[int]):
-    """Concatenate per-rank record blocks (n_r, 24) in rank order on every rank.
-    RCCL has no all-gather-v: blocks are padded to the largest count for a single
-    all_gather_into_tensor (one collective, large message), then compacted."""
+def all_gather_records(local, counts: Sequence[int], mode: str = "direct"):
+    """Concatenate per-rank record blocks (n_r, 24) in rank order on every rank (an all-gather-v; RCCL has no native one).
+
+    mode "direct" (default): every rank sends its block straight to every other rank and receives each peer's block at its
+    final offset in the merged buffer — exact sizes, no padding, no compaction copy, and on xGMI's all-to-all point-to-point
+    links every link carries exactly one block (grouped isend / irecv = one RCCL group call).
+    mode "padded": blocks padded to the largest count for a single all_gather_into_tensor, then compacted."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size()
-    assert len(counts) == world and local.shape[0] == counts[dist.get_rank()]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert len(counts) == world and local.shape[0] == counts[rank]
+    if mode == "direct":
+        off = offsets_from_counts(counts)
+        merged = torch.empty((off[-1],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = local.contiguous()
+        merged[off[rank]: off[rank + 1]].copy_(local)
+        ops = []
+        for step in range(1, world):                      # peer order staggered per rank: no two ranks start on the same peer
+            dst, src = (rank + step) % world, (rank - step) % world
+            if int(counts[rank]):
+                ops.append(dist.P2POp(dist.isend, local, dst))
+            if int(counts[src]):
+                ops.append(dist.P2POp(dist.irecv, merged[off[src]: off[src + 1]], src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return merged
     nmax = max(1, max(int(c) for c in counts))
     send = local
     if local.shape[0] != nmax:

@@ -36,6 +36,8 @@ def _worker(rank, world, port, R, cap, result_dir):
         assert counts[rank] == total
         keep = m2d.clamp_to_cap(counts, cap)
         merged = m2d.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep)
+        padded = m2d.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep, mode="padded")
+        assert torch.equal(merged.view(torch.int32), padded.view(torch.int32))     # both exchange schedules agree
         np.save(os.path.join(result_dir, f"merged_{rank}.npy"), merged.numpy())
         np.save(os.path.join(result_dir, f"counts_{rank}.npy"), np.asarray(counts))
     finally:
