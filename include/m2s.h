@@ -196,7 +196,7 @@ typedef struct m2s_prepass_params {
     uint32_t depth_w, depth_h;
     uint32_t depth_on_device;    /* 1: `depth` is a device pointer on the context's device (no copy)        */
     uint32_t arrival_order;      /* 0: survivors in input order (reproducible).  1: in arrival order, as the reference's atomic
-                                    append leaves them (same set, nondeterministic order; ~1.6x faster)                  */
+                                    append leaves them (same set, nondeterministic order; ~1.4x faster)                  */
 } m2s_prepass_params;
 
 /* == QuadNdcTransformation (gaussianSplattingPrepassCS.glsl:17-24), 96 bytes */
