@@ -72,29 +72,10 @@ __device__ __forceinline__ float random2d(float cx, float cy) {
 
 }  // namespace
 
-constexpr uint32_t kPPDelayGrid = 2048;     // grids at least this large (~3 rounds of resident workgroups) delay their look-back
-constexpr int kPPWaves = 8;                 // waves (= 64-record chunks) per workgroup and per chain word (4: -20 %, 16: -8 %)
-
-__global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
-                                                    float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
-                                                    unsigned long long* __restrict__ counter, unsigned long long* __restrict__ total,
-                                                    uint32_t* __restrict__ status) {
-    __shared__ float4 s_rec[kPPWaves][64 * 6];   // survivors, staged for contiguous stores
-    __shared__ float s_depth[kPPWaves][64];
-    __shared__ uint32_t s_cnt[kPPWaves];
-    __shared__ unsigned long long s_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t wid = blockIdx.x * kPPWaves + wave, n_waves = (n + 63u) / 64u;
-    const uint32_t first = wid * 64u, have = wid < n_waves ? min(64u, n - first) : 0u;   // waves past the end carry nothing
-    float4* S = s_rec[wave];
-
-    // ---- load: each lane reads its own record (six 16-byte loads, 96-byte lane stride).  The wave's 6 KiB are contiguous,
-    // so every cache line fetched is fully used; measured 8 % faster than six 1 KiB-coalesced loads transposed through LDS.
-    const bool valid = (uint32_t)lane < have;
-    const int rl = valid ? lane : 0;
-    const float4* gsrc = rec + (size_t)(first + rl) * 6;
-    const float4 gpos = gsrc[0], gcol = gsrc[1], gscl = gsrc[2], gnrm = gsrc[3], grot = gsrc[4], gpbr = gsrc[5];
-
+// gaussianSplattingPrepassCS.glsl:58-204 for one Gaussian (g: its six vec4, gid: its index = the reference's linear invocation
+// id).  Returns whether it survives; q / depth_vs are what the shader stores for a survivor.
+__device__ __forceinline__ bool prepass_one(const PrepassK& k, const float4 (&g)[6], uint32_t gid, bool valid, float4 (&q)[6], float& depth_vs) {
+    const float4 gpos = g[0], gcol = g[1], gscl = g[2], gnrm = g[3], grot = g[4], gpbr = g[5];
     // ---- the shader ------------------------------------------------------------------------------------------
     bool vis = valid;
     const float4 ws = m4_mul(k.M, gpos.x, gpos.y, gpos.z, 1.0f);                 // :67
@@ -168,8 +149,7 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     } else if (k.render_mode == 2) out_color = nrm;
     if (k.render_mode == 3) {
         // gl_GlobalInvocationID of the reference's dispatch (GaussiansPrepass.cpp:44-49; 16x16 local size)
-        const uint32_t gid = first + (uint32_t)lane;
-        const float fx = (float)(gid % k.global_w), fy = (float)(gid / k.global_w);
+                const float fx = (float)(gid % k.global_w), fy = (float)(gid / k.global_w);
         out_color = make_float4(random2d(fx, fy), random2d(fy, fx), random2d(fy * 1.234f, fx * 1.234f), 1.0f);
     }
 
@@ -211,22 +191,71 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     float i00 = 0.0f, i01 = 0.0f, i11 = 0.0f;
     if (det != 0.0f) { i00 = c11 / det; i01 = -c01 / det; i11 = c00 / det; }
 
-    // ---- ordered append ------------------------------------------------------------------------------------------
-    const unsigned long long mask = __ballot(vis);
-    const uint32_t cnt = (uint32_t)__popcll(mask);
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
-    if (lane == 0) s_cnt[wave] = cnt;
-    if (vis) {
-        float4* o = S + rank * 6;
-        o[0] = pos2d;                                                            // :194-202
-        o[1] = quad_scale;
-        o[2] = out_color;
-        o[3] = make_float4(i00, i01, i11, -vs.z);
-        o[4] = make_float4(nrm.x, nrm.y, nrm.z, gpbr.x);
-        o[5] = make_float4(ws.x, ws.y, ws.z, gpbr.y);
-        s_depth[wave][rank] = vs.z;                                              // :204
+    q[0] = pos2d;                                                                // :194-202
+    q[1] = quad_scale;
+    q[2] = out_color;
+    q[3] = make_float4(i00, i01, i11, -vs.z);
+    q[4] = make_float4(nrm.x, nrm.y, nrm.z, gpbr.x);
+    q[5] = make_float4(ws.x, ws.y, ws.z, gpbr.y);
+    depth_vs = vs.z;                                                             // :204
+    return vis;
+}
+
+constexpr uint32_t kPPDelayGrid = 2048;     // grids at least this large (~3 rounds of resident workgroups) delay their look-back
+constexpr int kPPWaves = 8;                 // waves per workgroup = per chain word (4: -20 %, 16: -8 %)
+// Gaussians per lane (a wave takes kPPRec x 64 consecutive records).  2 was measured: more bytes in flight per workgroup help
+// when many Gaussians are culled (close-up, input order: 0.129 -> 0.115 ms; 685 k records: 0.043 -> 0.037 ms) but not with
+// everything in view (0.145 -> 0.143 ms), and cost in arrival order (0.103 -> 0.110 ms) and on small inputs (fewer
+// workgroups than CUs).  Kept at 1.
+constexpr int kPPRec = 1;
+constexpr uint32_t kPPTile = kPPWaves * 64u * kPPRec;   // records per workgroup
+
+__global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
+                                                    float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
+                                                    unsigned long long* __restrict__ counter, unsigned long long* __restrict__ total,
+                                                    uint32_t* __restrict__ status) {
+    __shared__ float4 s_rec[kPPWaves][64 * 6];   // survivors of ONE 64-record group, staged for contiguous stores
+    __shared__ float s_depth[kPPWaves][64];
+    __shared__ uint32_t s_cnt[kPPWaves];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * kPPTile + (uint32_t)wave * (64u * kPPRec);   // this wave's first record
+    float4* S = s_rec[wave];
+
+    // ---- load + math.  Each lane reads its own records (six 16-byte loads each, 96-byte lane stride; a group's 6 KiB are
+    // contiguous, so every fetched line is fully used — 8 % faster than 1 KiB-coalesced loads transposed through LDS).  All
+    // groups' loads are issued before the first math: kPPRec x 96 bytes in flight per lane.  The survivors of group 0 go to
+    // the staging area at once; those of the later groups wait in registers until group 0 has been written out.
+    float4 g[kPPRec][6];
+    bool valid[kPPRec];
+#pragma unroll
+    for (int r = 0; r < kPPRec; ++r) {
+        const uint32_t gid = first + (uint32_t)r * 64u + (uint32_t)lane;
+        valid[r] = gid < n;
+        const float4* gsrc = rec + (size_t)(valid[r] ? gid : 0u) * 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) g[r][j] = gsrc[j];
     }
+    float4 q[kPPRec][6];
+    float dvs[kPPRec];
+    bool vis[kPPRec];
+    uint32_t cnt[kPPRec], rank[kPPRec], wcnt = 0;
+#pragma unroll
+    for (int r = 0; r < kPPRec; ++r) {
+        vis[r] = prepass_one(k, g[r], first + (uint32_t)r * 64u + (uint32_t)lane, valid[r], q[r], dvs[r]);
+        const unsigned long long mask = __ballot(vis[r]);
+        cnt[r] = (uint32_t)__popcll(mask);
+        rank[r] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        wcnt += cnt[r];
+        if (r == 0 && vis[0]) {
+            float4* o = S + rank[0] * 6;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) o[j] = q[0][j];
+            s_depth[wave][rank[0]] = dvs[0];
+        }
+    }
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    if (lane == 0) s_cnt[wave] = wcnt;
     __syncthreads();
     if (wave == 0) {
         const uint32_t bid = blockIdx.x, last = gridDim.x - 1u;
@@ -263,22 +292,34 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     unsigned long long base = s_base;
 #pragma unroll
     for (int w = 0; w < kPPWaves; ++w) base += (w < wave) ? s_cnt[w] : 0u;
-    float4* dst = quads + (size_t)base * 6;
-    const uint32_t n4 = cnt * 6u;
+    // ---- stores: group after group through the staging area, each a contiguous run of float4 ---------------------------------
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
-        if (idx < n4) {
-            const uint32_t r = idx / 6u;
-            dst[idx] = S[r * 6 + (idx - r * 6u)];
+    for (int r = 0; r < kPPRec; ++r) {
+        if (r > 0) {
+            wave_lds_sync();                          // the previous group has left the staging area
+            if (vis[r]) {
+                float4* o = S + rank[r] * 6;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o[j] = q[r][j];
+                s_depth[wave][rank[r]] = dvs[r];
+            }
+            wave_lds_sync();
         }
+        float4* dst = quads + (size_t)base * 6;
+        const uint32_t n4 = cnt[r] * 6u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
+            if (idx < n4) dst[idx] = S[idx];
+        }
+        if ((uint32_t)lane < cnt[r]) depths[base + lane] = s_depth[wave][lane];
+        base += cnt[r];
     }
-    if ((uint32_t)lane < cnt) depths[base + lane] = s_depth[wave][lane];
 }
 
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
                           uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st) {
-    const uint32_t n_waves = (n + 63u) / 64u, nb = (n_waves + kPPWaves - 1) / kPPWaves;
+    const uint32_t nb = (n + kPPTile - 1u) / kPPTile;
     hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status);
     return hipGetLastError();
 }
