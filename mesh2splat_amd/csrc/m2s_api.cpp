@@ -914,13 +914,14 @@ m2s_status m2s_upload_records(m2s_ctx* c, const m2s_gaussian* records, uint64_t 
     if (!c || (!records && n)) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->loaded_cap < n) {
+    const uint64_t want = std::max<uint64_t>(n, 1);     // an empty upload still yields a valid (empty) record buffer
+    if (c->loaded_cap < want) {
         if (c->d_loaded) { (void)hipFree(c->d_loaded); c->d_loaded = nullptr; c->loaded_cap = 0; }
-        HIPCHK(c, hipMalloc(&c->d_loaded, n * sizeof(m2s_gaussian)));
-        c->loaded_cap = n;
+        HIPCHK(c, hipMalloc(&c->d_loaded, want * sizeof(m2s_gaussian)));
+        c->loaded_cap = want;
     }
     if (n) HIPCHK(c, hipMemcpy(c->d_loaded, records, n * sizeof(m2s_gaussian), hipMemcpyHostToDevice));
-    c->last_records = c->d_loaded ? c->d_loaded : c->d_records;
+    c->last_records = c->d_loaded;
     c->last_total = c->last_stored = n;
     c->sorted_n = 0;
     c->pp_visible = 0;

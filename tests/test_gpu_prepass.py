@@ -173,6 +173,9 @@ def test_load_ply_then_prepass_and_sort(conv, oracle, fmt, has_pbr):
     assert_prepass_matches(conv.prepass(p), want, 0, f"loaded ply fmt {fmt}")
     sq = conv.sort_prepass()
     assert same_bits(sq, want[1][np.argsort(want[2].view(np.uint32), kind="stable")]).all()
+    if fmt == 0:                                   # an empty .ply: everything downstream sees zero records
+        conv.upload_records(rec[:0])
+        assert conv.prepass(p)[0] == 0 and conv.sort_prepass(download=False) == 0 and conv.download().shape[0] == 0
 
 
 def test_prepass_edge_cases(conv, oracle):
