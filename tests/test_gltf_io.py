@@ -262,3 +262,19 @@ def test_gltf_extensions(tmp_path, hiplib):
         _patch_glb_json(base, bad, extensionsUsed=[ext], extensionsRequired=[ext])
         with pytest.raises(_lib.M2SError, match=ext):
             gltf_io.load_glb(bad)
+
+
+def test_loader_threads_do_not_change_the_result(tmp_path, hiplib, monkeypatch):
+    """Large meshes are de-indexed, and embedded images decoded, by several host threads: same bytes as the serial run."""
+    scene = synth.cube_sphere(80, tex_size=64)                      # 76 800 triangles: above the per-thread grain
+    p = str(tmp_path / "big.glb")
+    gltf_io.write_glb(scene, p, with_tangents=False)                # exercises the fallback tangents too
+    monkeypatch.setenv("M2S_HOST_THREADS", "1")
+    serial = gltf_io.load_glb(p)
+    for threads in ("2", "7"):
+        monkeypatch.setenv("M2S_HOST_THREADS", threads)
+        par = gltf_io.load_glb(p)
+        assert np.array_equal(par.meshes[0].vertices.view(np.uint32), serial.meshes[0].vertices.view(np.uint32))
+        for k, t in serial.meshes[0].textures.items():
+            assert np.array_equal(par.meshes[0].textures[k], t)
+        assert np.array_equal(par.meshes[0].bbox_min, serial.meshes[0].bbox_min)
