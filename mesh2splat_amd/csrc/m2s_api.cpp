@@ -4,6 +4,7 @@
 #include "../../include/m2s.h"
 #include <cstdlib>
 #include "m2s_device.h"
+#include "m2s_ply.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -104,6 +105,7 @@ struct m2s_ctx {
     float* d_pp_depthtex = nullptr;
     uint64_t pp_depthtex_cap = 0;
     float last_prepass_ms = 0.0f;
+    m2s_gaussian* h_export[2] = { nullptr, nullptr };   // pinned chunk buffers of m2s_export_ply
     void* d_loaded = nullptr;                // m2s_upload_records (a loaded .ply)
     uint64_t loaded_cap = 0;
     void* d_sorted_quads = nullptr;          // m2s_sort_prepass
@@ -215,6 +217,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_quads) (void)hipFree(c->d_quads);
     if (c->d_sorted_quads) (void)hipFree(c->d_sorted_quads);
     if (c->d_loaded) (void)hipFree(c->d_loaded);
+    for (int k = 0; k < 2; ++k) if (c->h_export[k]) (void)hipHostFree(c->h_export[k]);
     if (c->d_pp_depths) (void)hipFree(c->d_pp_depths);
     if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
     if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
@@ -846,13 +849,31 @@ m2s_status m2s_download_triangle_counts(m2s_ctx* c, uint32_t* dst, uint64_t n) {
 m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std) {
     if (!c || !path) return M2S_ERR_INVALID;
     if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
-    std::vector<m2s_gaussian> host;
-    try { host.resize(c->last_stored); } catch (...) { return fail(c, M2S_ERR_OOM, "host allocation failed"); }
-    m2s_status s = m2s_download(c, host.data(), host.size());
-    if (s != M2S_OK) return s;
+    HIPCHK(c, hipSetDevice(c->device));
     // SceneManager.cpp:668
     const float scale_multiplier = gaussian_std / static_cast<float>(c->last_R);
-    s = m2s_write_ply(path, host.data(), host.size(), format, scale_multiplier);
+    // The records come down in chunks through two pinned buffers: while chunk k is encoded and written, chunk k+1 is on the
+    // PCIe bus (the reference maps the whole SSBO, then issues 62 stream writes per Gaussian from one thread).
+    const uint64_t n = c->last_stored;
+    const size_t chunk = m2s_ply::kChunkRows;
+    for (int k = 0; k < 2; ++k)
+        if (!c->h_export[k]) HIPCHK(c, hipHostMalloc((void**)&c->h_export[k], chunk * sizeof(m2s_gaussian), hipHostMallocDefault));
+    m2s_ply::Writer w;
+    m2s_status s = w.open(path, n, format, scale_multiplier);
+    if (s != M2S_OK) { c->err = std::string("could not write ") + path; return s; }
+    const char* src = static_cast<const char*>(c->last_records);
+    auto rows_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(chunk, n - k * chunk); };
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_export[0], src, rows_of(0) * sizeof(m2s_gaussian), hipMemcpyDeviceToHost, c->stream));
+    for (uint64_t k = 0; k < n_chunks && s == M2S_OK; ++k) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));                      // chunk k has arrived
+        if (k + 1 < n_chunks)
+            HIPCHK(c, hipMemcpyAsync(c->h_export[(k + 1) & 1], src + (k + 1) * chunk * sizeof(m2s_gaussian), rows_of(k + 1) * sizeof(m2s_gaussian),
+                                     hipMemcpyDeviceToHost, c->stream));
+        s = w.append(c->h_export[k & 1], rows_of(k));                    // returns once the pinned buffer has been read
+    }
+    const m2s_status cs = w.close();
+    if (s == M2S_OK) s = cs;
     if (s != M2S_OK) c->err = std::string("could not write ") + path;
     return s;
 }

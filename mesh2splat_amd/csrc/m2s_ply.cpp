@@ -3,12 +3,13 @@
 // PBR 339-428; dispatch savePlyVector 631-651).  The reference issues one ofstream::write per
 // field (62 per Gaussian in the standard format); here rows are encoded into a large buffer by
 // a pool of threads and written with a few big fwrite calls.
-#include "../../include/m2s.h"
+#include "m2s_ply.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -102,34 +103,66 @@ void encode_rows(const m2s_gaussian* g, size_t n, uint32_t format, float sm, uin
 
 }  // namespace
 
+namespace m2s_ply {
+
+m2s_status Writer::open(const char* path, uint64_t n_total, uint32_t format, float scale_multiplier) {
+    if (!path) return M2S_ERR_INVALID;
+    if (format > 2) format = 0;
+    f_ = std::fopen(path, "wb");
+    if (!f_) return M2S_ERR_IO;
+    const Format fmt = describe(format);
+    format_ = format; sm_ = scale_multiplier; row_bytes_ = fmt.row_bytes; expected_ = n_total; written_ = 0; ok_ = true; cur_ = 0;
+    std::string header = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(n_total) + "\n";
+    for (const auto& p : fmt.props) header += p + "\n";
+    header += "end_header\n";
+    ok_ = std::fwrite(header.data(), 1, header.size(), f_) == header.size();
+    return ok_ ? M2S_OK : M2S_ERR_IO;
+}
+
+m2s_status Writer::append(const m2s_gaussian* records, size_t rows) {
+    if (!f_) return M2S_ERR_STATE;
+    if (rows && !records) return M2S_ERR_INVALID;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (size_t r0 = 0; ok_ && r0 < rows; r0 += kChunkRows) {
+        const size_t n = std::min(kChunkRows, rows - r0);
+        std::vector<uint8_t>& buf = buf_[cur_];
+        try { if (buf.size() < n * row_bytes_) buf.resize(n * row_bytes_); } catch (...) { ok_ = false; return M2S_ERR_OOM; }
+        const unsigned nt = (unsigned)std::min<size_t>(hw, (n + 4095) / 4096);
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) {
+            const size_t a = n * t / nt, b = n * (t + 1) / nt;
+            pool.emplace_back(encode_rows, records + r0 + a, b - a, format_, sm_, buf.data() + a * row_bytes_);
+        }
+        encode_rows(records + r0, n / nt, format_, sm_, buf.data());
+        for (auto& th : pool) th.join();
+        if (pending_.valid()) ok_ = pending_.get() && ok_;       // the OTHER buffer has reached the file
+        FILE* f = f_;
+        const uint8_t* data = buf.data();
+        const size_t bytes = n * row_bytes_;
+        pending_ = std::async(std::launch::async, [f, data, bytes] { return std::fwrite(data, 1, bytes, f) == bytes; });
+        written_ += n;
+        cur_ ^= 1;
+    }
+    return ok_ ? M2S_OK : M2S_ERR_IO;
+}
+
+m2s_status Writer::close() {
+    if (!f_) return ok_ ? M2S_OK : M2S_ERR_IO;
+    if (pending_.valid()) ok_ = pending_.get() && ok_;
+    ok_ = (std::fclose(f_) == 0) && ok_;
+    f_ = nullptr;
+    if (written_ != expected_) ok_ = false;
+    return ok_ ? M2S_OK : M2S_ERR_IO;
+}
+
+}  // namespace m2s_ply
+
 extern "C" m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format,
                                     float scale_multiplier) {
     if (!path || (n && !records)) return M2S_ERR_INVALID;
-    if (format > 2) format = 0;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return M2S_ERR_IO;
-    const Format fmt = describe(format);
-    std::string header = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(n) + "\n";
-    for (const auto& p : fmt.props) header += p + "\n";
-    header += "end_header\n";
-    bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
-
-    const size_t chunk_rows = 1u << 18;  // 65 MB of standard rows per write
-    std::vector<uint8_t> buf;
-    try { buf.resize(std::min<uint64_t>(n, chunk_rows) * fmt.row_bytes); } catch (...) { std::fclose(f); return M2S_ERR_OOM; }
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    for (uint64_t r0 = 0; ok && r0 < n; r0 += chunk_rows) {
-        const size_t rows = (size_t)std::min<uint64_t>(chunk_rows, n - r0);
-        const unsigned nt = (unsigned)std::min<size_t>(hw, (rows + 4095) / 4096);
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; ++t) {
-            const size_t a = rows * t / nt, b = rows * (t + 1) / nt;
-            pool.emplace_back(encode_rows, records + r0 + a, b - a, format, scale_multiplier, buf.data() + a * fmt.row_bytes);
-        }
-        encode_rows(records + r0, rows / nt, format, scale_multiplier, buf.data());
-        for (auto& th : pool) th.join();
-        ok = std::fwrite(buf.data(), 1, rows * fmt.row_bytes, f) == rows * fmt.row_bytes;
-    }
-    ok = (std::fclose(f) == 0) && ok;
-    return ok ? M2S_OK : M2S_ERR_IO;
+    m2s_ply::Writer w;
+    m2s_status s = w.open(path, n, format, scale_multiplier);
+    if (s == M2S_OK) s = w.append(records, (size_t)n);
+    const m2s_status c = w.close();
+    return s != M2S_OK ? s : c;
 }

@@ -124,12 +124,14 @@ def test_opaque_is_plus_inf_and_default_format(tmp_path, oracle, hiplib):
     assert np.allclose(body[:, 57], np.log(np.float32(1e-7) * np.float32(0.01)))
 
 
-def test_large_multithreaded_write(tmp_path, oracle, hiplib):
+@pytest.mark.parametrize("fmt,rows", [(0, 300_000), (2, 600_000)])
+def test_large_multithreaded_write(tmp_path, oracle, hiplib, fmt, rows):
+    """More rows than one writer chunk (2^18): encoding threads + the double-buffered background file writes."""
     rng = np.random.default_rng(0)
-    rec = rng.uniform(0.01, 1.0, (300_000, 24)).astype(np.float32)
+    rec = rng.uniform(0.01, 1.0, (rows, 24)).astype(np.float32)
     a, b = str(tmp_path / "p.ply"), str(tmp_path / "o.ply")
-    write_ply(a, rec, 0, 0.001)
-    oracle.write_ply(b, rec, 0, 0.001)
+    write_ply(a, rec, fmt, 0.001)
+    oracle.write_ply(b, rec, fmt, 0.001)
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
