@@ -17,6 +17,7 @@
 #include <functional>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <thread>
 
 namespace m2s_host {
@@ -303,23 +304,25 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
             pd.enc = g.bin + off;
             pd.len = len;
         }
-        std::vector<PreDecoded*> work;
-        for (auto& kv : predecoded) work.push_back(&kv.second);
-        const unsigned n_threads = (unsigned)std::min<size_t>(host_threads(), work.size());
-        std::atomic<size_t> next{ 0 };
-        auto run = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < work.size();) {
-                PreDecoded& pd = *work[i];
+    }
+    // the decoders run while the geometry is de-indexed; whoever needs an image first (or the end of this function) joins them
+    std::vector<PreDecoded*> decode_work;
+    for (auto& kv : predecoded) decode_work.push_back(&kv.second);
+    std::atomic<size_t> decode_next{ 0 };
+    std::vector<std::thread> decode_pool;
+    auto join_decoders = [&]() { for (auto& th : decode_pool) if (th.joinable()) th.join(); };
+    struct AtExit { std::function<void()> f; ~AtExit() { f(); } } join_at_exit{ join_decoders };
+    {
+        auto run = [&decode_work, &decode_next]() {
+            for (size_t i; (i = decode_next.fetch_add(1)) < decode_work.size();) {
+                PreDecoded& pd = *decode_work[i];
                 const bool is_jpeg = pd.len >= 3 && pd.enc[0] == 0xFF && pd.enc[1] == 0xD8 && pd.enc[2] == 0xFF;
                 pd.ok = is_jpeg ? decode_jpeg(pd.enc, pd.len, pd.img, pd.perr) : decode_png(pd.enc, pd.len, pd.img, pd.perr);
             }
         };
-        if (n_threads > 1) {
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run);
-            run();
-            for (auto& th : pool) th.join();
-        } else if (!work.empty()) run();
+        const size_t n_threads = std::min<size_t>(host_threads(), decode_work.size());
+        if (host_threads() > 1) for (size_t t = 0; t < n_threads; ++t) decode_pool.emplace_back(run);
+        else run();                                                      // M2S_HOST_THREADS=1: everything on this thread
     }
 
     // ---- images are handed out lazily, once per glTF image ---------------------------------------------
@@ -365,6 +368,7 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         Image img;
         std::string perr;
         bool decoded_ok;
+        join_decoders();
         auto pre = predecoded.find(src);
         if (pre != predecoded.end() && pre->second.enc == enc) {          // decoded up front
             decoded_ok = pre->second.ok;
@@ -437,19 +441,6 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
                 err = "attribute accessor shorter than POSITION in mesh " + hm.name; return false;
             }
 
-            // material: SceneManager.cpp:99-193 (factors other than baseColorFactor are parsed but never used by the pass)
-            hm.base_color[0] = hm.base_color[1] = hm.base_color[2] = hm.base_color[3] = 1.0f;
-            const long long mat_i = prim["material"].int_or(-1);
-            const auto& mat = doc["materials"][(size_t)mat_i];
-            if (mat_i >= 0 && mat.is_object()) {
-                const auto& pbr = mat["pbrMetallicRoughness"];
-                const auto& bcf = pbr["baseColorFactor"];
-                if (bcf.is_array() && bcf.size() == 4) for (int k = 0; k < 4; ++k) hm.base_color[k] = (float)bcf[(size_t)k].number_or(1.0);
-                if (pbr["baseColorTexture"].is_object() && !load_image(pbr["baseColorTexture"]["index"].int_or(-1), hm.tex_image[0])) return false;
-                if (mat["normalTexture"].is_object() && !load_image(mat["normalTexture"]["index"].int_or(-1), hm.tex_image[1])) return false;
-                if (pbr["metallicRoughnessTexture"].is_object() && !load_image(pbr["metallicRoughnessTexture"]["index"].int_or(-1), hm.tex_image[2])) return false;
-            }
-
             const size_t n_tri = idx.size() / 3;
             hm.vertices.assign(n_tri * 3 * 17, 0.0f);
             // every triangle is independent and writes its own 51 floats: large meshes are de-indexed by several threads
@@ -499,6 +490,19 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
                 }
             }
             });
+
+            // material: SceneManager.cpp:99-193 (factors other than baseColorFactor are parsed but never used by the pass)
+            hm.base_color[0] = hm.base_color[1] = hm.base_color[2] = hm.base_color[3] = 1.0f;
+            const long long mat_i = prim["material"].int_or(-1);
+            const auto& mat = doc["materials"][(size_t)mat_i];
+            if (mat_i >= 0 && mat.is_object()) {
+                const auto& pbr = mat["pbrMetallicRoughness"];
+                const auto& bcf = pbr["baseColorFactor"];
+                if (bcf.is_array() && bcf.size() == 4) for (int k = 0; k < 4; ++k) hm.base_color[k] = (float)bcf[(size_t)k].number_or(1.0);
+                if (pbr["baseColorTexture"].is_object() && !load_image(pbr["baseColorTexture"]["index"].int_or(-1), hm.tex_image[0])) return false;
+                if (mat["normalTexture"].is_object() && !load_image(mat["normalTexture"]["index"].int_or(-1), hm.tex_image[1])) return false;
+                if (pbr["metallicRoughnessTexture"].is_object() && !load_image(pbr["metallicRoughnessTexture"]["index"].int_or(-1), hm.tex_image[2])) return false;
+            }
             scene.meshes.push_back(std::move(hm));
         }
     }
@@ -507,8 +511,15 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     scene.c_meshes.clear();
     for (HostMesh& hm : scene.meshes) {
-        for (size_t v = 0; v < hm.vertices.size(); v += 17)
-            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hm.vertices[v + k]); mx[k] = std::max(mx[k], hm.vertices[v + k]); }
+        // min / max do not depend on the order of evaluation: per-thread partial boxes, merged under a lock
+        std::mutex box_lock;
+        parallel_for(hm.vertices.size() / 17, 1u << 17, [&](size_t v_begin, size_t v_end) {
+            float lmn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, lmx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            for (size_t v = v_begin; v < v_end; ++v)
+                for (int k = 0; k < 3; ++k) { lmn[k] = std::min(lmn[k], hm.vertices[v * 17 + k]); lmx[k] = std::max(lmx[k], hm.vertices[v * 17 + k]); }
+            std::lock_guard<std::mutex> lk(box_lock);
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], lmn[k]); mx[k] = std::max(mx[k], lmx[k]); }
+        });
         std::memcpy(hm.bbox_min, mn, 12);
         std::memcpy(hm.bbox_max, mx, 12);
     }
