@@ -35,6 +35,7 @@ WORKLOADS = {
     "c2": (76, 2048, 512),     # SciFiHelmet stand-in (I-2)
     "small": (24, 256, 256),   # CI-sized
     "c4": ("grid", 1024, 1024),  # Sponza stand-in (I-4): 64 meshes x cube-sphere n=18, 64 materials (single GPU only)
+    "mid": (94, 2048, 1024),   # one mesh, 106 032 triangles, ~26 fragments per triangle (Sponza-like triangle sizes)
 }
 
 
@@ -53,6 +54,7 @@ def parse():
                     help="after the timed region, also measure two-lane overlapped submission (reported as 'overlapped'; off by "
                          "default so that a rocprofv3 trace of the default command holds only isolated launches)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()

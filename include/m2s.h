@@ -102,6 +102,10 @@ m2s_status m2s_set_triangle_range(m2s_ctx* ctx, uint64_t first, uint64_t count);
  * RGBA8 textures and generates mip levels 1..4 (glUtils.cpp:292-313).  Replaces any previous scene. */
 m2s_status m2s_upload_scene(m2s_ctx* ctx, const m2s_mesh* meshes, uint32_t n_meshes);
 
+/* Wall-clock breakdown (ms) of the last m2s_upload_scene: [0] whole call, [1] geometry (pinned staging + re-layout kernel),
+ * [2] textures (staging, mip and combo kernels, final sync), [3] device / pinned allocations. */
+m2s_status m2s_last_upload_ms(const m2s_ctx* ctx, float out_ms[4]);
+
 /* ---- the pass == ConversionPass::execute ------------------------------------------------------- */
 /* u_maxGaussians policy (converterFS.glsl:46-51): -1 (default) = the reference formula
  * min(R*R*6*max(1,meshes), 7'000'000) in 32-bit unsigned arithmetic (ConversionPass.cpp:21-24);
@@ -153,6 +157,54 @@ m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t
 /* Downloads the last convert's records and writes them: scaleMultiplier = gaussian_std / R
  * (SceneManager.cpp:668). */
 m2s_status m2s_export_ply(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std);
+
+/* Several writers, one file (one per GPU rank of a sharded conversion: no record gather needed): writes n host records as
+ * rows [first_row, first_row + n) of a .ply whose header announces total_rows.  The file is created if absent and never
+ * truncated below its final size; the writer of row 0 also writes the header and sets the file's length.  Writers may run
+ * concurrently (different processes); the result is byte-identical to m2s_write_ply of the concatenated records. */
+m2s_status m2s_write_ply_slice(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format, float scale_multiplier,
+                               uint64_t first_row, uint64_t total_rows);
+/* Same for the first n_rows records of the context's last conversion (n_rows <= m2s_num_stored). */
+m2s_status m2s_export_ply_slice(m2s_ctx* ctx, const char* path, uint32_t format, float gaussian_std, uint64_t first_row,
+                                uint64_t n_rows, uint64_t total_rows);
+
+/* ---- multi-GPU: triangle-range shards, one process per GPU, RCCL over xGMI ------------------------------------------
+ * The reference is a single-GPU program; this block implements BASELINE.json's sharding: every triangle is independent
+ * (no depth test, no blending: ConversionPass.cpp:45-48), the reference's one shared word — the append cursor,
+ * converterFS.glsl:46 — becomes one counter per rank, and concatenating the per-rank record blocks in rank order
+ * reproduces the single-GPU output byte for byte (the device emits in canonical (triangle, row, column) order).
+ * Per rank: m2s_dist_shard_ranges -> m2s_set_triangle_range + m2s_upload_scene (cap lifted: m2s_set_max_gaussians(0)) ->
+ * m2s_convert* -> m2s_dist_all_gather_counts (8 bytes per rank) -> either m2s_export_ply_slice at the rank's offset (no
+ * record leaves its GPU) or m2s_dist_gather_records (every block to every rank / to one root, exact sizes, one RCCL
+ * group of sends and receives).  librccl is opened at run time; without it these calls fail with M2S_ERR_STATE. */
+#define M2S_DIST_ID_BYTES 128
+typedef struct m2s_dist m2s_dist;
+/* Rank 0 obtains the communicator id (== ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means. */
+m2s_status m2s_dist_unique_id(uint8_t out_id[M2S_DIST_ID_BYTES]);
+/* Collective over all ranks (== ncclCommInitRank) on HIP device `device`. */
+m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int rank, int world, m2s_dist** out);
+void m2s_dist_destroy(m2s_dist* d);
+int m2s_dist_rank(const m2s_dist* d);
+int m2s_dist_world(const m2s_dist* d);
+/* d == NULL: message of the last failed m2s_dist_unique_id / _create / _shard_ranges on this thread. */
+const char* m2s_dist_last_error(const m2s_dist* d);
+/* Host only, deterministic (every rank computes the same plan): cuts the flattened triangle list into `world` contiguous
+ * ranges of about equal cost = estimated fragments at density R (projected area on the dominant axis plane, in pixels)
+ * + 0.25 per triangle.  first[r], count[r] feed m2s_set_triangle_range on rank r. */
+m2s_status m2s_dist_shard_ranges(const m2s_mesh* meshes, uint32_t n_meshes, uint32_t R, int world, uint64_t* first, uint64_t* count);
+/* The one mandatory exchange: every rank learns every rank's counter.  counts[world]; offsets[world + 1] (may be NULL) =
+ * exclusive prefix = where each rank's block starts in the merged buffer.  publish/collect is the non-blocking form for
+ * back-to-back conversions (up to 8 exchanges in flight, completed in order, on a stream of their own). */
+m2s_status m2s_dist_all_gather_counts(m2s_dist* d, uint64_t my_total, uint64_t* counts, uint64_t* offsets);
+m2s_status m2s_dist_publish_count(m2s_dist* d, uint64_t my_total);
+m2s_status m2s_dist_collect_counts(m2s_dist* d, uint64_t* counts, uint64_t* offsets);
+/* Global cap semantics of a sharded conversion (converterFS.glsl:46-51): the merged buffer keeps the first `cap` records
+ * in rank order (0 = unlimited); keep[r] = how many records rank r contributes. */
+void m2s_dist_clamp_to_cap(const uint64_t* counts, int world, uint64_t cap, uint64_t* keep);
+/* Record exchange: rank r's block (counts[r] records at d_mine on rank r) lands at record offset sum(counts[0..r)) of
+ * d_merged on every rank (root < 0) or on `root` only (d_merged may be NULL elsewhere).  Device pointers; enqueued on
+ * hip_stream (the stream the conversion ran on); returns without waiting for it. */
+m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64_t* counts, void* d_merged, int root, void* hip_stream);
 
 /* ---- depth sort == RadixSortPass::execute (RadixSortPass.cpp:8-90) ------------------------------------ */
 /* Sorts the records stored by the last m2s_convert by key = floatBitsToUint(view-space z), ascending on the

@@ -29,6 +29,10 @@ EXPORTS = (
     "m2s_io_last_error", "m2s_sort_by_depth", "m2s_device_sorted_records", "m2s_download_sorted", "m2s_last_sort_ms",
     "m2s_upload_records", "m2s_prepass", "m2s_device_quads", "m2s_device_prepass_depths", "m2s_download_prepass", "m2s_last_prepass_ms",
     "m2s_sort_prepass", "m2s_device_sorted_quads", "m2s_download_sorted_quads", "m2s_last_sort_prepass_ms",
+    "m2s_last_upload_ms", "m2s_write_ply_slice", "m2s_export_ply_slice",
+    "m2s_dist_unique_id", "m2s_dist_create", "m2s_dist_destroy", "m2s_dist_rank", "m2s_dist_world", "m2s_dist_last_error",
+    "m2s_dist_shard_ranges", "m2s_dist_all_gather_counts", "m2s_dist_publish_count", "m2s_dist_collect_counts",
+    "m2s_dist_clamp_to_cap", "m2s_dist_gather_records",
 )
 
 
@@ -143,6 +147,21 @@ def load():
         "m2s_device_sorted_records": (vp, [vp]),
         "m2s_download_sorted": (C.c_int, [vp, vp, u64]),
         "m2s_last_sort_ms": (C.c_float, [vp]),
+        "m2s_last_upload_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "m2s_write_ply_slice": (C.c_int, [C.c_char_p, vp, u64, u32, C.c_float, u64, u64]),
+        "m2s_export_ply_slice": (C.c_int, [vp, C.c_char_p, u32, C.c_float, u64, u64, u64]),
+        "m2s_dist_unique_id": (C.c_int, [vp]),
+        "m2s_dist_create": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "m2s_dist_destroy": (None, [vp]),
+        "m2s_dist_rank": (C.c_int, [vp]),
+        "m2s_dist_world": (C.c_int, [vp]),
+        "m2s_dist_last_error": (C.c_char_p, [vp]),
+        "m2s_dist_shard_ranges": (C.c_int, [C.POINTER(MeshC), u32, u32, C.c_int, C.POINTER(u64), C.POINTER(u64)]),
+        "m2s_dist_all_gather_counts": (C.c_int, [vp, u64, C.POINTER(u64), C.POINTER(u64)]),
+        "m2s_dist_publish_count": (C.c_int, [vp, u64]),
+        "m2s_dist_collect_counts": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "m2s_dist_clamp_to_cap": (None, [C.POINTER(u64), C.c_int, u64, C.POINTER(u64)]),
+        "m2s_dist_gather_records": (C.c_int, [vp, vp, C.POINTER(u64), vp, C.c_int, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

@@ -89,6 +89,12 @@ class Converter:
         self._check(self._L.m2s_upload_scene(self._h, arr, n))
         del keep
 
+    def last_upload_ms(self) -> dict:
+        """Wall-clock breakdown of the last upload_scene (ms)."""
+        ms = (C.c_float * 4)()
+        self._check(self._L.m2s_last_upload_ms(self._h, ms))
+        return {"total": float(ms[0]), "geometry": float(ms[1]), "textures": float(ms[2]), "alloc": float(ms[3])}
+
     # -- the pass ---------------------------------------------------------------------------------
     def set_max_gaussians(self, cap: int):
         """-1 reference formula (default), 0 unlimited, >0 explicit."""

@@ -7,10 +7,13 @@
 #include "m2s_ply.h"
 
 #include <algorithm>
+#include <array>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -21,9 +24,10 @@ thread_local std::string g_create_error = "";
 
 constexpr uint32_t kMaxGaussiansToSort = 7000000u;  // RenderPass.hpp:9
 constexpr uint64_t kMaxTriangles = (1ull << 28) - 1;  // 32-bit byte offsets into the 16 B/triangle planes
-constexpr size_t kStagingBytes = 256ull << 20;      // H2D staging for the AoS -> SoA repack
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+const char* const kStaleMsg = "the records of the conversion last waited for have been overwritten by a later submission at another R "
+                              "(wait for it, or submit into your own buffers)";
 }  // namespace
 
 struct m2s_ctx {
@@ -36,7 +40,6 @@ struct m2s_ctx {
     SceneDev scene{};
     MeshParams* d_meshes = nullptr;
     uint32_t* d_mesh_first = nullptr;
-    std::vector<void*> tex_mem;
     uint32_t n_meshes_total = 0;
     bool has_scene = false;
     uint64_t range_first = 0, range_count = UINT64_MAX;
@@ -52,9 +55,23 @@ struct m2s_ctx {
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
     BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions
-    uint32_t multipass_R = 0;               // AUTO: R at which this scene is converted by the multi-pass pipeline
-    uint32_t decided_R = 0;                 // AUTO: R for which the fused / multi-pass decision has been taken
-    uint32_t mp_ready_R = 0;                // R of the last completed multi-pass conversion (its work buffers are sized)
+    // What the context remembers about the uploaded scene at a given resolution R.  The reference converts on load and
+    // whenever the density slider moves (guiRendererConcreteMediator.cpp:51-57), i.e. mostly at an R it has not seen
+    // before, so nothing here may be REQUIRED for a fast conversion: a new R costs no counting pass and no extra host
+    // round trip (the AUTO decision is taken from frag_per_R2, the band bases are a by-product of the first launch).
+    struct RInfo {
+        bool decided = false;      // AUTO: single-pass / multi-pass decision taken
+        bool multipass = false;    // ... and it was "multi-pass"
+        bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
+        bool async_ok = false;     // a completed conversion needed no host decision between kernels
+        bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
+        bool bands_ready = false;  // d_bands[band_slot] holds the XCD band bases of k_fused2 for this R
+        int band_slot = 0;
+    };
+    std::map<uint32_t, RInfo> rinfo;
+    double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
+    unsigned long long* d_bands = nullptr;  // kBandSlots x 8 band bases (device)
+    void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
     // and record buffer, so that consecutive single-kernel conversions overlap (the tail of one, where the GPU drains,
@@ -64,20 +81,21 @@ struct m2s_ctx {
     unsigned long long* d_chain_b = nullptr;
     void* d_records_b = nullptr;
     uint64_t records_b_cap = 0;
-    BandInfo bands{};                       // XCD bands of k_fused2 for the scene at R == band_R (from the exact count)
-    uint32_t band_R = 0;
-    uint32_t team_off_R = 0;                // R at which k_fused2 reported a workgroup that did not fit its LDS stream
     int pipeline = M2S_PIPELINE_AUTO;
-    uint32_t sized_R = 0;                   // unlimited-cap policy: R the context buffer was sized for
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
 
     // asynchronous submissions (m2s_convert_submit / m2s_convert_wait): a ring of result slots.  Slot k uses
     // h_total[2 + 2k] (counter) and h_total[3 + 2k] (status words), written by the kernel itself.
     struct Slot { hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr; uint64_t limit = 0; void* d_out = nullptr; uint32_t R = 0;
-                  bool sync_result = false; uint64_t sync_total = 0; bool prof = false; float ms[M2S_K_N] = {}; };
+                  bool sync_result = false; uint64_t sync_total = 0; bool prof = false; float ms[M2S_K_N] = {};
+                  int own_lane = -1; uint32_t gen = 0;   // context-owned buffer (0 / 1) and its generation at submission; -1: caller's buffer
+                  bool wrote_bands = false; };
     Slot slot[M2S_MAX_IN_FLIGHT];
     uint32_t slot_head = 0, slot_count = 0; // oldest in-flight slot, number in flight
-    uint32_t async_ok_R = 0;                // R at which a completed conversion of this scene needed no host decision
+    hipStream_t last_submit_stream = nullptr;   // stream of the newest in-flight submission (work buffers are shared: see submit)
+    uint32_t buf_R[2] = { 0, 0 };           // context-owned record buffers (lane a / b): R of the newest conversion enqueued into it ...
+    uint32_t buf_gen[2] = { 0, 0 };         // ... and a generation that advances whenever that R changes
+    bool records_stale = false;             // the conversion last waited for has been overwritten by a later submission
 
     // output
     void* d_records = nullptr;
@@ -106,6 +124,15 @@ struct m2s_ctx {
     uint64_t pp_depthtex_cap = 0;
     float last_prepass_ms = 0.0f;
     m2s_gaussian* h_export[2] = { nullptr, nullptr };   // pinned chunk buffers of m2s_export_ply
+    // upload staging: two pinned host chunks (filled by a few host threads while the previous chunk is on the bus) and
+    // two device chunks for the AoS -> SoA repack; allocated at the first upload, kept
+    void* h_stage[2] = { nullptr, nullptr };
+    void* d_stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_ev[2] = { nullptr, nullptr };
+    void* scene_arena = nullptr;             // one allocation for mesh table, textures, combo textures and work buffers
+    float last_upload_ms[4] = { 0, 0, 0, 0 }; // [0] total, [1] geometry, [2] textures + mips + combo, [3] allocations
+    void* d_rows = nullptr;                  // m2s_export_ply: .ply rows encoded on the device (formats 1 and 2)
+    uint64_t rows_cap = 0;                   // bytes
     void* d_loaded = nullptr;                // m2s_upload_records (a loaded .ply)
     uint64_t loaded_cap = 0;
     void* d_sorted_quads = nullptr;          // m2s_sort_prepass
@@ -134,30 +161,31 @@ static m2s_status fail(m2s_ctx* c, m2s_status s, const std::string& msg) {
 
 static void free_scene(m2s_ctx* c) {
     if (c->tri_mem) (void)hipFree(c->tri_mem);
-    if (c->d_meshes) (void)hipFree(c->d_meshes);
-    if (c->d_mesh_first) (void)hipFree(c->d_mesh_first);
-    for (void* p : c->tex_mem) (void)hipFree(p);
-    if (c->d_cnt) (void)hipFree(c->d_cnt);
-    if (c->d_off) (void)hipFree(c->d_off);
-    if (c->d_partials) (void)hipFree(c->d_partials);
-    if (c->d_chain) (void)hipFree(c->d_chain);
+    if (c->scene_arena) (void)hipFree(c->scene_arena);
     if (c->d_chain_b) (void)hipFree(c->d_chain_b);
-    c->d_chain_b = nullptr;
-    if (c->d_biglist) (void)hipFree(c->d_biglist);
-    if (c->d_bigmeta) (void)hipFree(c->d_bigmeta);
-    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr;
-    c->sized_R = 0;
-    c->multipass_R = 0;
-    c->decided_R = 0;
-    c->mp_ready_R = 0;
-    c->team_off_R = 0;
-    c->band_R = 0;
-    c->async_ok_R = 0;
-    c->tri_mem = nullptr; c->d_meshes = nullptr; c->d_mesh_first = nullptr;
-    c->tex_mem.clear();
+    if (c->d_setup) (void)hipFree(c->d_setup);
+    c->d_chain_b = nullptr; c->d_setup = nullptr;
+    c->tri_mem = nullptr; c->scene_arena = nullptr;
+    // everything below lived inside the arena
+    c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
+    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr;
+    c->rinfo.clear();
+    c->frag_per_R2 = -1.0;
     c->scene = SceneDev{};
     c->has_scene = false;
+}
+
+// What is remembered about this scene at resolution R (created on first use; the table is bounded: a slider dragged
+// through hundreds of densities simply starts over).
+constexpr int kBandSlots = 64;
+static m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
+    auto it = c->rinfo.find(R);
+    if (it != c->rinfo.end()) return it->second;
+    if (c->rinfo.size() >= (size_t)kBandSlots) c->rinfo.clear();
+    m2s_ctx::RInfo ri;
+    ri.band_slot = (int)c->rinfo.size();
+    return c->rinfo.emplace(R, ri).first->second;
 }
 
 extern "C" {
@@ -192,6 +220,8 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto& ev : c->stage_ev)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto& sl : c->slot)
         if ((e = hipEventCreate(&sl.done)) != hipSuccess || (e = hipEventCreate(&sl.t0)) != hipSuccess ||
             (e = hipEventCreate(&sl.t1)) != hipSuccess)
@@ -200,14 +230,19 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     return M2S_OK;
 }
 
+// every conversion still in flight has finished when this returns (their slots stay queued for m2s_convert_wait)
+static void drain_in_flight(m2s_ctx* c) {
+    for (uint32_t k = 0; k < c->slot_count; ++k) {
+        auto& sl = c->slot[(c->slot_head + k) % M2S_MAX_IN_FLIGHT];
+        if (!sl.sync_result) (void)hipEventSynchronize(sl.done);
+    }
+}
+
 void m2s_destroy(m2s_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (uint32_t k = 0; k < c->slot_count; ++k) {   // conversions still in flight on a caller's stream
-        auto& sl = c->slot[(c->slot_head + k) % M2S_MAX_IN_FLIGHT];
-        if (!sl.sync_result) (void)hipEventSynchronize(sl.done);
-    }
+    drain_in_flight(c);   // conversions still in flight on a caller's stream
     free_scene(c);
     if (c->d_start) (void)hipFree(c->d_start);
     if (c->d_records) (void)hipFree(c->d_records);
@@ -217,7 +252,13 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_quads) (void)hipFree(c->d_quads);
     if (c->d_sorted_quads) (void)hipFree(c->d_sorted_quads);
     if (c->d_loaded) (void)hipFree(c->d_loaded);
+    if (c->d_rows) (void)hipFree(c->d_rows);
     for (int k = 0; k < 2; ++k) if (c->h_export[k]) (void)hipHostFree(c->h_export[k]);
+    for (int k = 0; k < 2; ++k) {
+        if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+        if (c->d_stage[k]) (void)hipFree(c->d_stage[k]);
+        if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
+    }
     if (c->d_pp_depths) (void)hipFree(c->d_pp_depths);
     if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
     if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
@@ -249,18 +290,76 @@ m2s_status m2s_set_max_gaussians(m2s_ctx* c, int64_t cap) {
     return M2S_OK;
 }
 
+}  // extern "C"
+
+// ---- host -> device through pinned staging ---------------------------------------------------------------------------
+// The caller's buffers are ordinary pageable memory (std::vector in the reference, SceneManager.cpp:483-512): a plain
+// hipMemcpy from them runs at 1-2 GB/s on this platform (round 1: 86-232 ms for the 254 MB of the C3 scene).  Here a few
+// host threads copy a 16 MiB chunk into one of two PINNED buffers while the DMA engine moves the other one, so the bus,
+// not the page-by-page staging inside the runtime, sets the pace.
+namespace {
+constexpr size_t kStageChunk = 16ull << 20;
+
+void par_memcpy(void* dst, const void* src, size_t n) {
+    const size_t kMin = 2ull << 20;
+    unsigned nt = (unsigned)std::min<size_t>(4, n / kMin);
+    if (const char* e = std::getenv("M2S_HOST_THREADS")) { if (std::atol(e) == 1) nt = 1; }
+    if (nt <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < nt; ++i) {
+        const size_t b = n * i / nt, e = n * (i + 1) / nt;
+        pool.emplace_back([=] { memcpy((char*)dst + b, (const char*)src + b, e - b); });
+    }
+    memcpy(dst, src, n / nt);
+    for (auto& t : pool) t.join();
+}
+
+m2s_status ensure_stage(m2s_ctx* c) {
+    for (int k = 0; k < 2; ++k) {
+        if (!c->h_stage[k]) HIPCHK(c, hipHostMalloc(&c->h_stage[k], kStageChunk, hipHostMallocDefault));
+        if (!c->d_stage[k]) HIPCHK(c, hipMalloc(&c->d_stage[k], kStageChunk));
+    }
+    return M2S_OK;
+}
+
+// Moves `bytes` from pageable `src` to the device in chunks of at most `chunk` bytes (<= kStageChunk).  Chunk i lands in
+// dst + offset (dst != nullptr) or in the device staging buffer d_stage[i & 1] (dst == nullptr); then on_chunk(device
+// pointer of the chunk, offset, bytes of the chunk) may enqueue work that consumes it on c->stream.
+template <class F>
+m2s_status staged_h2d(m2s_ctx* c, const char* src, size_t bytes, size_t chunk, char* dst, uint32_t& turn, F on_chunk) {
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = std::min(chunk, bytes - off);
+        const int k = (int)(turn++ & 1u);
+        HIPCHK(c, hipEventSynchronize(c->stage_ev[k]));          // the DMA that last read h_stage[k] has finished
+        par_memcpy(c->h_stage[k], src + off, n);
+        char* d = dst ? dst + off : (char*)c->d_stage[k];        // d_stage[k]: its previous consumer precedes us on the stream
+        HIPCHK(c, hipMemcpyAsync(d, c->h_stage[k], n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->stage_ev[k], c->stream));
+        on_chunk(d, off, n);
+    }
+    return M2S_OK;
+}
+}  // namespace
+
+extern "C" {
+
 m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshes) {
     if (!c) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (n_meshes > 0xFFFFFFu) return fail(c, M2S_ERR_INVALID, "more than 2^24-1 meshes");   // TriShade keeps the index in 24 bits
     if (n_meshes && !meshes) return fail(c, M2S_ERR_INVALID, "meshes is NULL");
     HIPCHK(c, hipSetDevice(c->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     // ---- validate + global triangle index space -------------------------------------------------
     std::vector<uint32_t> mesh_first(n_meshes + 1, 0);
     uint64_t T = 0;
     for (uint32_t i = 0; i < n_meshes; ++i) {
         const m2s_mesh& m = meshes[i];
         if (m.stride_floats < 12) return fail(c, M2S_ERR_INVALID, "stride_floats must be >= 12");
+        if (m.stride_floats > 4096) return fail(c, M2S_ERR_INVALID, "stride_floats must be <= 4096");
         if (m.n_vertices % 3) return fail(c, M2S_ERR_INVALID, "n_vertices must be a multiple of 3");
         if (m.n_vertices && !m.vertices) return fail(c, M2S_ERR_INVALID, "vertices is NULL");
         for (int k = 0; k < 3; ++k)
@@ -280,13 +379,89 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->scene.n_meshes = n_meshes;
     c->scene.n_tri = n_tri;
     c->scene.tri_first = (uint32_t)first;
+    c->last_total = c->last_stored = 0;
+    c->last_records = nullptr;
+    c->records_stale = false;
 
-    // ---- geometry planes: 144 B / triangle ------------------------------------------------------
+    // ---- layout: geometry planes (144 B / triangle) in one allocation, everything else in a second one -------------
+    const auto t_alloc = std::chrono::steady_clock::now();
     const size_t np = std::max<size_t>(n_tri, 1);
     size_t offs[11], cur = 0;
     const size_t widths[11] = { 16, 16, 4, 16, 8, 16, 16, 4, 16, 16, 16 };
     for (int k = 0; k < 11; ++k) { offs[k] = cur; cur = align_up(cur + np * widths[k], 256); }
     HIPCHK(c, hipMalloc(&c->tri_mem, cur));
+
+    // textures (deduplicated by host pointer), their mip chains, combo chains: sizes first
+    struct TexPlan { const uint8_t* src; TexDesc d; size_t arena_off; };
+    struct ComboPlan { ComboDesc d; size_t arena_off; uint32_t ia, in, im; };
+    std::vector<TexPlan> tex_plan;
+    std::vector<ComboPlan> combo_plan;
+    std::map<std::tuple<const uint8_t*, uint32_t, uint32_t>, uint32_t> dedup;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cdedup;
+    std::vector<std::array<int, 3>> mesh_tex(std::max<uint32_t>(n_meshes, 1), std::array<int, 3>{ -1, -1, -1 });
+    std::vector<int> mesh_combo(std::max<uint32_t>(n_meshes, 1), -1);
+    size_t arena = 0;
+    auto take = [&](size_t bytes) { const size_t o = arena; arena = align_up(arena + std::max<size_t>(bytes, 4), 256); return o; };
+    for (uint32_t i = 0; i < n_meshes; ++i) {
+        const m2s_mesh& m = meshes[i];
+        for (int k = 0; k < 3; ++k) {
+            const m2s_texture& t = m.tex[k];
+            if (!t.rgba8) continue;
+            const auto key = std::make_tuple(t.rgba8, t.width, t.height);
+            auto it = dedup.find(key);
+            if (it != dedup.end()) { mesh_tex[i][k] = (int)it->second; continue; }
+            TexPlan p{};
+            p.src = t.rgba8;
+            p.d.w = t.width; p.d.h = t.height;
+            uint32_t mx = std::max(t.width, t.height), nl = 1;
+            while (mx > 1 && nl < 5) { mx >>= 1; nl++; }
+            p.d.n_levels = nl;
+            size_t tot = 0;
+            for (uint32_t l = 0; l < nl; ++l) {
+                p.d.off[l] = (uint32_t)tot;
+                tot += (size_t)std::max(1u, t.width >> l) * std::max(1u, t.height >> l);
+            }
+            p.arena_off = take(tot * 4);
+            dedup[key] = (uint32_t)tex_plan.size();
+            mesh_tex[i][k] = (int)tex_plan.size();
+            tex_plan.push_back(p);
+        }
+        // combo texture (interleaved albedo / normal / MR, see ComboDesc): all three maps present, same size
+        const int ia = mesh_tex[i][0], in = mesh_tex[i][1], im = mesh_tex[i][2];
+        if (ia < 0 || in < 0 || im < 0) continue;
+        const TexDesc &ta = tex_plan[ia].d, &tn = tex_plan[in].d, &tm = tex_plan[im].d;
+        if (ta.w != tn.w || ta.w != tm.w || ta.h != tn.h || ta.h != tm.h) continue;
+        const auto ckey = std::make_tuple((uint32_t)ia, (uint32_t)in, (uint32_t)im);
+        auto cit = cdedup.find(ckey);
+        if (cit != cdedup.end()) { mesh_combo[i] = (int)cit->second; continue; }
+        ComboPlan cp{};
+        size_t tot = 0;
+        for (uint32_t l = 0; l < ta.n_levels; ++l) {
+            cp.d.coff[l] = (uint32_t)tot;
+            tot += (size_t)(std::max(1u, ta.w >> l) + 1) * std::max(1u, ta.h >> l) * 3;
+        }
+        if (tot > 0x3FFFFFF0ull) continue;  // the sampler addresses the combo texels with 32-bit BYTE offsets
+        cp.arena_off = take(tot * 4);
+        cp.ia = (uint32_t)ia; cp.in = (uint32_t)in; cp.im = (uint32_t)im;
+        cdedup[ckey] = (uint32_t)combo_plan.size();
+        mesh_combo[i] = (int)combo_plan.size();
+        combo_plan.push_back(cp);
+    }
+    const size_t n_mp = std::max<uint32_t>(n_meshes, 1);
+    const size_t chain_words = std::max<size_t>(n_fused_waves(n_tri), 1);
+    const size_t o_meshes = take(n_mp * sizeof(MeshParams));
+    const size_t o_mesh_first = take(mesh_first.size() * sizeof(uint32_t));
+    const size_t o_cnt = take(np * sizeof(uint32_t));
+    const size_t o_off = take((np + 1) * sizeof(uint32_t));
+    const size_t o_partials = take(std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t));
+    const size_t o_chain = take(chain_words * sizeof(unsigned long long));
+    const size_t o_biglist = take(np * sizeof(BigItem));
+    const size_t o_bigmeta = take(4 * sizeof(uint32_t));
+    const size_t o_bands = take((size_t)kBandSlots * 8 * sizeof(unsigned long long));
+    HIPCHK(c, hipMalloc(&c->scene_arena, arena));
+    { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
+    c->last_upload_ms[3] = ms_since(t_alloc);
+    char* A = (char*)c->scene_arena;
     char* b = (char*)c->tri_mem;
     TriPlanes& tp = c->scene.tri;
     tp.A0 = (const float4*)(b + offs[0]); tp.A1 = (const float4*)(b + offs[1]); tp.A2 = (const float*)(b + offs[2]);
@@ -294,129 +469,90 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     tp.C0 = (const float4*)(b + offs[5]); tp.C1 = (const float4*)(b + offs[6]); tp.C2 = (const float*)(b + offs[7]);
     tp.D0 = (const float4*)(b + offs[8]); tp.D1 = (const float4*)(b + offs[9]); tp.D2 = (const float4*)(b + offs[10]);
 
-    if (n_tri) {
-        void* staging = nullptr;
-        size_t need = 0;
-        for (uint32_t i = 0; i < n_meshes; ++i) {
-            const uint64_t s = std::max<uint64_t>(first, mesh_first[i]), e = std::min<uint64_t>(last, mesh_first[i + 1]);
-            if (e > s) need = std::max<size_t>(need, (size_t)(e - s) * 3 * meshes[i].stride_floats * sizeof(float));
-        }
-        const size_t stage_bytes = std::min(need, kStagingBytes);
-        HIPCHK(c, hipMalloc(&staging, std::max<size_t>(stage_bytes, 256)));
-        for (uint32_t i = 0; i < n_meshes; ++i) {
-            const uint64_t s = std::max<uint64_t>(first, mesh_first[i]), e = std::min<uint64_t>(last, mesh_first[i + 1]);
-            if (e <= s) continue;
-            const size_t tri_bytes = (size_t)3 * meshes[i].stride_floats * sizeof(float);
-            const uint64_t per_chunk = std::max<uint64_t>(1, stage_bytes / tri_bytes);
-            for (uint64_t t0 = s; t0 < e; t0 += per_chunk) {
-                const uint64_t n = std::min<uint64_t>(per_chunk, e - t0);
-                const float* src = meshes[i].vertices + (size_t)(t0 - mesh_first[i]) * 3 * meshes[i].stride_floats;
-                hipError_t he = hipMemcpyAsync(staging, src, n * tri_bytes, hipMemcpyHostToDevice, c->stream);
-                if (he == hipSuccess) {
-                    launch_repack((const float*)staging, meshes[i].stride_floats, (uint32_t)n, 0, (uint32_t)n,
-                                  (uint32_t)(t0 - first), tp, c->stream);
-                    he = hipStreamSynchronize(c->stream);  // staging is reused by the next chunk
-                }
-                if (he != hipSuccess) { (void)hipFree(staging); HIPCHK(c, he); }
-            }
-        }
-        (void)hipFree(staging);
+    // ---- geometry: AoS chunks -> pinned -> device staging -> k_repack into the SoA planes ---------------------------
+    const auto t_geo = std::chrono::steady_clock::now();
+    uint32_t turn = 0;
+    for (uint32_t i = 0; i < n_meshes && n_tri; ++i) {
+        const uint64_t s = std::max<uint64_t>(first, mesh_first[i]), e = std::min<uint64_t>(last, mesh_first[i + 1]);
+        if (e <= s) continue;
+        const uint32_t stride = meshes[i].stride_floats;
+        const size_t tri_bytes = (size_t)3 * stride * sizeof(float);
+        const size_t per_chunk = std::max<size_t>(1, kStageChunk / tri_bytes) * tri_bytes;    // whole triangles per chunk
+        const char* src = (const char*)(meshes[i].vertices + (size_t)(s - mesh_first[i]) * 3 * stride);
+        const uint32_t dst0 = (uint32_t)(s - first);
+        const m2s_status st = staged_h2d(c, src, (size_t)(e - s) * tri_bytes, per_chunk, nullptr, turn,
+            [&](char* d, size_t off, size_t n) {
+                launch_repack((const float*)d, stride, (uint32_t)(n / tri_bytes), 0, (uint32_t)(n / tri_bytes),
+                              dst0 + (uint32_t)(off / tri_bytes), tp, c->stream);
+            });
+        if (st != M2S_OK) return st;
     }
+    c->last_upload_ms[1] = ms_since(t_geo);
 
-    // ---- textures: level 0 upload + mip levels 1..4 (glUtils.cpp:292-313) ------------------------
-    std::vector<MeshParams> mp(std::max<uint32_t>(n_meshes, 1));
-    std::map<std::tuple<const uint8_t*, uint32_t, uint32_t>, TexDesc> dedup;
+    // ---- textures: level 0 through the same staging, levels 1..4 on the device (glUtils.cpp:292-313) -----------------
+    const auto t_tex = std::chrono::steady_clock::now();
+    for (TexPlan& p : tex_plan) {
+        uint32_t* mem = (uint32_t*)(A + p.arena_off);
+        p.d.texels = mem;
+        const m2s_status st = staged_h2d(c, (const char*)p.src, (size_t)p.d.w * p.d.h * 4, kStageChunk, (char*)mem, turn,
+                                         [](char*, size_t, size_t) {});
+        if (st != M2S_OK) return st;
+        for (uint32_t l = 1; l < p.d.n_levels; ++l)
+            launch_mip_level(mem + p.d.off[l - 1], std::max(1u, p.d.w >> (l - 1)), std::max(1u, p.d.h >> (l - 1)),
+                             mem + p.d.off[l], std::max(1u, p.d.w >> l), std::max(1u, p.d.h >> l), c->stream);
+    }
+    for (ComboPlan& cp : combo_plan) {
+        uint32_t* mem = (uint32_t*)(A + cp.arena_off);
+        cp.d.texels = mem;
+        const TexDesc &ta = tex_plan[cp.ia].d, &tn = tex_plan[cp.in].d, &tm = tex_plan[cp.im].d;
+        for (uint32_t l = 0; l < ta.n_levels; ++l)
+            launch_combo_level(ta.texels + ta.off[l], tn.texels + tn.off[l], tm.texels + tm.off[l], std::max(1u, ta.w >> l),
+                               std::max(1u, ta.h >> l), mem + cp.d.coff[l], c->stream);
+    }
+    std::vector<MeshParams> mp(n_mp);
+    memset(mp.data(), 0, mp.size() * sizeof(MeshParams));
     for (uint32_t i = 0; i < n_meshes; ++i) {
         const m2s_mesh& m = meshes[i];
         MeshParams& p = mp[i];
-        memset(&p, 0, sizeof p);
         memcpy(p.bmin, m.bbox_min, 12);
         memcpy(p.bmax, m.bbox_max, 12);
         memcpy(p.color, m.base_color, 16);
-        for (int k = 0; k < 3; ++k) {
-            const m2s_texture& t = m.tex[k];
-            if (!t.rgba8) continue;
-            auto key = std::make_tuple(t.rgba8, t.width, t.height);
-            auto it = dedup.find(key);
-            if (it != dedup.end()) { p.tex[k] = it->second; continue; }
-            TexDesc d{};
-            d.w = t.width; d.h = t.height;
-            uint32_t mx = std::max(t.width, t.height), nl = 1;
-            while (mx > 1 && nl < 5) { mx >>= 1; nl++; }
-            d.n_levels = nl;
-            size_t tot = 0;
-            for (uint32_t l = 0; l < nl; ++l) {
-                d.off[l] = (uint32_t)tot;
-                tot += (size_t)std::max(1u, t.width >> l) * std::max(1u, t.height >> l);
-            }
-            void* mem = nullptr;
-            HIPCHK(c, hipMalloc(&mem, tot * 4));
-            c->tex_mem.push_back(mem);
-            d.texels = (const uint32_t*)mem;
-            HIPCHK(c, hipMemcpyAsync(mem, t.rgba8, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice, c->stream));
-            for (uint32_t l = 1; l < nl; ++l)
-                launch_mip_level(d.texels + d.off[l - 1], std::max(1u, t.width >> (l - 1)), std::max(1u, t.height >> (l - 1)),
-                                 (uint32_t*)mem + d.off[l], std::max(1u, t.width >> l), std::max(1u, t.height >> l), c->stream);
-            p.tex[k] = d;
-            dedup[key] = d;
-        }
+        for (int k = 0; k < 3; ++k) if (mesh_tex[i][k] >= 0) p.tex[k] = tex_plan[mesh_tex[i][k]].d;
+        if (mesh_combo[i] >= 0) p.combo = combo_plan[mesh_combo[i]].d;
     }
-    // ---- combo textures (interleaved albedo/normal/MR, see ComboDesc) ----------------------------------
-    {
-        std::map<std::tuple<const uint32_t*, const uint32_t*, const uint32_t*>, ComboDesc> cdedup;
-        for (uint32_t i = 0; i < n_meshes; ++i) {
-            MeshParams& p = mp[i];
-            const TexDesc &ta = p.tex[0], &tn = p.tex[1], &tm = p.tex[2];
-            if (!ta.texels || !tn.texels || !tm.texels) continue;
-            if (ta.w != tn.w || ta.w != tm.w || ta.h != tn.h || ta.h != tm.h) continue;
-            auto key = std::make_tuple(ta.texels, tn.texels, tm.texels);
-            auto it = cdedup.find(key);
-            if (it != cdedup.end()) { p.combo = it->second; continue; }
-            ComboDesc cd{};
-            size_t tot = 0;
-            for (uint32_t l = 0; l < ta.n_levels; ++l) {
-                cd.coff[l] = (uint32_t)tot;
-                tot += (size_t)(std::max(1u, ta.w >> l) + 1) * std::max(1u, ta.h >> l) * 3;
-            }
-            if (tot > 0x3FFFFFF0ull) continue;  // the sampler addresses the combo texels with 32-bit BYTE offsets
-            void* mem = nullptr;
-            HIPCHK(c, hipMalloc(&mem, tot * 4));
-            c->tex_mem.push_back(mem);
-            cd.texels = (const uint32_t*)mem;
-            for (uint32_t l = 0; l < ta.n_levels; ++l)
-                launch_combo_level(ta.texels + ta.off[l], tn.texels + tn.off[l], tm.texels + tm.off[l], std::max(1u, ta.w >> l),
-                                   std::max(1u, ta.h >> l), (uint32_t*)mem + cd.coff[l], c->stream);
-            p.combo = cd;
-            cdedup[key] = cd;
-        }
-    }
-    HIPCHK(c, hipMalloc((void**)&c->d_meshes, mp.size() * sizeof(MeshParams)));
+    c->d_meshes = (MeshParams*)(A + o_meshes);
+    c->d_mesh_first = (uint32_t*)(A + o_mesh_first);
     HIPCHK(c, hipMemcpyAsync(c->d_meshes, mp.data(), mp.size() * sizeof(MeshParams), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMalloc((void**)&c->d_mesh_first, mesh_first.size() * sizeof(uint32_t)));
-    HIPCHK(c, hipMemcpyAsync(c->d_mesh_first, mesh_first.data(), mesh_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mesh_first, mesh_first.data(), mesh_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     c->scene.meshes = c->d_meshes;
     c->scene.mesh_first = c->d_mesh_first;
 
     // ---- work buffers -----------------------------------------------------------------------------
-    HIPCHK(c, hipMalloc((void**)&c->d_cnt, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_off, (np + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_partials, std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_chain, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(c->d_chain, 0, std::max<size_t>(n_fused_waves(n_tri), 1) * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMalloc((void**)&c->d_biglist, np * sizeof(BigItem)));
-    HIPCHK(c, hipMalloc((void**)&c->d_bigmeta, 4 * sizeof(uint32_t)));
+    c->d_cnt = (uint32_t*)(A + o_cnt);
+    c->d_off = (uint32_t*)(A + o_off);
+    c->d_partials = (uint32_t*)(A + o_partials);
+    c->d_chain = (unsigned long long*)(A + o_chain);
+    c->d_biglist = (BigItem*)(A + o_biglist);
+    c->d_bigmeta = (uint32_t*)(A + o_bigmeta);
+    c->d_bands = (unsigned long long*)(A + o_bands);
+    HIPCHK(c, hipMemsetAsync(c->d_chain, 0, chain_words * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries; the caller's buffers are released
+    HIPCHK(c, hipGetLastError());
+    c->last_upload_ms[2] = ms_since(t_tex);
+    c->last_upload_ms[0] = ms_since(t_begin);
     c->has_scene = true;
-    c->last_total = c->last_stored = 0;
-    c->last_records = nullptr;
     return M2S_OK;
 }
 
-// Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless the scene is too
-// small to fill the GPU with 64-triangle batches (k_fused then runs 32 / 16 triangles per wave) or a workgroup's
-// fragments did not fit its LDS stream at this R before.
+m2s_status m2s_last_upload_ms(const m2s_ctx* c, float out_ms[4]) {
+    if (!c || !out_ms) return M2S_ERR_INVALID;
+    memcpy(out_ms, c->last_upload_ms, sizeof c->last_upload_ms);
+    return M2S_OK;
+}
+
+}  // extern "C"
+
 // Chain words carry a 16-bit launch tag instead of being cleared per launch.  The two single-pass kernels use different
 // numbers of words, so a word one of them left behind could read as freshly published 65 536 launches later: when the
 // tag wraps, everything in flight is drained and both chains are cleared (once per ~10 s of back-to-back conversions).
@@ -431,15 +567,23 @@ static hipError_t next_epoch(m2s_ctx* c, uint32_t* out) {
     return r;
 }
 
-static bool use_team(const m2s_ctx* c, uint32_t R) {
-    if (c->pipeline == M2S_PIPELINE_WAVE || c->team_off_R == R) return false;
-    return true;
+// Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless a workgroup's
+// fragments did not fit its LDS stream at this R before.
+static bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    return !(c->pipeline == M2S_PIPELINE_WAVE || ri.team_off);
 }
 
-static BandInfo bands_for(const m2s_ctx* c, uint32_t R) {
-    if (c->band_R == R) return c->bands;
-    BandInfo none{};
-    return none;
+// XCD bands of k_fused2 for this launch: read them if an earlier launch at this R left them behind, otherwise ask this
+// launch to leave them (second lane: never asked to write — two lanes could race on the slot)
+static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, bool may_write, bool* writes) {
+    BandInfo b{};
+    if (writes) *writes = false;
+    const uint32_t bpb = fused2_band_width(c->scene.n_tri);
+    if (!bpb || !c->d_bands || std::getenv("M2S_NO_BANDS")) return b;
+    unsigned long long* slot = c->d_bands + (size_t)ri.band_slot * 8;
+    if (ri.bands_ready) { b.base = slot; b.workgroups_per_band = bpb; }
+    else if (may_write) { b.out = slot; b.out_workgroups_per_band = bpb; if (writes) *writes = true; }
+    return b;
 }
 
 static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
@@ -451,32 +595,109 @@ static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     return std::min(mx, kMaxGaussiansToSort);
 }
 
-// Multi-pass pipeline (count -> scan -> offsets -> emit): handles every triangle size, output-balanced.
-static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, hipStream_t st) {
+// exact fragment count of the scene at R (k_count + scan + read-back): the one host round trip a NEW SCENE pays
+static m2s_status count_now(m2s_ctx* c, uint32_t R, hipStream_t st) {
     const SceneDev& sc = c->scene;
     const bool prof = c->profiling;
-    if (!counted) {
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-        launch_count(sc, R, c->d_cnt, c->d_partials, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-        launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-    }
-    const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
-    if (c->start_cap < n_blocks) {
-        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
-        HIPCHK(c, hipMalloc((void**)&c->d_start, std::max<size_t>(n_blocks, 1) * sizeof(uint32_t)));
-        c->start_cap = n_blocks;
-    }
-    launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
-    launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-    HIPCHK(c, hipGetLastError());
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_count(sc, R, c->d_cnt, c->d_partials, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
     HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    HIPCHK(c, hipStreamSynchronize(st));
     if (prof)
-        for (int k = counted ? 2 : 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+        for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+    c->frag_per_R2 = (double)c->h_total[0] / ((double)R * (double)R);
+    return M2S_OK;
+}
+
+// The context-owned record buffer is a grow-only pool.  The reference re-creates its SSBO whenever the cap changes
+// (ConversionPass.cpp:25-33), i.e. on every move of the density slider; here a change of R costs no allocation: the pool
+// doubles until it reaches the largest size the cap policy can ask for (7 M records = 672 MB for the reference formula).
+static m2s_status ensure_records(m2s_ctx* c, uint64_t want) {
+    if (c->records_cap >= want && c->d_records) return M2S_OK;
+    uint64_t grow = std::max<uint64_t>(want, 1);
+    if (c->records_cap) grow = std::max(grow, 2 * c->records_cap);
+    if (c->cap_policy < 0) grow = std::max(want, std::min<uint64_t>(grow, kMaxGaussiansToSort));
+    drain_in_flight(c);   // nothing may still be writing the buffer that is about to be released
+    if (c->d_records) { (void)hipFree(c->d_records); c->d_records = nullptr; c->records_cap = 0; }
+    hipError_t e = hipMalloc(&c->d_records, grow * sizeof(m2s_gaussian));
+    if (e != hipSuccess && grow > want) { grow = want; e = hipMalloc(&c->d_records, grow * sizeof(m2s_gaussian)); }
+    HIPCHK(c, e);
+    c->records_cap = grow;
+    // in-flight conversions into the old buffer are complete but their records are gone
+    for (uint32_t k = 0; k < c->slot_count; ++k) {
+        auto& sl = c->slot[(c->slot_head + k) % M2S_MAX_IN_FLIGHT];
+        if (sl.own_lane == 0) { sl.d_out = c->d_records; sl.gen = c->buf_gen[0] - 1u; }
+    }
+    return M2S_OK;
+}
+
+// Multi-pass pipeline: handles every triangle size, output-balanced.  Second generation (m2s_emit2.hip): k_count_scan
+// (count + offsets + per-triangle setup records, one kernel) -> k_emit2 (wave-granular).  M2S_MULTIPASS_V1=1 selects the
+// first generation (count -> scan -> offsets -> emit, m2s_kernels.hip) for A/B measurements.
+static bool multipass_v1() { static const bool v1 = std::getenv("M2S_MULTIPASS_V1") != nullptr; return v1; }
+
+static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
+    const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
+    if (c->start_cap < n_start) {
+        drain_in_flight(c);
+        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
+        const size_t want = std::max<size_t>(std::max<size_t>(n_start, 2 * c->start_cap), 16384);
+        HIPCHK(c, hipMalloc((void**)&c->d_start, want * sizeof(uint32_t)));
+        c->start_cap = want;
+    }
+    if (!multipass_v1() && !c->d_setup) HIPCHK(c, hipMalloc(&c->d_setup, setup_bytes(c->scene.n_tri)));
+    return M2S_OK;
+}
+
+// enqueues the pipeline's kernels and the read-back of the counter into *h_res (pinned); no synchronisation
+static m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, bool prof,
+                                    unsigned long long* h_res, hipStream_t st) {
+    const SceneDev& sc = c->scene;
+    if (multipass_v1()) {
+        if (!counted) {
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+            launch_count(sc, R, c->d_cnt, c->d_partials, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+        }
+        const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
+        launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+        launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    } else {
+        uint32_t epoch;
+        HIPCHK(c, next_epoch(c, &epoch));
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
+                          reinterpret_cast<uint32_t*>(&h_res[1]), st);
+        if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
+        launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+    return M2S_OK;
+}
+
+static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, hipStream_t st) {
+    const bool prof = c->profiling;
+    { const m2s_status s = ensure_multipass_buffers(c, limit); if (s != M2S_OK) return s; }
+    c->h_total[0] = 0; c->h_total[1] = 0;
+    { const m2s_status s = enqueue_multipass(c, R, d_out, limit, counted, prof, c->h_total, st); if (s != M2S_OK) return s; }
+    HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
+    if (prof) {
+        if (multipass_v1()) { for (int k = counted ? 2 : 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
+        else {
+            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_COUNT], c->ev[0], c->ev[1]));
+            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
+        }
+    }
     return M2S_OK;
 }
 
@@ -487,10 +708,14 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         return fail(c, M2S_ERR_STATE, "conversions submitted with m2s_convert_submit are still in flight: m2s_convert_wait first");
     if (R == 0 || R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [1, 4096]");
     HIPCHK(c, hipSetDevice(c->device));
+    // A synchronous conversion shares the work buffers (chain, counts, offsets, deferred-triangle list) with whatever
+    // was submitted before it, possibly on other streams: let that finish first.
+    if (from_submit) drain_in_flight(c);
     const SceneDev& sc = c->scene;
     const uint64_t cap = resolve_cap(c, R);
     const bool prof = c->profiling;
     c->last_R = R;
+    c->records_stale = false;
     memset(c->last_ms, 0, sizeof c->last_ms);
 
     if (sc.n_tri == 0) {
@@ -499,105 +724,64 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         if (out_total) *out_total = 0;
         return M2S_OK;
     }
+    m2s_ctx::RInfo& ri = rinfo_for(c, R);
+
+    // ---- AUTO: which pipeline for this scene at this R? ---------------------------------------------
+    // The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
+    // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
+    // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
+    // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).
+    // The fragment count of a scene is proportional to R^2 (window coordinates scale with R), so ONE exact count — taken
+    // at the scene's first conversion, 0.02-0.06 ms plus a host round trip — decides for every later R without touching
+    // the device: the threshold is not sharp, and both pipelines produce the same bytes anyway.
+    bool counted = false;  // k_count + k_scan already ran in this call, at this R
+    const bool need_estimate = (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) || (!d_user && !cap);
+    if (need_estimate && c->frag_per_R2 < 0.0) {
+        const m2s_status s = count_now(c, R, st);
+        if (s != M2S_OK) return s;
+        counted = true;
+    }
+    const double predicted = c->frag_per_R2 >= 0.0 ? c->frag_per_R2 * (double)R * (double)R : 0.0;
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) {
+        ri.decided = true;
+        ri.multipass = (counted ? (double)c->h_total[0] : predicted) >= 11.0 * (double)sc.n_tri;
+    }
 
     // ---- where do the records go, and how many may be stored? ------------------------------------
-    bool counted = false;  // k_count + k_scan already ran in this call
     uint64_t limit;
     float4* d_out;
     if (d_user) {
         limit = cap ? std::min(cap, user_cap) : user_cap;
         d_out = (float4*)d_user;
     } else {
-        uint64_t want = cap;
-        if (!cap && (c->sized_R != R || !c->d_records)) {
-            // unlimited policy: size the SSBO from an exact count (once per (scene, R))
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-            launch_count(sc, R, c->d_cnt, c->d_partials, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-            HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            if (prof)
-                for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
-            counted = true;
-            want = std::max<uint64_t>(c->h_total[0], 1);
-            c->sized_R = R;
-        } else if (!cap) {
-            want = c->records_cap;
-        }
-        // ConversionPass.cpp:25-33: (re)allocate when the size differs (grow-only for the unlimited policy)
-        if ((cap && c->records_cap != want) || (!cap && c->records_cap < want)) {
-            if (c->d_records) { (void)hipFree(c->d_records); c->d_records = nullptr; c->records_cap = 0; }
-            HIPCHK(c, hipMalloc(&c->d_records, want * sizeof(m2s_gaussian)));
-            c->records_cap = want;
-        }
+        // unlimited policy: room for the predicted count plus slack; a conversion that still overflows is repeated below
+        const uint64_t want = cap ? cap : (counted ? std::max<uint64_t>(c->h_total[0], 1) : (uint64_t)(predicted * 1.02) + 4096);
+        const m2s_status s = ensure_records(c, want);
+        if (s != M2S_OK) return s;
         limit = cap ? cap : c->records_cap;
         d_out = (float4*)c->d_records;
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
 
-    // ---- AUTO: which pipeline for this scene at this R? ---------------------------------------------
-    // The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
-    // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
-    // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
-    // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).  The exact count
-    // costs 0.02-0.06 ms and is taken once per (scene, R); the decision is remembered.
-    if (c->pipeline == M2S_PIPELINE_AUTO && c->decided_R != R) {
-        if (!counted) {
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-            launch_count(sc, R, c->d_cnt, c->d_partials, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-            HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            if (prof)
-                for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
-            counted = true;
-        }
-        c->decided_R = R;
-        c->multipass_R = (c->h_total[0] >= 11ull * sc.n_tri) ? R : 0;
-        // XCD bands for k_fused2: the same count tells where the output of each eighth of the triangle list starts
-        // (d_partials now holds the exclusive prefix per 1024 triangles = per 4 workgroups of 256)
-        c->band_R = 0;
-        if (!c->multipass_R && fused_tpw(sc.n_tri) == 64u && !std::getenv("M2S_NO_BANDS")) {
-            const uint32_t wgs = (n_fused_waves(sc.n_tri) + 3u) / 4u;
-            uint32_t bpb = (wgs + 7u) / 8u;
-            bpb = (bpb + 3u) & ~3u;
-            const uint32_t n_part = n_count_blocks(sc.n_tri);
-            uint32_t pre[8];
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t pi = (uint32_t)x * (bpb / 4u);
-                if (pi < n_part) HIPCHK(c, hipMemcpyAsync(&pre[x], c->d_partials + pi, 4, hipMemcpyDeviceToHost, st));
-            }
-            HIPCHK(c, hipStreamSynchronize(st));
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t pi = (uint32_t)x * (bpb / 4u);
-                c->bands.base[x] = pi < n_part ? (unsigned long long)pre[x] : c->h_total[0];
-            }
-            c->bands.workgroups_per_band = bpb;
-            c->band_R = R;
-        }
-    }
-
+    for (int round = 0; round < 2; ++round) {
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
-    if (c->pipeline != M2S_PIPELINE_MULTIPASS && c->multipass_R != R) {
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass) {
         counted = false;   // the fused kernel does its own counting; a count taken above only sized / decided
         // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
         // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
         // counter and its two status words straight into pinned host memory.
         uint32_t any_big = 0, err = 0;
+        bool wrote_bands = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            const bool team = use_team(c, R);
+            const bool team = use_team(c, ri);
             c->h_total[0] = 0;
             c->h_total[1] = 0;
             uint32_t epoch;
             HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
             if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -607,20 +791,21 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+            if (team && !err && wrote_bands) ri.bands_ready = true;
             if (!(err && team)) break;
             // a workgroup's fragments did not fit the team kernel's LDS stream (or a wait timed out): the one-wave-per-batch
             // form has no such limit.  Remember it for this scene and R, forget what the aborted launch listed, try again.
-            c->team_off_R = R;
+            ri.team_off = true;
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
         }
         done = true;
         // a clean single-kernel conversion: the same scene at the same R can be submitted asynchronously from now on
-        c->async_ok_R = (!err && !any_big) ? R : 0;
+        ri.async_ok = !err && !any_big;
         if (err) {
             // The bounded look-back spin gave up (never observed; would need a dispatcher that starves earlier
             // workgroups).  Degrade to the multi-pass pipeline, which has no inter-workgroup dependency.
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
-            c->multipass_R = R;
+            ri.multipass = true;
             done = false;
         } else
         if (any_big) {
@@ -633,7 +818,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
                 // Scene dominated by mid-size / big triangles (e.g. a coarse mesh at high density): one workgroup per
                 // triangle chunk would be mostly empty.  The output-partitioned multi-pass pipeline packs them densely;
                 // remember the decision so that later conversions of this scene at this R go straight to it.
-                c->multipass_R = R;
+                ri.multipass = true;
                 done = false;
             } else {
                 // second stage: emit exactly the deferred triangles, one workgroup per 1024-fragment chunk
@@ -649,17 +834,33 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     if (!done) {
         m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
         if (s != M2S_OK) return s;
-        c->mp_ready_R = R;
+        ri.mp_ready = true;
         c->last_pipeline = M2S_PIPELINE_MULTIPASS;
+    }
+    // unlimited policy, context-owned buffer: the prediction was too low — make room for the exact count and repeat
+    // (never seen with the 2 % slack; the fragment count scales with R^2 up to clipping at the viewport edge)
+    if (!d_user && !cap && c->h_total[0] > limit && limit < 0xFFFFFFFFull && round == 0) {
+        const m2s_status s = ensure_records(c, c->h_total[0]);
+        if (s != M2S_OK) return s;
+        limit = std::min<uint64_t>(c->records_cap, 0xFFFFFFFFull);
+        d_out = (float4*)c->d_records;
+        counted = false;
+        continue;
+    }
+    break;
     }
     const uint64_t total = c->h_total[0];
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
+    c->frag_per_R2 = (double)total / ((double)R * (double)R);
     c->last_total = total;
     c->last_stored = std::min(total, limit);
     c->last_records = d_out;
+    if (!d_user) { if (c->buf_R[0] != R) { c->buf_R[0] = R; ++c->buf_gen[0]; } }
     if (out_total) *out_total = total;
     return M2S_OK;
 }
+
+extern "C" {
 
 m2s_status m2s_convert(m2s_ctx* c, uint32_t R, uint64_t* out_total) {
     if (!c) return M2S_ERR_INVALID;
@@ -685,16 +886,28 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     const uint32_t k = (c->slot_head + c->slot_count) % M2S_MAX_IN_FLIGHT;
     m2s_ctx::Slot& sl = c->slot[k];
     const uint64_t cap = resolve_cap(c, R);
+    m2s_ctx::RInfo& ri = rinfo_for(c, R);
     // Fast path: this scene at this R already converted cleanly with the single kernel (no deferred triangles, so no
     // host decision between kernels) and the output buffer needs no (re)allocation.
-    const bool own_ready = d_records || (cap ? (c->d_records && c->records_cap == cap) : (c->d_records && c->sized_R == R));
-    const bool fast = c->scene.n_tri > 0 && c->async_ok_R == R && c->pipeline != M2S_PIPELINE_MULTIPASS && c->multipass_R != R && own_ready;
+    const bool own_ready = d_records || (c->d_records && c->buf_R[0] == R && (cap ? c->records_cap >= cap : true));
+    const bool fast = c->scene.n_tri > 0 && ri.async_ok && c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass && own_ready;
     // Multi-pass conversions have no host decision between their four kernels either; once this (scene, R) has been
     // converted that way (work buffers sized, AUTO decision taken) they are enqueued without waiting as well.
     // (With kernel timing on they run synchronously: the per-kernel events are shared.)
-    const bool fast_mp = !fast && c->scene.n_tri > 0 && own_ready && !c->profiling && c->mp_ready_R == R &&
-                         (c->pipeline == M2S_PIPELINE_MULTIPASS || (c->decided_R == R && c->multipass_R == R));
+    const bool fast_mp = !fast && c->scene.n_tri > 0 && own_ready && !c->profiling && ri.mp_ready &&
+                         (c->pipeline == M2S_PIPELINE_MULTIPASS || (ri.decided && ri.multipass));
     sl.R = R;
+    sl.wrote_bands = false;
+    sl.own_lane = d_records ? -1 : 0;
+    // All conversions of a context share its work buffers (look-back chain, counts, offsets, the deferred-triangle
+    // list): they must execute in submission order.  On one stream that is automatic; a submission on ANOTHER stream
+    // than the newest one in flight is ordered behind it with an event.  (The second lane is exempt: it has its own
+    // chain and is only taken by single-kernel conversions that touch nothing else.)
+    auto chain_behind_newest = [&](hipStream_t on) -> hipError_t {
+        if (!c->slot_count || c->last_submit_stream == on) return hipSuccess;
+        const m2s_ctx::Slot& prev = c->slot[(c->slot_head + c->slot_count - 1) % M2S_MAX_IN_FLIGHT];
+        return prev.sync_result ? hipSuccess : hipStreamWaitEvent(on, prev.done, 0);
+    };
     if (fast_mp) {
         HIPCHK(c, hipSetDevice(c->device));
         uint64_t limit;
@@ -702,29 +915,27 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
         else { limit = cap ? cap : c->records_cap; d_out = c->d_records; }
         if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
-        const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
-        if (c->start_cap >= n_blocks) {
+        const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
+        if (c->start_cap >= n_start && (multipass_v1() || c->d_setup)) {
+            HIPCHK(c, chain_behind_newest(st));
             unsigned long long* res = &c->h_total[2 + 2 * k];
             res[0] = 0; res[1] = 0;
-            const SceneDev& sc = c->scene;
-            launch_count(sc, R, c->d_cnt, c->d_partials, st);
-            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-            launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
-            launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, (float4*)d_out, n_blocks, st);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(&res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+            { const m2s_status ms_ = enqueue_multipass(c, R, (float4*)d_out, limit, false, false, res, st); if (ms_ != M2S_OK) return ms_; }
             HIPCHK(c, hipEventRecord(sl.done, st));
             c->last_pipeline = M2S_PIPELINE_MULTIPASS;
+            c->last_submit_stream = st;
             sl.prof = false;
             sl.sync_result = false;
             sl.limit = limit;
             sl.d_out = d_out;
+            sl.gen = c->buf_gen[0];
             ++c->slot_count;
             return M2S_OK;
         }
     }
     if (!fast) {
         // first conversion of a (scene, R), or one that needs the second stage / the multi-pass pipeline: run it now
+        // (run_pass first lets everything in flight finish: it may re-allocate the record pool and reuses the work buffers)
         uint64_t total = 0;
         const m2s_status s = run_pass(c, R, d_records, capacity_records, st, &total, true);
         if (s != M2S_OK) return s;
@@ -733,6 +944,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         memcpy(sl.ms, c->last_ms, sizeof sl.ms);   // a later submit overwrites last_ms before this slot is waited for
         sl.limit = c->last_stored;   // already clamped
         sl.d_out = const_cast<void*>(c->last_records);
+        sl.gen = c->buf_gen[0];
         ++c->slot_count;
         return M2S_OK;
     }
@@ -740,6 +952,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     uint64_t limit;
     void* d_out;
     unsigned long long* chain = c->d_chain;
+    bool second_lane = false;
     if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
     else {
         limit = cap ? cap : c->records_cap;
@@ -753,31 +966,45 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
                 HIPCHK(c, hipMalloc((void**)&c->d_chain_b, words * sizeof(unsigned long long)));
                 HIPCHK(c, hipMemsetAsync(c->d_chain_b, 0, words * sizeof(unsigned long long), c->stream_b));
             }
-            if (c->records_b_cap != c->records_cap) {
+            if (c->records_b_cap < c->records_cap) {
+                for (uint32_t q = 0; q < c->slot_count; ++q) {   // nothing may still be writing the old second buffer
+                    auto& o = c->slot[(c->slot_head + q) % M2S_MAX_IN_FLIGHT];
+                    if (o.own_lane == 1 && !o.sync_result) (void)hipEventSynchronize(o.done);
+                }
                 if (c->d_records_b) { (void)hipFree(c->d_records_b); c->d_records_b = nullptr; c->records_b_cap = 0; }
                 HIPCHK(c, hipMalloc(&c->d_records_b, c->records_cap * sizeof(m2s_gaussian)));
                 c->records_b_cap = c->records_cap;
+                ++c->buf_gen[1];
             }
             st = c->stream_b;
             chain = c->d_chain_b;
             d_out = c->d_records_b;
+            second_lane = true;
+            sl.own_lane = 1;
         }
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
+    if (!second_lane && !(c->lanes == 2 && !d_records)) HIPCHK(c, chain_behind_newest(st));
+    if (sl.own_lane >= 0) {
+        if (c->buf_R[sl.own_lane] != R) { c->buf_R[sl.own_lane] = R; ++c->buf_gen[sl.own_lane]; }
+        sl.gen = c->buf_gen[sl.own_lane];
+    }
     unsigned long long* res = &c->h_total[2 + 2 * k];
     res[0] = 0; res[1] = 0;
     sl.prof = c->profiling;
     uint32_t epoch;
     HIPCHK(c, next_epoch(c, &epoch));
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
-    c->last_pipeline = use_team(c, R) ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-    if (use_team(c, R)) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                                      c->d_biglist, c->d_bigmeta, bands_for(c, R), st);
+    const bool team = use_team(c, ri);
+    c->last_pipeline = team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+    if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
+                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
+    if (!second_lane) c->last_submit_stream = st;
     sl.sync_result = false;
     sl.limit = limit;
     sl.d_out = d_out;
@@ -792,9 +1019,15 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     m2s_ctx::Slot& sl = c->slot[k];
     c->slot_head = (c->slot_head + 1) % M2S_MAX_IN_FLIGHT;
     --c->slot_count;
+    // Conversions into a context-owned buffer overwrite each other in order, like repeated draws into one SSBO.  If a
+    // LATER submission at another R has been enqueued into the buffer this conversion wrote, its records are not what
+    // that buffer holds (any more): consumers (m2s_download, m2s_export_ply, m2s_prepass, sorts) then refuse instead of
+    // returning the other conversion's records.
+    const bool stale = sl.own_lane >= 0 && sl.gen != c->buf_gen[sl.own_lane];
     if (sl.sync_result) {   // run_pass already filled last_*
         if (out_total) *out_total = sl.sync_total;
         c->last_total = sl.sync_total; c->last_stored = sl.limit; c->last_records = sl.d_out; c->last_R = sl.R;
+        c->records_stale = stale;
         memcpy(c->last_ms, sl.ms, sizeof sl.ms);
         return M2S_OK;
     }
@@ -803,17 +1036,20 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     const uint32_t any_big = (uint32_t)(c->h_total[3 + 2 * k] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[3 + 2 * k] >> 32);
     memset(c->last_ms, 0, sizeof c->last_ms);
     if (sl.prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], sl.t0, sl.t1));
+    m2s_ctx::RInfo& ri = rinfo_for(c, sl.R);
     if (err || any_big) {   // cannot happen for a scene/R that converted cleanly before; never return partial output silently
-        c->async_ok_R = 0;
+        ri.async_ok = false;
         (void)hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream);
         (void)hipStreamSynchronize(c->stream);
         return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
     }
+    if (sl.wrote_bands) ri.bands_ready = true;   // that launch has completed: its band bases are in place
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);
     c->last_records = sl.d_out;
     c->last_R = sl.R;
+    c->records_stale = stale;
     if (out_total) *out_total = total;
     return M2S_OK;
 }
@@ -825,6 +1061,7 @@ uint64_t m2s_num_triangles(const m2s_ctx* c) { return c ? c->scene.n_tri : 0; }
 m2s_status m2s_download(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_records) {
     if (!c) return M2S_ERR_INVALID;
     if (!c->last_stored) return M2S_OK;
+    if (c->records_stale) return fail(c, M2S_ERR_STATE, kStaleMsg);
     if (!dst) return fail(c, M2S_ERR_INVALID, "dst is NULL");
     if (capacity_records < c->last_stored) return fail(c, M2S_ERR_CAPACITY, "dst holds fewer records than were stored");
     HIPCHK(c, hipSetDevice(c->device));
@@ -846,31 +1083,53 @@ m2s_status m2s_download_triangle_counts(m2s_ctx* c, uint32_t* dst, uint64_t n) {
     return M2S_OK;
 }
 
-m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std) {
-    if (!c || !path) return M2S_ERR_INVALID;
-    if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run");
+// Downloads rows [0, n_rows) of the last conversion's records and writes them as rows [first_row, first_row + n_rows) of
+// a .ply that holds total_rows rows (whole-file export: first_row = 0, n_rows = total_rows = stored records).
+//   format 0 (248 B / row from a 96 B record): the records cross PCIe, host threads encode (a device-side encoder would
+//            inflate the transfer 2.6x);
+//   formats 1, 2 (76 / 48 B per row): the rows are encoded ON THE DEVICE (k_encode_rows, m2s_export.hip) — log scale,
+//            SH-DC colour, logit opacity; for format 2 also the octahedral normal and the u8 packing (parsers.cpp:232-428)
+//            — so what crosses PCIe is the file's own bytes, which go from the pinned buffers straight into the file.
+// Either way chunk k+1 is on the bus while chunk k is written.
+static m2s_status export_rows(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std, uint64_t first_row, uint64_t n_rows,
+                              uint64_t total_rows, bool slice) {
+    if (!c->last_R) return fail(c, M2S_ERR_STATE, "no conversion has run (uploaded records carry no resolutionTarget: use m2s_write_ply)");
+    if (c->records_stale) return fail(c, M2S_ERR_STATE, kStaleMsg);
+    if (n_rows > c->last_stored) return fail(c, M2S_ERR_INVALID, "more rows requested than the last conversion stored");
     HIPCHK(c, hipSetDevice(c->device));
+    if (format > 2) format = 0;          // parsers.cpp:646-648
     // SceneManager.cpp:668
     const float scale_multiplier = gaussian_std / static_cast<float>(c->last_R);
-    // The records come down in chunks through two pinned buffers: while chunk k is encoded and written, chunk k+1 is on the
-    // PCIe bus (the reference maps the whole SSBO, then issues 62 stream writes per Gaussian from one thread).
-    const uint64_t n = c->last_stored;
     const size_t chunk = m2s_ply::kChunkRows;
     for (int k = 0; k < 2; ++k)
         if (!c->h_export[k]) HIPCHK(c, hipHostMalloc((void**)&c->h_export[k], chunk * sizeof(m2s_gaussian), hipHostMallocDefault));
     m2s_ply::Writer w;
-    m2s_status s = w.open(path, n, format, scale_multiplier);
+    m2s_status s = slice ? w.open_slice(path, total_rows, format, scale_multiplier, first_row, n_rows)
+                         : w.open(path, total_rows, format, scale_multiplier);
     if (s != M2S_OK) { c->err = std::string("could not write ") + path; return s; }
+    const bool on_device = format != 0 && !std::getenv("M2S_HOST_ENCODE");
+    const size_t unit = on_device ? w.row_bytes() : sizeof(m2s_gaussian);     // bytes per row on the bus
     const char* src = static_cast<const char*>(c->last_records);
-    auto rows_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(chunk, n - k * chunk); };
-    const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_export[0], src, rows_of(0) * sizeof(m2s_gaussian), hipMemcpyDeviceToHost, c->stream));
+    if (on_device && n_rows) {
+        const uint64_t need = n_rows * unit;
+        if (c->rows_cap < need) {
+            if (c->d_rows) { (void)hipFree(c->d_rows); c->d_rows = nullptr; c->rows_cap = 0; }
+            HIPCHK(c, hipMalloc(&c->d_rows, need));
+            c->rows_cap = need;
+        }
+        launch_encode_rows((const float4*)c->last_records, n_rows, format, scale_multiplier, (uint8_t*)c->d_rows, c->stream);
+        HIPCHK(c, hipGetLastError());
+        src = static_cast<const char*>(c->d_rows);
+    }
+    auto rows_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(chunk, n_rows - k * chunk); };
+    const uint64_t n_chunks = (n_rows + chunk - 1) / chunk;
+    if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_export[0], src, rows_of(0) * unit, hipMemcpyDeviceToHost, c->stream));
     for (uint64_t k = 0; k < n_chunks && s == M2S_OK; ++k) {
         HIPCHK(c, hipStreamSynchronize(c->stream));                      // chunk k has arrived
         if (k + 1 < n_chunks)
-            HIPCHK(c, hipMemcpyAsync(c->h_export[(k + 1) & 1], src + (k + 1) * chunk * sizeof(m2s_gaussian), rows_of(k + 1) * sizeof(m2s_gaussian),
-                                     hipMemcpyDeviceToHost, c->stream));
-        s = w.append(c->h_export[k & 1], rows_of(k));                    // returns once the pinned buffer has been read
+            HIPCHK(c, hipMemcpyAsync(c->h_export[(k + 1) & 1], src + (k + 1) * chunk * unit, rows_of(k + 1) * unit, hipMemcpyDeviceToHost, c->stream));
+        // (both return once the pinned buffer has been read)
+        s = on_device ? w.append_encoded(reinterpret_cast<const uint8_t*>(c->h_export[k & 1]), rows_of(k)) : w.append(c->h_export[k & 1], rows_of(k));
     }
     const m2s_status cs = w.close();
     if (s == M2S_OK) s = cs;
@@ -878,10 +1137,23 @@ m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float g
     return s;
 }
 
+m2s_status m2s_export_ply(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std) {
+    if (!c || !path) return M2S_ERR_INVALID;
+    return export_rows(c, path, format, gaussian_std, 0, c->last_stored, c->last_stored, false);
+}
+
+m2s_status m2s_export_ply_slice(m2s_ctx* c, const char* path, uint32_t format, float gaussian_std, uint64_t first_row, uint64_t n_rows,
+                                uint64_t total_rows) {
+    if (!c || !path) return M2S_ERR_INVALID;
+    if (first_row > total_rows || n_rows > total_rows - first_row) return fail(c, M2S_ERR_INVALID, "slice exceeds the file");
+    return export_rows(c, path, format, gaussian_std, first_row, n_rows, total_rows, true);
+}
+
 // RadixSortPass::execute (RadixSortPass.cpp:8-90) on the records of the last conversion.
 m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t* out_n) {
     if (!c || !world_to_view) return M2S_ERR_INVALID;
     if (!c->last_records) return fail(c, M2S_ERR_STATE, "no conversion has run and no records were uploaded");
+    if (c->records_stale) return fail(c, M2S_ERR_STATE, kStaleMsg);
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t n = c->last_stored;
     c->sorted_n = 0;
@@ -944,6 +1216,8 @@ m2s_status m2s_upload_records(m2s_ctx* c, const m2s_gaussian* records, uint64_t 
     if (n) HIPCHK(c, hipMemcpy(c->d_loaded, records, n * sizeof(m2s_gaussian), hipMemcpyHostToDevice));
     c->last_records = c->d_loaded;
     c->last_total = c->last_stored = n;
+    c->records_stale = false;
+    c->last_R = 0;      // uploaded records carry no resolutionTarget: m2s_export_ply (scale multiplier = std / R) refuses them
     c->sorted_n = 0;
     c->pp_visible = 0;
     c->sq_n = 0;
@@ -956,6 +1230,7 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (!d_records) {
         if (!c->last_records) return fail(c, M2S_ERR_STATE, "no conversion has run, no records were uploaded and none were passed");
+        if (c->records_stale) return fail(c, M2S_ERR_STATE, kStaleMsg);
         d_records = c->last_records;
         n = c->last_stored;
     }
@@ -1095,7 +1370,7 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_TEAM) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
-        c->decided_R = 0; c->multipass_R = 0; c->team_off_R = 0; c->async_ok_R = 0; c->mp_ready_R = 0; c->band_R = 0;
+        c->rinfo.clear();
     }
     c->pipeline = pipeline;
     return M2S_OK;

@@ -84,11 +84,30 @@ void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tr
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
                  const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
 
-// XCD bands of k_fused2 (see m2s_fused2.hip): workgroups_per_band == 0 switches banding off
+// second-generation multi-pass pipeline (m2s_emit2.hip): count + scan + offsets in one kernel, wave-granular emit
+uint32_t emit2_slices(uint64_t limit);       // entries of start[] needed for `limit` output records
+uint32_t count_scan_blocks(uint32_t n_tri);  // chain words k_count_scan uses
+size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array
+void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, hipStream_t st);
+void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
+                  uint64_t limit, const void* setup, float4* out, hipStream_t st);
+
+// device-side .ply row encoder, formats 1 and 2 (m2s_export.hip)
+void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float scale_multiplier, uint8_t* out, hipStream_t st);
+
+// XCD bands of k_fused2 (see m2s_fused2.hip): workgroups_per_band == 0 switches banding off.  The band bases live in
+// DEVICE memory: a launch without bands leaves them behind as a by-product (every workgroup that would start a band
+// writes the base it resolved to `out`), the next launch of the same scene at the same R reads them — no counting
+// kernel, no host round trip (round 1 took them from k_count's partial sums through eight small copies).
 struct BandInfo {
-    unsigned long long base[8];       // record index at which each band's output starts
-    uint32_t workgroups_per_band;     // multiple of 4 (a band then starts on a k_count block boundary)
+    const unsigned long long* base;   // [8] record index at which each band's output starts (device memory); read when workgroups_per_band != 0
+    uint32_t workgroups_per_band;     // multiple of 4
+    unsigned long long* out;          // [8] or nullptr: where a launch WITHOUT bands records the bases for out_workgroups_per_band
+    uint32_t out_workgroups_per_band;
 };
+// band width for a scene of n_tri triangles (0: the scene is too small for 64-triangle batches, no bands)
+uint32_t fused2_band_width(uint32_t n_tri);
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const BandInfo& bands, hipStream_t st);

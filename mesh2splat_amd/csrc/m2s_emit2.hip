@@ -1,0 +1,354 @@
+// m2s_emit2.hip — the multi-pass pipeline, second generation (gfx950): two kernels, every triangle set up ONCE.
+//
+// The first generation (m2s_kernels.hip: k_count -> k_scan_partials -> k_offsets -> k_emit) is what scenes with mid-size
+// and large triangles take (tens to millions of fragments per triangle: Sponza-like content, coarse meshes at high
+// density).  Measured on the C4 stand-in (248 832 triangles, 8.27 M fragments, 7 M stored; profiles/r02): k_emit 0.336 ms
+// = 2.1 TB/s of algorithmic bytes, waves waiting 70 % of their cycles; k_count 0.062 ms with ONE workgroup per CU; two
+// tiny kernels plus three dependent-launch gaps in between.  What was wrong with it:
+//   * k_emit's workgroup of 4 waves marches in lock step: expansion (a few dozen busy lanes), barrier, then four rounds of
+//     shade -> barrier -> store -> barrier; 48 KB of LDS per workgroup;
+//   * every workgroup sets its triangles up again (positions, mesh lookup, GS, raster setup, Scale / quaternion / LODs);
+//   * k_count walks 4 triangles per thread in 243 workgroups: a latency chain with 4 waves per CU.
+//
+// Here:
+//   k_count_scan  1 thread / triangle, 256 triangles / workgroup.  GS + raster setup + exact count (row walker), the
+//                 fragment stage's per-triangle constants (TriShade) and the three edge functions are written to a
+//                 112-byte TriSetup record, and the SAME kernel turns the counts into output offsets with a decoupled
+//                 look-back over the context's chain words (one word per workgroup): no scan kernel, no offsets kernel.
+//                 It also fills start[]: the triangle that owns output record m * 512.
+//   k_emit2       every WAVE owns 512 consecutive output records and never synchronises with another wave: it loads the
+//                 TriSetup of the (typically 5-60) triangles overlapping its slice, expands them into an LDS entry list
+//                 (row walker; triangles of more than 32 rows wave-cooperatively), and shades strips of 64 entries
+//                 exactly like the single-pass kernel does: record staged half a wave at a time, 16 B/lane non-temporal
+//                 stores.  10.5 KB of LDS per wave.  Output-partitioned, so balanced for ANY triangle size.
+// Output: bit-identical to every other pipeline (same device functions, same operation order).
+#include "m2s_fused_common.h"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace m2s {
+
+constexpr int kSlice = 512;            // output records per wave in k_emit2
+constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_scan
+
+// What k_emit2 needs to know about a triangle: the fragment stage's constants plus the third edge function and the
+// pixel bounding box (the first two edges and the box origin are in the TriShade).  7 x 16 bytes.
+struct TriSetup {
+    TriShade ts;
+    int a0, b0;          // edge function opposite vertex 0 ...
+    long long e0;        // ... and its value at the centre of pixel (x0, y0)
+    uint32_t ext;        // x1 | y1 << 12 | bias << 24
+    uint32_t pad[3];
+};
+static_assert(sizeof(TriSetup) == 112, "TriSetup must be seven float4");
+
+__device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
+    Raster r;
+    const int x0 = (int)(s.ts.org & 0xFFFu), y0 = (int)(s.ts.org >> 12);
+    const long long Px0 = 256ll * x0 + 128, Py0 = 256ll * y0 + 128;
+    r.a[0] = s.a0; r.b[0] = s.b0; r.a[1] = s.ts.a1; r.b[1] = s.ts.b1; r.a[2] = s.ts.a2; r.b[2] = s.ts.b2;
+    r.c[0] = s.e0 - (long long)s.a0 * Px0 - (long long)s.b0 * Py0;
+    r.c[1] = s.ts.e1 - (long long)s.ts.a1 * Px0 - (long long)s.ts.b1 * Py0;
+    r.c[2] = s.ts.e2 - (long long)s.ts.a2 * Px0 - (long long)s.ts.b2 * Py0;
+    r.area2 = 1; r.ext = 0;
+    r.bias = (int)(s.ext >> 24);
+    r.x0 = x0; r.y0 = y0; r.x1 = (int)(s.ext & 0xFFFu); r.y1 = (int)((s.ext >> 12) & 0xFFFu);
+    return r;
+}
+
+// ============================================================================================
+// k_count_scan
+// ============================================================================================
+__global__ void __launch_bounds__(kCountBlock) k_count_scan(SceneDev sc, uint32_t R, uint32_t* __restrict__ off,
+                                                            uint32_t* __restrict__ start, uint32_t n_start,
+                                                            unsigned long long* __restrict__ chain, uint32_t epoch,
+                                                            unsigned long long* __restrict__ total_out,
+                                                            float4* __restrict__ setup, uint32_t* __restrict__ status) {
+    __shared__ uint32_t wsum[kCountBlock / 64];
+    __shared__ unsigned long long base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blockBase = blockIdx.x * kCountBlock;
+    const uint32_t t = blockBase + threadIdx.x;
+    const bool valid = t < sc.n_tri;
+    const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
+    const uint32_t m0 = find_mesh(sc, sc.tri_first + blockBase);
+    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+
+    float p[9];
+    Geo g;
+    Raster rs;
+    bool ok = false;
+    uint32_t m = m0;
+    float4 uvb0 = make_float4(0, 0, 0, 0);
+    float2 uvb1 = make_float2(0, 0);
+    if (valid) {
+        load_positions(sc.tri, t, p);
+        uvb0 = sc.tri.B0[t];
+        uvb1 = sc.tri.B1[t];
+        if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
+        geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+        ok = raster_setup(g, R, rs);
+    }
+    const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
+    uint32_t c = 0;
+    if (ok && rows <= kRowsCount) {
+        RowWalker rw;
+        row_walker_init(rs, rs.y0, rw);
+        for (int y = rs.y0; y <= rs.y1; ++y) {
+            int xa, xb;
+            row_walker_next(rw, xa, xb);
+            c += (uint32_t)max(xb - xa + 1, 0);
+        }
+    }
+    {   // triangles spanning more rows: the whole wave counts one triangle, one row per lane
+        unsigned long long big = __ballot(ok && rows > kRowsCount);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const Raster b = shfl_raster(rs, src);
+            uint32_t part = 0;
+            for (int y = b.y0 + lane; y <= b.y1; y += 64) {
+                int xa, xb;
+                row_span(b, y, xa, xb);
+                part += (uint32_t)max(xb - xa + 1, 0);
+            }
+            part = wave_sum(part);
+            if (lane == src) c = part;
+        }
+    }
+    if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
+        TriSetup s;
+        tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
+        s.ts.mesh |= m;
+        const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+        s.a0 = rs.a[0]; s.b0 = rs.b[0];
+        s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
+        s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
+        s.pad[0] = s.pad[1] = s.pad[2] = 0;
+        const float4* src4 = reinterpret_cast<const float4*>(&s);
+        float4* dst4 = setup + (size_t)t * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
+    }
+
+    // ---- counts -> offsets: workgroup scan + decoupled look-back (chain word = one per workgroup) ----
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kCountBlock / 64; ++w) {
+        if (w < wave) woff += wsum[w];
+        tot += wsum[w];
+    }
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    if (wave == 0) {
+        const uint32_t b = blockIdx.x;
+        if (lane == 0) chain_store(&chain[b], (b == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+        const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
+        if (lane == 0) {
+            if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
+            base_s = base;
+            if (b == gridDim.x - 1) *total_out = base + tot;
+        }
+    }
+    __syncthreads();
+    const unsigned long long base = base_s;
+    const unsigned long long o0 = base + woff + (incl - c);
+    if (valid) {
+        // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
+        const unsigned long long o1 = o0 + c;
+        off[t] = (uint32_t)min(o0, 0xFFFFFFFFull);
+        if (t == sc.n_tri - 1) off[sc.n_tri] = (uint32_t)min(o1, 0xFFFFFFFFull);
+    }
+    // start[m] = the triangle that owns output record m * kSlice.  A triangle covering many slices (up to 32 768 for a
+    // 4096 x 4096 px one) has the whole wave write them.
+    const unsigned long long mf = (o0 + kSlice - 1) / kSlice, ml = c ? (o0 + c - 1) / kSlice : 0;
+    const bool few = valid && c && ml >= mf && (ml - mf) < 16;
+    if (few)
+        for (unsigned long long mm = mf; mm <= ml && mm < n_start; ++mm) start[mm] = t;
+    unsigned long long many = __ballot(valid && c && ml >= mf && !few);
+    while (many) {
+        const int src = __ffsll((long long)many) - 1;
+        many &= many - 1;
+        const unsigned long long f = __shfl(mf, src), l = __shfl(ml, src);
+        const uint32_t tt = __shfl(t, src);
+        for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) start[mm] = tt;
+    }
+}
+
+// ============================================================================================
+// k_emit2
+// ============================================================================================
+struct Emit2Lds {
+    float4 tri[64 * 5];          // TriShade of the current batch of (up to) 64 triangles
+    uint32_t entries[kSlice];    // slot << 24 | y << 12 | x, indexed by (record index - slice base)
+    float4 stage[32 * 6];        // half-wave record staging
+    uint32_t row_off[64];        // wave-cooperative expansion of tall triangles: row-length prefix ...
+    int row_xa[64];              // ... and first covered column of 64 consecutive rows
+};
+
+__global__ void __launch_bounds__(kBlock, 3) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ start,
+                                                     const unsigned long long* __restrict__ total_p, unsigned long long limit,
+                                                     const float4* __restrict__ setup, float4* __restrict__ out) {
+    __shared__ Emit2Lds lds_all[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Emit2Lds& L = lds_all[wave];
+    const unsigned long long total = *total_p;
+    const unsigned long long nw = total < limit ? total : limit;  // records actually stored
+    // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): every XCD gets one CONTIGUOUS part
+    // of the output — of the mesh surface, of texture space — instead of every 8th workgroup.
+    const uint32_t per_wg = kSlice * (kBlock / 64);
+    const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
+    const uint32_t per_xcd = (nblk + 7) / 8;
+    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || lblock >= nblk) return;
+    const uint32_t slice = lblock * (kBlock / 64) + wave;
+    const unsigned long long wbase64 = (unsigned long long)slice * kSlice;
+    if (wbase64 >= nw) return;
+    const uint32_t wbase = (uint32_t)wbase64;
+    const uint32_t wend = (uint32_t)(nw - wbase64 < (unsigned long long)kSlice ? nw : wbase64 + kSlice);
+    const uint32_t T = sc.n_tri;
+
+    uint32_t pos = wbase;                 // next record to produce
+    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; t_cur += 64) {
+        // ---- the batch: 64 consecutive triangles, one per lane ----
+        const uint32_t t = t_cur + lane;
+        uint32_t o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
+        if (t < T) { o0 = off[t]; o1 = off[t + 1]; }
+        // records of this batch: [pos, bend)
+        const uint32_t t_next = min(t_cur + 64u, T);
+        const uint32_t o_next = off[t_next];                 // (scalar) first record of the next batch
+        const uint32_t bend = min(wend, o_next);
+        const bool active = (o1 > o0) && (o0 < bend) && (o1 > pos);
+        Raster rs;
+        rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.bias = 0; rs.area2 = 1; rs.ext = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
+        if (active) {
+            TriSetup s;
+            const float4* src4 = setup + (size_t)t * 7;
+            float4* dst4 = reinterpret_cast<float4*>(&s);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) L.tri[lane * 5 + k] = dst4[k];
+            rs = raster_from_setup(s);
+        }
+        // ---- expansion: (triangle slot, pixel) entries of [pos, bend), in canonical order ----
+        const uint32_t tag = (uint32_t)lane << 24;
+        const int rows = active ? rs.y1 - rs.y0 + 1 : 0;
+        if (active && rows <= kRowsThread) {
+            uint32_t k = o0;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
+            for (int y = rs.y0; y <= rs.y1 && k < bend; ++y) {
+                int xa, xb;
+                row_walker_next(rw, xa, xb);
+                const uint32_t len = (uint32_t)max(xb - xa + 1, 0);
+                if (k + len > pos) {
+                    for (int x = xa; x <= xb; ++x, ++k)
+                        if (k >= pos && k < bend) L.entries[k - wbase] = tag | ((uint32_t)y << 12) | (uint32_t)x;
+                } else k += len;
+            }
+        }
+        unsigned long long big = __ballot(active && rows > kRowsThread);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const Raster b = shfl_raster(rs, src);
+            const uint32_t btag = (uint32_t)src << 24;
+            uint32_t acc = __shfl(o0, src);
+            for (int yc = b.y0; yc <= b.y1 && acc < bend; yc += 64) {
+                const int y = yc + lane;
+                int xa = 0, xb = -1;
+                if (y <= b.y1) row_span(b, y, xa, xb);
+                const uint32_t len = (uint32_t)max(xb - xa + 1, 0);
+                const uint32_t incl = wave_incl_scan(len, lane);
+                const uint32_t chunk = __shfl(incl, 63);
+                if (acc + chunk > pos) {
+                    wave_lds_sync();
+                    L.row_off[lane] = incl - len;
+                    L.row_xa[lane] = xa;
+                    wave_lds_sync();
+                    const uint32_t lo = acc < pos ? pos - acc : 0;
+                    const uint32_t hi = acc + chunk > bend ? bend - acc : chunk;
+                    for (uint32_t k = lo + lane; k < hi; k += 64) {
+                        int r = 0;  // largest r with row_off[r] <= k
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1)
+                            if (L.row_off[r + step] <= k) r += step;
+                        const int x = L.row_xa[r] + (int)(k - L.row_off[r]);
+                        L.entries[acc + k - wbase] = btag | ((uint32_t)(yc + r) << 12) | (uint32_t)x;
+                    }
+                }
+                acc += chunk;
+            }
+        }
+        wave_lds_sync();
+        // ---- fragment phase: strips of 64 entries ----
+        for (uint32_t s0 = pos; s0 < bend; s0 += 64) {
+            const uint32_t n = min(64u, bend - s0);
+            const bool have = (uint32_t)lane < n;
+            uint32_t en = 0;
+            if (have) en = L.entries[s0 - wbase + lane];
+            const uint32_t tl = (en >> 24) & 63u;
+            uint32_t my_mesh = 0;
+            if (have) my_mesh = reinterpret_cast<const uint32_t*>(&L.tri[tl * 5 + 4])[3] & 0xFFFFFFu;
+            const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
+            const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
+            float4 rec[6];
+            if (have) {
+                const TriShade& ts = *reinterpret_cast<const TriShade*>(&L.tri[tl * 5]);
+                const uint32_t tt = t_cur + tl;
+                if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
+                else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
+            }
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                if (have && (lane >> 5) == half) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L.stage[(lane & 31) * 6 + k] = rec[k];
+                }
+                wave_lds_sync();
+                float4* __restrict__ dsto = out + ((size_t)s0 + 32u * half) * 6;
+                const uint32_t nv = n > 32u * half ? min(32u, n - 32u * half) : 0u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t q = (uint32_t)lane + 64u * j;
+                    const uint32_t r = q / 6u;
+                    if (r < nv) nt_store(&dsto[q], L.stage[q]);
+                }
+                wave_lds_sync();
+            }
+        }
+        pos = bend;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+uint32_t emit2_slices(uint64_t limit) { return (uint32_t)((limit + kSlice - 1) / kSlice); }
+uint32_t count_scan_blocks(uint32_t n_tri) { return (n_tri + kCountBlock - 1) / kCountBlock; }
+size_t setup_bytes(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
+
+void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, hipStream_t st) {
+    if (!sc.n_tri) return;
+    hipLaunchKernelGGL(k_count_scan, dim3(count_scan_blocks(sc.n_tri)), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
+                       epoch & 0xFFFFu, total, (float4*)setup, status);
+}
+
+void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
+                  uint64_t limit, const void* setup, float4* out, hipStream_t st) {
+    if (!sc.n_tri || !limit) return;
+    const uint32_t per_wg = kSlice * (kBlock / 64);
+    uint32_t n_blocks = (uint32_t)((limit + per_wg - 1) / per_wg);
+    n_blocks = (n_blocks + 7u) & ~7u;  // the XCD swizzle needs whole groups of 8
+    hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
+                       (const float4*)setup, out);
+}
+
+}  // namespace m2s

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     if (wave == 0 && lane == 0) {
         S.claimed = 0; S.irregular = 0; S.error = 0;
         S.base_state = (b0 == 0 || band_first) ? 2u : 0u;
-        S.base = band_first ? bands.base[xcd] : 0ull;
+        S.base = band_first ? bands.base[xcd] : 0ull;   // scalar load from device memory
     }
     __syncthreads();
 
@@ -436,6 +436,8 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
         if (have_base && lane == 0) {
             chain_store(&chain[b0 + nb_here - 1], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (b0 + nb_here == n_batches) *total_out = base + out_total;
+            // by-product of a launch without bands: where each band of the NEXT launch at this R starts
+            if (bands.out && lb % bands.out_workgroups_per_band == 0u) bands.out[lb / bands.out_workgroups_per_band] = base;
         }
     }
     if (lds_load(&S.error) && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -450,11 +452,18 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     BandInfo b = bands;
-    if (tpw != 64u || kTeam != 4) b.workgroups_per_band = 0;   // band bases come from 1024-triangle count blocks
-    if (b.workgroups_per_band) nb = 8u * b.workgroups_per_band;
+    if (tpw != 64u || kTeam != 4) { b.workgroups_per_band = 0; b.out = nullptr; }
+    if (b.workgroups_per_band) { nb = 8u * b.workgroups_per_band; b.out = nullptr; }
     else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta, tpw, b);
+}
+
+uint32_t fused2_band_width(uint32_t n_tri) {
+    if (fused_tpw(n_tri) != 64u || kTeam != 4) return 0;
+    const uint32_t wgs = (n_fused_waves(n_tri) + 3u) / 4u;
+    const uint32_t bpb = (wgs + 7u) / 8u;
+    return (bpb + 3u) & ~3u;
 }
 
 #ifdef M2S_TIMING

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <atomic>
 #include <map>
@@ -135,15 +136,31 @@ bool get_accessor(const Glb& g, long long idx, Accessor& a, std::string& err) {
     if (bv["buffer"].int_or(0) != 0) { err = "only the GLB-embedded buffer 0 is supported"; return false; }
     a.component = (int)acc["componentType"].int_or(0);
     a.ncomp = type_ncomp(acc["type"].string_or(""));
-    a.count = (size_t)acc["count"].int_or(0);
     a.normalized = acc["normalized"].kind == m2s_json::Value::Bool && acc["normalized"].b;
     const size_t elem = (size_t)comp_size(a.component) * a.ncomp;
     if (!elem) { err = "unsupported accessor type"; return false; }
-    a.stride = (size_t)bv["byteStride"].int_or(0);
-    if (!a.stride) a.stride = elem;
-    const size_t off = (size_t)bv["byteOffset"].int_or(0) + (size_t)acc["byteOffset"].int_or(0);
-    if (a.count && off + (a.count - 1) * a.stride + elem > g.bin_len) { err = "accessor exceeds the binary chunk"; return false; }
+    // Every quantity below comes from the (untrusted) JSON chunk: reject negatives before any cast and bound the
+    // element range without forming off + (count-1)*stride + elem, which can wrap.
+    const long long count = acc["count"].int_or(0), stride = bv["byteStride"].int_or(0);
+    const long long bvo = bv["byteOffset"].int_or(0), aco = acc["byteOffset"].int_or(0);
+    if (count < 0 || stride < 0 || bvo < 0 || aco < 0) { err = "negative accessor field"; return false; }
+    if ((unsigned long long)bvo > g.bin_len || (unsigned long long)aco > g.bin_len - (size_t)bvo) { err = "accessor exceeds the binary chunk"; return false; }
+    const size_t off = (size_t)bvo + (size_t)aco;
+    a.stride = stride ? (size_t)stride : elem;
+    a.count = (size_t)count;
+    if (a.count) {
+        const size_t room = g.bin_len - off;               // bytes from the first element to the end of the chunk
+        if (room < elem || (a.count - 1) > (room - elem) / a.stride) { err = "accessor exceeds the binary chunk"; return false; }
+    }
     a.base = g.bin + off;
+    return true;
+}
+
+// byteOffset/byteLength of a bufferView, validated against the binary chunk (both come from untrusted JSON)
+static bool view_range(const m2s_json::Value& bv, size_t bin_len, size_t& off, size_t& len) {
+    const long long o = bv["byteOffset"].int_or(0), l = bv["byteLength"].int_or(0);
+    if (o < 0 || l < 0 || (unsigned long long)o > bin_len || (unsigned long long)l > bin_len - (size_t)o) return false;
+    off = (size_t)o; len = (size_t)l;
     return true;
 }
 
@@ -214,10 +231,18 @@ template <class F>
 static void parallel_for(size_t n, size_t grain, F f) {
     const size_t T = std::min<size_t>(host_threads(), n / std::max<size_t>(grain, 1));
     if (T <= 1) { f((size_t)0, n); return; }
+    // an exception inside a worker is carried to the calling thread (first one wins) instead of std::terminate
     std::vector<std::thread> pool;
-    for (size_t i = 1; i < T; ++i) pool.emplace_back([=] { f(i * n / T, (i + 1) * n / T); });
-    f((size_t)0, n / T);
+    std::exception_ptr first_error;
+    std::mutex error_lock;
+    auto guarded = [&](size_t b, size_t e) {
+        try { f(b, e); }
+        catch (...) { std::lock_guard<std::mutex> lk(error_lock); if (!first_error) first_error = std::current_exception(); }
+    };
+    for (size_t i = 1; i < T; ++i) pool.emplace_back([&guarded, i, n, T] { guarded(i * n / T, (i + 1) * n / T); });
+    guarded((size_t)0, n / T);
     for (auto& th : pool) th.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
@@ -298,8 +323,8 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
             const long long bvi = im["bufferView"].int_or(-1);
             const auto& bv = doc["bufferViews"][(size_t)bvi];
             if (bvi < 0 || !bv.is_object()) continue;
-            const size_t off = (size_t)bv["byteOffset"].int_or(0), len = (size_t)bv["byteLength"].int_or(0);
-            if (off + len > g.bin_len) continue;                         // reported when (if) the image is used
+            size_t off = 0, len = 0;
+            if (!view_range(bv, g.bin_len, off, len)) continue;          // reported when (if) the image is used
             PreDecoded& pd = predecoded[src];
             pd.enc = g.bin + off;
             pd.len = len;
@@ -317,7 +342,11 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
             for (size_t i; (i = decode_next.fetch_add(1)) < decode_work.size();) {
                 PreDecoded& pd = *decode_work[i];
                 const bool is_jpeg = pd.len >= 3 && pd.enc[0] == 0xFF && pd.enc[1] == 0xD8 && pd.enc[2] == 0xFF;
-                pd.ok = is_jpeg ? decode_jpeg(pd.enc, pd.len, pd.img, pd.perr) : decode_png(pd.enc, pd.len, pd.img, pd.perr);
+                // a decoder that throws (bad_alloc on a header claiming a huge image) must not take the process down
+                // from inside a worker thread: record it like any other decode failure
+                try { pd.ok = is_jpeg ? decode_jpeg(pd.enc, pd.len, pd.img, pd.perr) : decode_png(pd.enc, pd.len, pd.img, pd.perr); }
+                catch (const std::exception& e) { pd.ok = false; pd.perr = std::string("decoder failed: ") + e.what(); }
+                catch (...) { pd.ok = false; pd.perr = "decoder failed"; }
             }
         };
         const size_t n_threads = std::min<size_t>(host_threads(), decode_work.size());
@@ -343,9 +372,8 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         const long long bvi = im["bufferView"].int_or(-1);
         const auto& bv = doc["bufferViews"][(size_t)bvi];
         if (bvi >= 0 && bv.is_object()) {
-            const size_t off = (size_t)bv["byteOffset"].int_or(0);
-            len = (size_t)bv["byteLength"].int_or(0);
-            if (off + len > g.bin_len) { err = "image bufferView exceeds the binary chunk"; return false; }
+            size_t off = 0;
+            if (!view_range(bv, g.bin_len, off, len)) { err = "image bufferView exceeds the binary chunk"; return false; }
             enc = g.bin + off;
         } else {
             const std::string uri = im["uri"].string_or("");

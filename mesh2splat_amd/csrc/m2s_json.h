@@ -3,6 +3,7 @@
 // escapes (\uXXXX -> UTF-8), numbers, true/false/null.  Header-only, host-only.
 #pragma once
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -43,7 +44,11 @@ struct Value {
     }
     size_t size() const { return kind == Arr ? arr->size() : kind == Obj ? obj->size() : 0; }
     double number_or(double d) const { return kind == Number ? num : d; }
-    long long int_or(long long d) const { return kind == Number ? (long long)std::llround(num) : d; }
+    // NaN / out-of-range numbers (llround would be undefined) read as "absent"
+    long long int_or(long long d) const {
+        if (kind != Number || !(num > -9.0e18 && num < 9.0e18)) return d;
+        return (long long)std::llround(num);
+    }
     std::string string_or(const std::string& d) const { return kind == String ? str : d; }
 };
 
@@ -122,9 +127,14 @@ private:
         ++s_;
         return o;
     }
+    int depth_ = 0;
+    static constexpr int kMaxDepth = 512;      // nesting limit: value() recurses, "[[[[..." must not exhaust the stack
+    struct DepthGuard { int& d; explicit DepthGuard(int& x) : d(x) { ++d; } ~DepthGuard() { --d; } };
     Value value() {
         ws();
         if (s_ >= e_) fail("unexpected end");
+        DepthGuard guard(depth_);
+        if (depth_ > kMaxDepth) fail("nesting too deep");
         Value v;
         char c = *s_;
         if (c == '{') {
@@ -165,11 +175,12 @@ private:
         else if (lit("false")) { v.kind = Value::Bool; v.b = false; }
         else if (lit("null")) { v.kind = Value::Null; }
         else {
-            char* end = nullptr;
-            std::string tmp(s_, (size_t)std::min<ptrdiff_t>(e_ - s_, 64));
-            v.num = std::strtod(tmp.c_str(), &end);
-            if (end == tmp.c_str()) fail("unexpected character");
-            s_ += end - tmp.c_str();
+            // std::from_chars: correctly rounded like glibc's strtod, but independent of the embedding process's
+            // LC_NUMERIC (under a comma-decimal locale strtod reads "1.5" as 1)
+            const auto r = std::from_chars(s_, e_, v.num);
+            if (r.ec == std::errc::result_out_of_range) v.num = (*s_ == '-') ? -HUGE_VAL : HUGE_VAL;   // strtod's answer
+            else if (r.ec != std::errc() || r.ptr == s_) fail("unexpected character");
+            s_ = r.ptr;
             v.kind = Value::Number;
         }
         return v;

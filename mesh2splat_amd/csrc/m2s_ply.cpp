@@ -5,6 +5,9 @@
 // a pool of threads and written with a few big fwrite calls.
 #include "m2s_ply.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -119,6 +122,36 @@ m2s_status Writer::open(const char* path, uint64_t n_total, uint32_t format, flo
     return ok_ ? M2S_OK : M2S_ERR_IO;
 }
 
+m2s_status Writer::open_slice(const char* path, uint64_t n_total, uint32_t format, float scale_multiplier, uint64_t first_row, uint64_t n_rows) {
+    if (!path || first_row > n_total || n_rows > n_total - first_row) return M2S_ERR_INVALID;
+    if (format > 2) format = 0;
+    const Format fmt = describe(format);
+    std::string header = "ply\nformat binary_little_endian 1.0\nelement vertex " + std::to_string(n_total) + "\n";
+    for (const auto& p : fmt.props) header += p + "\n";
+    header += "end_header\n";
+    const int fd = ::open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) return M2S_ERR_IO;
+    format_ = format; sm_ = scale_multiplier; row_bytes_ = fmt.row_bytes; expected_ = n_rows; written_ = 0; ok_ = true; cur_ = 0;
+    if (first_row == 0) {   // the header's writer also fixes the length (drops what a longer, older file held beyond it)
+        const unsigned long long len = header.size() + n_total * (unsigned long long)fmt.row_bytes;
+        ok_ = ::ftruncate(fd, (off_t)len) == 0;
+    }
+    f_ = ::fdopen(fd, "wb");
+    if (!f_) { ::close(fd); return M2S_ERR_IO; }
+    if (first_row == 0) ok_ = ok_ && std::fwrite(header.data(), 1, header.size(), f_) == header.size();
+    else ok_ = ::fseeko(f_, (off_t)(header.size() + first_row * (unsigned long long)fmt.row_bytes), SEEK_SET) == 0;
+    return ok_ ? M2S_OK : M2S_ERR_IO;
+}
+
+m2s_status Writer::append_encoded(const uint8_t* rows, size_t n_rows) {
+    if (!f_) return M2S_ERR_STATE;
+    if (n_rows && !rows) return M2S_ERR_INVALID;
+    if (pending_.valid()) ok_ = pending_.get() && ok_;
+    ok_ = ok_ && std::fwrite(rows, row_bytes_, n_rows, f_) == n_rows;
+    written_ += n_rows;
+    return ok_ ? M2S_OK : M2S_ERR_IO;
+}
+
 m2s_status Writer::append(const m2s_gaussian* records, size_t rows) {
     if (!f_) return M2S_ERR_STATE;
     if (rows && !records) return M2S_ERR_INVALID;
@@ -156,6 +189,16 @@ m2s_status Writer::close() {
 }
 
 }  // namespace m2s_ply
+
+extern "C" m2s_status m2s_write_ply_slice(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format, float scale_multiplier,
+                                          uint64_t first_row, uint64_t total_rows) {
+    if (!path || (n && !records)) return M2S_ERR_INVALID;
+    m2s_ply::Writer w;
+    m2s_status s = w.open_slice(path, total_rows, format, scale_multiplier, first_row, n);
+    if (s == M2S_OK) s = w.append(records, (size_t)n);
+    const m2s_status c = w.close();
+    return s != M2S_OK ? s : c;
+}
 
 extern "C" m2s_status m2s_write_ply(const char* path, const m2s_gaussian* records, uint64_t n, uint32_t format,
                                     float scale_multiplier) {

@@ -16,6 +16,14 @@ class Writer {
 public:
     ~Writer() { (void)close(); }
     m2s_status open(const char* path, uint64_t n_total, uint32_t format, float scale_multiplier);
+    // One writer of SEVERAL that fill the same file (one per GPU rank): this one writes rows [first_row, first_row + n_rows)
+    // of a file whose header announces n_total rows.  The file is created if needed and never truncated below its final
+    // size; the writer of row 0 also writes the header and sets the file's length.
+    m2s_status open_slice(const char* path, uint64_t n_total, uint32_t format, float scale_multiplier, uint64_t first_row, uint64_t n_rows);
+    // rows that are already encoded (the device-side encoder of m2s_export_ply): `bytes` must be a whole number of rows;
+    // returns once `rows` has been read completely
+    m2s_status append_encoded(const uint8_t* rows, size_t n_rows);
+    size_t row_bytes() const { return row_bytes_; }
     m2s_status append(const m2s_gaussian* records, size_t rows);   // returns once `records` has been read completely
     m2s_status close();                                            // flushes; M2S_ERR_IO if anything failed or rows are missing
 

@@ -76,6 +76,7 @@ bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err) {
         pos += 12 + (size_t)clen;
     }
     if (!have_ihdr || w == 0 || h == 0 || w > 32768 || h > 32768) { err = "bad PNG header"; return false; }
+    if ((uint64_t)w * h > (1ull << 30)) { err = "PNG too large"; return false; }   // same pixel cap as the JPEG path
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -103,10 +104,29 @@ bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err) {
     else if (interlace == 1) {
         for (int p = 0; p < 7; ++p) raw_len += pass_bytes(pass_w(p), pass_h(p));
     } else { err = "unsupported PNG interlace method"; return false; }
+    // Streamed inflate: the image needs exactly raw_len bytes; what the zlib stream holds beyond them (trailing bytes some
+    // encoders leave, which stb_image ignores) is not an error, a stream that ends early is.
     std::vector<uint8_t> raw(raw_len);
-    uLongf got = (uLongf)raw_len;
-    int zr = uncompress(raw.data(), &got, idat.data(), (uLong)idat.size());
-    if (zr != Z_OK || got != raw_len) { err = "PNG inflate failed"; return false; }
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) { err = "PNG inflate failed"; return false; }
+        size_t in_pos = 0;
+        int zr = Z_OK;
+        while (zs.total_out < raw_len && zr == Z_OK) {
+            if (zs.avail_in == 0) {
+                const size_t take = std::min<size_t>(idat.size() - in_pos, (size_t)1 << 30);
+                if (!take) break;
+                zs.next_in = idat.data() + in_pos; zs.avail_in = (uInt)take; in_pos += take;
+            }
+            zs.next_out = raw.data() + zs.total_out;
+            zs.avail_out = (uInt)std::min<size_t>(raw_len - zs.total_out, (size_t)1 << 30);
+            zr = inflate(&zs, Z_NO_FLUSH);
+        }
+        const bool complete = zs.total_out == raw_len && (zr == Z_OK || zr == Z_STREAM_END);
+        inflateEnd(&zs);
+        if (!complete) { err = "PNG inflate failed"; return false; }
+    }
 
     img.width = w; img.height = h;
     img.rgba.assign((size_t)w * h * 4, 255);
