@@ -1,18 +1,25 @@
 #!/usr/bin/env python
 """bench.py — Gaussians/sec of the mesh -> 3DGS conversion pass on N MI355X GPUs.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one execution of the conversion pass (== ConversionPass::execute: count, scan,
-offsets, emit, counter read-back) on geometry and textures already resident in HBM.
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK /
+WORLD_SIZE in the environment) or typed as is — bench.py then starts the N ranks itself (one process per GPU).
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): I-3 = cube-sphere n=289
+A "step" is one execution of the conversion pass (== ConversionPass::execute) on geometry and textures already resident
+in HBM.  Headline workload (BASELINE.json configs[2], the one the metric is quoted on): I-3 = cube-sphere n=289
 (1 002 252 triangles), three procedural 2048^2 RGBA8 maps, density R = 1024.
-N > 1 is WEAK scaling: the scene holds N such meshes (co-located, so every mesh has the same
-cumulative bbox and the same fragment count), sharded by triangle range one mesh per rank; the
-only collective in the timed step is the all-gather of the per-rank counters that gives every
-rank its offset in the virtual concatenated splat buffer.  The full record all-gather over xGMI
-(north-star) is measured separately after the timed region and reported under "gather".
+
+N > 1, headline = WEAK scaling: the scene holds N such meshes (co-located, so every mesh has the same cumulative bbox and
+the same fragment count), sharded by triangle range one mesh per rank; the only collective in the timed step is the
+8-byte all-gather of the per-rank counters (RCCL through the C ABI, m2s_dist_*), which gives every rank its offset in the
+merged splat buffer.  Reported next to it, outside `value`:
+  gather           the all-pairs record exchange over xGMI that concatenates the per-rank blocks on every rank;
+  strong_scaling   ONE scene (C3, and the C4 stand-in) cut into N fragment-balanced triangle ranges: convert + counter
+                   exchange ("no_gather": what per-rank .ply slice writers need) and convert + record exchange ("gather").
+N == 1 adds: cold_path (first call on a fresh context, densities never seen before, three rotating scene copies that
+do not fit the Infinity Cache), extra_workloads (C2 stand-in, a 26-fragments-per-triangle mesh, the C4 stand-in),
+viewer_passes, cpu_baseline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -47,13 +54,13 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
-    ap.add_argument("--gather-direct", action="store_true", help="also time the exact-size all-pairs record exchange (dist.all_gather_records)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
     ap.add_argument("--no-viewer-extra", action="store_true", help="skip the prepass / depth-sort measurement after the timed region")
     ap.add_argument("--overlap-extra", action="store_true",
                     help="after the timed region, also measure two-lane overlapped submission (reported as 'overlapped'; off by "
                          "default so that a rocprofv3 trace of the default command holds only isolated launches)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the C2 / mid-size / C4 lines (and the C4 strong-scaling run at N > 1)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
@@ -207,29 +214,269 @@ def viewer_extra(conv, R, total):
     return out
 
 
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` typed by hand (no torchrun): start N ranks ourselves, one per GPU, and relay their output."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Rig:
+    """One rank's converter on one scene + the step loops (pipelined or blocking), shared by the headline and the extras."""
+
+    def __init__(self, torch, local_rank, scene, R, tri_range=None, cap=-1, out_rows=None, exchange=None):
+        from mesh2splat_amd.converter import Converter
+        self.torch, self.R, self.exchange = torch, R, exchange
+        self.conv = Converter(local_rank)
+        if tri_range is not None:
+            self.conv.set_triangle_range(*tri_range)
+        self.conv.upload_scene(scene)
+        self.conv.set_max_gaussians(cap)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.out = None
+        if out_rows is not None:        # caller-owned record buffer (multi-GPU: the block this rank contributes)
+            if out_rows == 0:
+                probe = torch.empty((1, 24), dtype=torch.float32, device="cuda")
+                out_rows = max(1, self.conv.convert_into(R, probe.data_ptr(), 1, self.stream))
+            self.out = torch.empty((out_rows, 24), dtype=torch.float32, device="cuda")
+        self.kms = {k: 0.0 for k in ("count", "scan", "offsets", "emit", "fused")}
+        self.n_prof = 0
+        self.in_flight_counts = 0
+        self.last_counts = None
+
+    def _publish(self, total):
+        if self.exchange is None:
+            return
+        self.exchange.publish_count(total)
+        self.in_flight_counts += 1
+        while self.in_flight_counts > 2:       # keep two exchanges in flight: the host never waits for the newest one
+            self.last_counts = self.exchange.collect_counts()
+            self.in_flight_counts -= 1
+
+    def drain_counts(self):
+        while self.in_flight_counts:
+            self.last_counts = self.exchange.collect_counts()
+            self.in_flight_counts -= 1
+
+    def submit(self):
+        if self.out is not None:
+            self.conv.submit(self.R, self.out.data_ptr(), self.out.shape[0], self.stream)
+        else:
+            self.conv.submit(self.R)
+
+    def step_sync(self):
+        if self.out is None:
+            total = self.conv.convert(self.R)
+        else:
+            total = self.conv.convert_into(self.R, self.out.data_ptr(), self.out.shape[0], self.stream)
+        self._publish(total)
+        return total
+
+    def run(self, k, timed=False, sync_steps=False, prof_every=4):
+        """k conversions (pipelined two deep unless sync_steps); returns the last counter; accumulates sampled kernel times"""
+        conv, total = self.conv, 0
+        if k <= 0:
+            return 0
+        if sync_steps:
+            for i in range(k):
+                conv.set_profiling(timed and i % prof_every == 0)
+                total = self.step_sync()
+                if timed and i % prof_every == 0:
+                    self._take_kms()
+            conv.set_profiling(False)
+            return total
+        conv.set_profiling(timed)
+        self.submit()
+        for i in range(k):
+            if i + 1 < k:
+                conv.set_profiling(timed and (i + 1) % prof_every == 0)
+                self.submit()
+            total = conv.wait()
+            self._publish(total)
+            if timed and i % prof_every == 0:
+                self._take_kms()
+        conv.set_profiling(False)
+        return total
+
+    def _take_kms(self):
+        self.n_prof += 1
+        for n_, v in self.conv.last_kernel_ms().items():
+            self.kms[n_] += v
+
+    def kernel_ms(self):
+        return {k: v / max(self.n_prof, 1) for k, v in self.kms.items()}
+
+    def reset_kms(self):
+        self.kms = {k: 0.0 for k in self.kms}
+        self.n_prof = 0
+
+    def close(self):
+        self.conv.close()
+
+
+def timed_loop(torch, dist, multi, rig, steps, warmup, sync_steps=False):
+    """warmup, barrier + sync, `steps` conversions, barrier + sync; returns (seconds (max over ranks), last counter)"""
+    def sync():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+    if warmup:
+        rig.run(warmup, sync_steps=sync_steps)
+        rig.drain_counts()
+    rig.reset_kms()
+    sync()
+    t0 = time.perf_counter()
+    total = rig.run(steps, timed=True, sync_steps=sync_steps)
+    rig.drain_counts()
+    sync()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, total
+
+
+def stored_of(rig):
+    return rig.conv.num_stored
+
+
+def whole_conversion_roofline(total_stored, tri, ms):
+    """96 B per STORED Gaussian + 144 B per triangle over the whole conversion's time."""
+    b = 96.0 * total_stored + 144.0 * tri
+    gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"algorithmic_bytes": b, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+
+
+def cold_path(torch, local_rank, scene, R, steady_sync_ms):
+    """What a conversion costs when nothing is warm (the reference converts on load and on every move of the density
+    slider, guiRendererConcreteMediator.cpp:51-57 — always a NEW (scene, R)):
+      first_call_ms  fresh context, scene uploaded, first m2s_convert (includes the exact count that decides the pipeline
+                     and the allocation of the record pool);
+      new_R_ms       blocking conversions at densities this context has never seen (R, R-8, R-16, ...): no cached decision,
+                     no cached band bases, cap changes every time;
+      cold_inputs    three independent copies of the scene (> 700 MB of inputs: more than the 256 MiB Infinity Cache) converted
+                     round-robin, kernel time by HIP events."""
+    import numpy as np
+    from mesh2splat_amd.converter import Converter
+    out = {}
+    conv = Converter(local_rank)
+    conv.upload_scene(scene)
+    out["upload_ms"] = conv.last_upload_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = conv.convert(R)
+    out["first_call_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    conv.convert(R)
+    out["second_call_ms"] = (time.perf_counter() - t0) * 1e3
+    new_r = []
+    for k in range(1, 9):
+        r = R - 8 * k
+        if r < 16:
+            break
+        t0 = time.perf_counter()
+        conv.convert(r)
+        new_r.append((time.perf_counter() - t0) * 1e3)
+    same = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        conv.convert(R)
+        same.append((time.perf_counter() - t0) * 1e3)
+    out["new_R_ms"] = {"median": float(np.median(new_r)), "max": float(np.max(new_r)), "densities": [R - 8 * k for k in range(1, len(new_r) + 1)]}
+    out["same_R_sync_ms"] = float(np.median(same[2:]))
+    out["new_R_over_steady"] = out["new_R_ms"]["median"] / out["same_R_sync_ms"]
+    # rotating copies: distinct host arrays -> distinct device copies of geometry and textures
+    import copy
+    rigs = [conv]
+    for _ in range(2):
+        c2 = Converter(local_rank)
+        c2.upload_scene(copy.deepcopy(scene))
+        rigs.append(c2)
+    T = conv.num_triangles
+    for c_ in rigs:
+        c_.convert(R)
+        c_.convert(R)
+        c_.set_profiling(True)
+    ms, wall = [], []
+    for i in range(30):
+        c_ = rigs[i % 3]
+        t0 = time.perf_counter()
+        c_.convert(R)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        k = c_.last_kernel_ms()
+        ms.append(sum(k.values()))
+    m = float(np.median(ms[3:]))
+    inputs_mb = 3 * (144.0 * T + sum(int(t.nbytes) for me in scene.meshes for t in me.textures.values()) * 1.34) / 1e6
+    out["cold_inputs"] = {"copies": 3, "input_MB_total": inputs_mb, "kernel_ms": m, "sync_ms": float(np.median(wall[3:])),
+                          **whole_conversion_roofline(min(total, conv.num_stored), T, m)}
+    for c_ in rigs:
+        c_.close()
+    return out
+
+
+def extra_workload(torch, dist, local_rank, name, steps=24, warmup=3):
+    """One more BASELINE config on this GPU: whole-conversion ms, Gaussians/s, roofline fraction by algorithmic bytes."""
+    from mesh2splat_amd import synth
+    n, tex, R = WORKLOADS[name]
+    scene = synth.sphere_grid(4, n=18, tex_size=tex) if n == "grid" else synth.colocated_spheres(1, n, tex)
+    rig = Rig(torch, local_rank, scene, R)
+    dt, total = timed_loop(torch, dist, False, rig, steps, warmup)
+    ms = dt / steps * 1e3
+    k = rig.kernel_ms()
+    kern = sum(k.values())
+    res = {"workload": name, "R": R, "triangles": scene.n_triangles, "meshes": scene.n_meshes, "gaussians": int(total),
+           "stored": int(stored_of(rig)), "ms_per_step": ms, "value": total / (ms * 1e-3), "pipeline": rig.conv.last_pipeline,
+           "kernel_ms": {a: b for a, b in k.items() if b > 0}, "kernels_total_ms": kern,
+           "roofline_whole_conversion": whole_conversion_roofline(stored_of(rig), scene.n_triangles, kern)}
+    rig.close()
+    return res
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         a.gpus = world
 
     import torch  # first, so that the HIP runtime torch ships is the one the process uses
     import torch.distributed as dist
     import numpy as np
     from mesh2splat_amd import synth
-    from mesh2splat_amd.converter import Converter
+    from mesh2splat_amd import dist as m2d
 
     torch.cuda.set_device(local_rank)
     multi = world > 1 or a.force_dist
+    exchange = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+
+        def bootstrap(ident):
+            # rank 0's RCCL id reaches the other ranks through the process group that torchrun set up; from here on the
+            # data path talks to RCCL through the C ABI (m2s_dist_*), not through torch.distributed
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if ident is not None:
+                t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
         # librccl announces itself through C stdio ("Librccl path : ..."); push that out now so that the JSON line
         # stays the LAST line of stdout
         import ctypes
@@ -239,167 +486,137 @@ def main():
     n, tex, R = WORKLOADS[a.workload]
     if n == "grid":
         if world > 1:
-            raise SystemExit("workload c4 is a single-GPU diagnostic")
+            raise SystemExit("workload c4 as the headline is single-GPU (it is part of the strong-scaling section at N > 1)")
         scene = synth.sphere_grid(4, n=18, tex_size=tex)
         tri_per_mesh = scene.n_triangles
     else:
         scene = synth.colocated_spheres(world, n, tex)
         tri_per_mesh = scene.meshes[0].n_triangles
 
-    conv = Converter(local_rank)
-    conv.set_triangle_range(rank * tri_per_mesh, tri_per_mesh)
-    conv.upload_scene(scene)
-    # N == 1: the reference's own cap formula.  N > 1: the merged scene exceeds the reference's
-    # 7 M envelope, so the cap is lifted and each rank writes into its own buffer.
-    conv.set_max_gaussians(0 if multi else -1)
-    T_local = conv.num_triangles
-
-    stream = torch.cuda.current_stream().cuda_stream
-    out = None
-    RING = 4              # counters of up to RING steps in flight: each all-gather owns its send and receive slot
-    counts_ring = torch.zeros((RING, world), dtype=torch.int64, device="cuda")
-    mine_ring = torch.zeros((RING, 1), dtype=torch.int64, device="cuda")
-    counts = counts_ring[0]
-    n_published = [0]
-
-    # Steps are pipelined two deep (m2s_convert_submit / m2s_convert_wait): while the GPU runs conversion k the host
-    # has already enqueued k+1 and reads k's counter afterwards.  Every conversion runs to completion inside the
-    # timed region and every counter is read back; what disappears is the launch + completion round trip between
-    # consecutive kernels.  --sync-steps restores one blocking call per step.
-    side = torch.cuda.Stream() if multi else None
-    pending = []          # outstanding counter all-gathers (multi-GPU)
-
-    def publish(total):
-        """offsets of every rank in the merged buffer: an 8-byte all-gather per step, off the conversion stream"""
-        nonlocal counts
-        k = n_published[0] % RING
-        n_published[0] += 1
-        counts = counts_ring[k]
-        with torch.cuda.stream(side):
-            mine_ring[k].fill_(total)
-            pending.append(dist.all_gather_into_tensor(counts_ring[k], mine_ring[k], async_op=True))
-            while len(pending) > 2:
-                pending.pop(0).wait()    # (orders the side stream behind an all-gather issued two steps ago; the host does not block)
-
-    def submit():
-        if multi:
-            conv.submit(R, out.data_ptr(), out.shape[0], stream)
-        else:
-            conv.submit(R)
-
-    def step_sync():
-        if not multi:
-            return conv.convert(R)
-        total = conv.convert_into(R, out.data_ptr(), out.shape[0], stream)
-        publish(total)
-        return total
-
-    PROF_EVERY = 8        # HIP events bracket every 8th launch: an event pair costs ~10 us of stream time per launch
-    n_prof = [0]
-
-    def run_steps(k, timed=False):
-        """k conversions, pipelined two deep; returns the last counter; accumulates the sampled kernel times"""
-        total = 0
-        if a.sync_steps:
-            for i in range(k):
-                conv.set_profiling(timed and i % PROF_EVERY == 0)
-                total = step_sync()
-                if timed and i % PROF_EVERY == 0:
-                    n_prof[0] += 1
-                    for n_, v in conv.last_kernel_ms().items():
-                        kms[n_] += v
-            return total
-        conv.set_profiling(timed)
-        submit()
-        for i in range(k):
-            if i + 1 < k:
-                conv.set_profiling(timed and (i + 1) % PROF_EVERY == 0)
-                submit()
-            total = conv.wait()
-            if multi:
-                publish(total)
-            if timed and i % PROF_EVERY == 0:
-                n_prof[0] += 1
-                for n_, v in conv.last_kernel_ms().items():
-                    kms[n_] += v
-        return total
-
+    # ---- headline: WEAK scaling, one I-3 mesh per rank -------------------------------------------------------------
+    # N == 1: the reference's own cap formula.  N > 1: the merged scene exceeds the reference's 7 M envelope,
+    # so the cap is lifted and each rank writes into its own buffer; the counters are exchanged every step (RCCL, C ABI).
+    rig = Rig(torch, local_rank, scene, R, tri_range=(rank * tri_per_mesh, tri_per_mesh), cap=0 if multi else -1,
+              out_rows=0 if multi else None, exchange=exchange)
+    T_local = rig.conv.num_triangles
+    dt, total = timed_loop(torch, dist, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
+    ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
     if multi:
-        # size the per-rank record buffer once (like the SSBO (re)allocation, outside the timed region)
-        probe = torch.empty((1, 24), dtype=torch.float32, device="cuda")
-        need = conv.convert_into(R, probe.data_ptr(), 1, stream)
-        out = torch.empty((need, 24), dtype=torch.float32, device="cuda")
+        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
+    n_all = int(ntot.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = n_all / (dt / a.steps)
+    kms = rig.kernel_ms()
+    n_prof = rig.n_prof
+    last_pipeline = rig.conv.last_pipeline
+    stored_local = stored_of(rig)
 
-    def sync():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    kms = {k: 0.0 for k in ("count", "scan", "offsets", "emit", "fused")}
-    if a.warmup:
-        run_steps(a.warmup)
-    kms = {k: 0.0 for k in kms}
-    sync()
-    t0 = time.perf_counter()
-    total = run_steps(a.steps, timed=True)   # HIP events on the launch stream around every PROF_EVERY-th launch
-    if pending:
-        with torch.cuda.stream(side):
-            for w in pending:
-                w.wait()
-        pending.clear()
-    sync()
-    dt = time.perf_counter() - t0
-    conv.set_profiling(False)
     # for the record: the same loop with one blocking call per step (outside the timed region)
-    sync()
-    s0 = time.perf_counter()
     per_step = []
     for _ in range(min(a.steps, 20)):
         p0 = time.perf_counter()
-        step_sync()
+        rig.step_sync()
         per_step.append((time.perf_counter() - p0) * 1e3)
-    if pending:
-        with torch.cuda.stream(side):
-            for w in pending:
-                w.wait()
-        pending.clear()
-    sync()
-    sync_ms = (time.perf_counter() - s0) / min(a.steps, 20) * 1e3
-    # also for the record: two lanes (two streams, chains and record buffers), three conversions in flight, so that
-    # consecutive conversions overlap.  Not the headline: overlapped launches have no meaningful individual duration,
-    # and the roofline above is about the kernel.
+    rig.drain_counts()
+    torch.cuda.synchronize()
+    sync_ms = float(np.mean(per_step))
+    per_step.sort()
+    sync_stats = {"median": per_step[len(per_step) // 2], "p10": per_step[len(per_step) // 10], "p90": per_step[(len(per_step) * 9) // 10]}
+    # a dedicated kernel-time sample: 64 blocking launches, HIP events on every one (not part of `value`)
+    rig.reset_kms()
+    rig.run(64, timed=True, sync_steps=True, prof_every=1)
+    rig.drain_counts()
+    dedicated = rig.kernel_ms()
+
     overlapped = None
-    if a.overlap_extra and not multi and conv.last_pipeline in ("team", "wave"):
+    if a.overlap_extra and not multi and last_pipeline in ("team", "wave"):
+        conv = rig.conv
         conv.set_async_lanes(2)
         n_ov = max(min(a.steps, 60), 6)
         for _ in range(4):
             conv.submit(R)
         for _ in range(4):
             conv.wait()
-        sync()
+        torch.cuda.synchronize()
         o0 = time.perf_counter()
         conv.submit(R); conv.submit(R)
         for i in range(n_ov):
             if i + 2 < n_ov:
                 conv.submit(R)
             ov_total = conv.wait()
-        sync()
+        torch.cuda.synchronize()
         ov_ms = (time.perf_counter() - o0) / n_ov * 1e3
         conv.set_async_lanes(1)
         overlapped = {"ms_per_step": ov_ms, "value": ov_total / (ov_ms * 1e-3), "unit": "Gaussians/s",
                       "what": "m2s_set_async_lanes(2), three conversions in flight: consecutive conversions overlap on two streams"}
-    # the two viewer passes that consume the records in the reference's frame (SURVEY 8 f-4 / f-2): for the record, after the
-    # timed region; never part of `value`
     viewer = None
     if not a.no_viewer_extra and not multi:
         try:
-            viewer = viewer_extra(conv, R, total)
+            viewer = viewer_extra(rig.conv, R, total)
         except Exception as e:  # noqa: BLE001 - an extra must not take the headline down
             viewer = {"error": str(e)}
-    per_step.sort()
-    sync_stats = {"median": per_step[len(per_step) // 2], "p10": per_step[len(per_step) // 10], "p90": per_step[(len(per_step) * 9) // 10]}
-    # a second denominator for the roofline: what a plain device-to-device copy reaches on this box (read + write bytes)
+
+    # ---- multi-GPU extras: the record exchange of the weak-scaling run, then STRONG scaling of ONE scene --------------
+    gather = None
+    strong = None
+    if multi:
+        counts, offs = exchange.all_gather_counts(total)
+        reps = 5
+        if not a.no_gather:
+            merged = torch.empty((max(offs[-1], 1), 24), dtype=torch.float32, device="cuda")
+            for _ in range(2):
+                exchange.gather_records(rig.out.data_ptr(), counts, merged.data_ptr(), -1, rig.stream)
+            torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            for _ in range(reps):
+                rig.step_sync()
+                exchange.gather_records(rig.out.data_ptr(), counts, merged.data_ptr(), -1, rig.stream)
+            rig.drain_counts()
+            torch.cuda.synchronize(); dist.barrier()
+            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+            dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+            gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
+                      "bytes_received_per_rank": 96 * (offs[-1] - counts[rank]),
+                      "what": "convert + exact-size all-pairs exchange of every rank's block to every rank (m2s_dist_gather_records: one "
+                              "RCCL group of ncclSend/ncclRecv at the final offsets of the merged buffer)"}
+            del merged
+        rig.close()
+        strong = {}
+        for sname in (["c3"] + (["c4"] if not a.no_extra_workloads else [])):
+            sn, stex, sR = WORKLOADS[sname]
+            one = synth.sphere_grid(4, n=18, tex_size=stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
+            plan = m2d.shard_ranges_native(one, sR, world)
+            srig = Rig(torch, local_rank, one, sR, tri_range=plan[rank], cap=0, out_rows=0, exchange=exchange)
+            sdt, stotal = timed_loop(torch, dist, True, srig, a.steps, a.warmup)
+            scounts, soffs = exchange.all_gather_counts(stotal)
+            entry = {"scene": sname, "R": sR, "triangles": one.n_triangles, "gaussians": soffs[-1], "per_rank_gaussians": scounts,
+                     "per_rank_triangles": [c_ for _, c_ in plan],
+                     "no_gather": {"ms_per_step": sdt / a.steps * 1e3, "value": soffs[-1] / (sdt / a.steps),
+                                   "what": "shards by estimated fragments (m2s_dist_shard_ranges), convert + counter exchange; every rank "
+                                           "keeps its block and knows its offset (what per-rank .ply slice writers need)"}}
+            if not a.no_gather:
+                merged = torch.empty((max(soffs[-1], 1), 24), dtype=torch.float32, device="cuda")
+                exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
+                torch.cuda.synchronize(); dist.barrier()
+                g0 = time.perf_counter()
+                for _ in range(reps):
+                    srig.step_sync()
+                    exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
+                srig.drain_counts()
+                torch.cuda.synchronize(); dist.barrier()
+                gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+                dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+                entry["gather"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": soffs[-1] / float(gdt.item()),
+                                   "what": "convert + all-pairs record exchange into the merged buffer on every rank"}
+                # the merged buffer must be the single-GPU output: checksum of checksums across ranks
+                chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device="cuda")
+                allchk = [torch.zeros_like(chk) for _ in range(world)]
+                dist.all_gather(allchk, chk)
+                entry["gather"]["merged_identical_on_all_ranks"] = bool(all(int(x.item()) == int(chk.item()) for x in allchk))
+                del merged
+            strong[sname] = entry
+            srig.close()
+
     copy_gbs = None
     if rank == 0:
         nbytes = 1 << 30
@@ -415,60 +632,13 @@ def main():
         copy_gbs = 2.0 * nbytes * 10 / (time.perf_counter() - c0) / 1e9
         del src, dstb
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
-    if multi:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    n_all = int(ntot.item())
-    ms_per_step = dt / a.steps * 1e3
-    value = n_all / (dt / a.steps)
-
-    # optional: the north-star record all-gather (xGMI-bound), measured outside the timed region
-    gather = None
-    if multi and not a.no_gather:
-        nmax = int(counts.max().item())
-        send = torch.zeros((nmax, 24), dtype=torch.float32, device="cuda")
-        send[: out.shape[0]] = out
-        recv = torch.empty((world * nmax, 24), dtype=torch.float32, device="cuda")
-        for _ in range(2):
-            dist.all_gather_into_tensor(recv, send)
-        sync()
-        g0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            step_sync()
-            send[: out.shape[0]] = out
-            dist.all_gather_into_tensor(recv, send)
-        sync()
-        gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
-        dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-        gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
-                  "what": "convert + padded RCCL all-gather of all records to every rank"}
-        if a.gather_direct:      # the exact-size all-pairs schedule of dist.all_gather_records (grouped isend / irecv)
-            from mesh2splat_amd import dist as m2d
-            cl = [int(x) for x in counts.tolist()]
-            for _ in range(2):
-                m2d.all_gather_records(out[: cl[rank]], cl)
-            sync()
-            g0 = time.perf_counter()
-            for _ in range(reps):
-                step_sync()
-                m2d.all_gather_records(out[: cl[rank]], cl)
-            sync()
-            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
-            dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-            gather["direct"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()),
-                                "what": "convert + exact-size all-pairs exchange (isend/irecv group) into the merged buffer"}
-
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        kname = {"team": "k_fused2", "wave": "k_fused"}.get(conv.last_pipeline, "k_emit")
-        emit_ms = kms[dom] / max(n_prof[0], 1)
-        # algorithmic bytes of one emit launch: 96 B per Gaussian written + 144 B per triangle read
+        kname = {"team": "k_fused2", "wave": "k_fused"}.get(last_pipeline, "k_emit2")
+        emit_ms = kms[dom]
+        # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
-        b_alg = 96.0 * total + 144.0 * T_local
+        b_alg = 96.0 * stored_local + 144.0 * T_local
         achieved = b_alg / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
         res = {
             "metric": "Gaussians/sec emitted (mesh->3DGS conversion pass, density 1024^2)" if R == 1024 else
@@ -481,35 +651,58 @@ def main():
                                    (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
                                     f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
+                       "rccl_ranks": (dist.get_world_size() if multi else 1),
+                       "exchange": ("per step: 8-byte counter all-gather through the C ABI (m2s_dist_publish_count / collect_counts: "
+                                    "ncclAllGather on its own stream)") if multi else "none (single GPU)",
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
                        "submission": "one blocking call per step" if a.sync_steps else
                                      "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
             "sync_ms_per_step": sync_ms, "sync_ms_stats": sync_stats, "overlapped": overlapped, "viewer_passes": viewer,
-            "kernel_ms": {k: v / max(n_prof[0], 1) for k, v in kms.items()},
-            "kernel_timing": f"HIP events on the launch stream around every {PROF_EVERY}th launch of the timed region ({n_prof[0]} launches)",
+            "kernel_ms": kms,
+            "kernel_timing": f"HIP events on the launch stream around every 4th launch of the timed region ({n_prof} launches)",
+            "kernel_ms_dedicated": {"what": "64 blocking launches after the timed region, HIP events on every one", **dedicated},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "kernel": kname,
                          "algorithmic_bytes": b_alg, "measured_copy_peak": copy_gbs,
                          "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                         "write_only_frac": (96.0 * total / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
+                         "frac_dedicated_sample": (b_alg / (dedicated[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dedicated[dom] > 0 else None,
+                         "write_only_frac": (96.0 * stored_local / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
         }
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tr):
             try:
                 with open(tr) as f:
                     t = json.load(f)
-                if t.get("workload") == a.workload:
+                if t.get("workload") == a.workload and t.get(kname + "_hbm_bytes_per_launch"):
                     res["roofline"]["traffic"] = t.get(kname + "_hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from the committed "
+                                                         "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
             except Exception:
                 pass
         if gather:
             res["gather"] = gather
-        if not a.no_cpu_baseline and world == 1:
+        if strong:
+            res["strong_scaling"] = strong
+        if not multi:
             one = scene if n == "grid" else synth.colocated_spheres(1, n, tex)
-            res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds, gpu_total=total)
+            if not a.no_cold:
+                try:
+                    res["cold_path"] = cold_path(torch, local_rank, one, R, sync_ms)
+                except Exception as e:  # noqa: BLE001
+                    res["cold_path"] = {"error": str(e)}
+            if not a.no_extra_workloads and a.workload == "c3":
+                res["extra_workloads"] = {}
+                for w in ("c2", "mid", "c4"):
+                    try:
+                        res["extra_workloads"][w] = extra_workload(torch, dist, local_rank, w)
+                    except Exception as e:  # noqa: BLE001
+                        res["extra_workloads"][w] = {"error": str(e)}
+            if not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds, gpu_total=total)
         print(json.dumps(res), flush=True)
 
     if multi:
+        exchange.close()
         dist.destroy_process_group()
 
 

@@ -205,6 +205,8 @@ void m2s_dist_clamp_to_cap(const uint64_t* counts, int world, uint64_t cap, uint
  * d_merged on every rank (root < 0) or on `root` only (d_merged may be NULL elsewhere).  Device pointers; enqueued on
  * hip_stream (the stream the conversion ran on); returns without waiting for it. */
 m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64_t* counts, void* d_merged, int root, void* hip_stream);
+/* Blocks until everything enqueued on hip_stream (the record exchange) has completed. */
+m2s_status m2s_dist_wait(m2s_dist* d, void* hip_stream);
 
 /* ---- depth sort == RadixSortPass::execute (RadixSortPass.cpp:8-90) ------------------------------------ */
 /* Sorts the records stored by the last m2s_convert by key = floatBitsToUint(view-space z), ascending on the
@@ -223,6 +225,13 @@ float m2s_last_sort_ms(const m2s_ctx* ctx);
  * m2s_num_stored / m2s_device_records / m2s_download / m2s_prepass / m2s_sort_by_depth then refer to them.  The next
  * conversion replaces them.  (The viewer treats such records as format 1: set m2s_prepass_params.format accordingly.) */
 m2s_status m2s_upload_records(m2s_ctx* ctx, const m2s_gaussian* records, uint64_t n);
+
+/* Records that already live in device memory (e.g. the merged buffer of m2s_dist_gather_records) become the context's current
+ * records without a copy: m2s_num_stored / m2s_download / m2s_export_ply (scale multiplier = std / R) / m2s_prepass /
+ * m2s_sort_by_depth then refer to them.  The memory stays the caller's and must outlive those calls. */
+m2s_status m2s_set_records(m2s_ctx* ctx, const void* d_records, uint64_t n, uint32_t R);
+/* Room for n records in the context-owned pool (grow-only, like the conversion's own allocation); *out_ptr = device address. */
+m2s_status m2s_reserve_records(m2s_ctx* ctx, uint64_t n, void** out_ptr);
 
 /* ---- viewer prepass == GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) ---------------------------- */
 /* What the reference's compute shader gaussianSplattingPrepassCS.glsl:58-204 (+ common.glsl) does to every Gaussian

@@ -24,6 +24,33 @@ from . import _lib
 from .scene import RECORD_FLOATS, TEXTURE_SLOTS, Scene
 
 
+def marshal_scene(scene: Scene):
+    """Scene -> (m2s_mesh[] for the C ABI, objects that must stay alive while it is used)."""
+    n = scene.n_meshes
+    arr = (_lib.MeshC * max(1, n))()
+    keep = []
+    for i, m in enumerate(scene.meshes):
+        v = np.ascontiguousarray(m.vertices, np.float32)
+        keep.append(v)
+        arr[i].vertices = v.ctypes.data
+        arr[i].n_vertices = v.shape[0]
+        arr[i].stride_floats = v.shape[1]
+        for k in range(3):
+            arr[i].bbox_min[k] = float(m.bbox_min[k])
+            arr[i].bbox_max[k] = float(m.bbox_max[k])
+        for k in range(4):
+            arr[i].base_color[k] = float(m.base_color[k])
+        for k, key in enumerate(TEXTURE_SLOTS):
+            t = m.textures.get(key)
+            if t is None:
+                continue
+            keep.append(t)
+            arr[i].tex[k].rgba8 = t.ctypes.data
+            arr[i].tex[k].width = t.shape[1]
+            arr[i].tex[k].height = t.shape[0]
+    return arr, keep
+
+
 class Converter:
     """Thin owner of one m2s_ctx (one per host thread / per GPU rank)."""
 
@@ -64,29 +91,8 @@ class Converter:
         self._check(self._L.m2s_set_triangle_range(self._h, int(first), (1 << 64) - 1 if count is None else int(count)))
 
     def upload_scene(self, scene: Scene):
-        n = scene.n_meshes
-        arr = (_lib.MeshC * max(1, n))()
-        keep = []
-        for i, m in enumerate(scene.meshes):
-            v = np.ascontiguousarray(m.vertices, np.float32)
-            keep.append(v)
-            arr[i].vertices = v.ctypes.data
-            arr[i].n_vertices = v.shape[0]
-            arr[i].stride_floats = v.shape[1]
-            for k in range(3):
-                arr[i].bbox_min[k] = float(m.bbox_min[k])
-                arr[i].bbox_max[k] = float(m.bbox_max[k])
-            for k in range(4):
-                arr[i].base_color[k] = float(m.base_color[k])
-            for k, key in enumerate(TEXTURE_SLOTS):
-                t = m.textures.get(key)
-                if t is None:
-                    continue
-                keep.append(t)
-                arr[i].tex[k].rgba8 = t.ctypes.data
-                arr[i].tex[k].width = t.shape[1]
-                arr[i].tex[k].height = t.shape[0]
-        self._check(self._L.m2s_upload_scene(self._h, arr, n))
+        arr, keep = marshal_scene(scene)
+        self._check(self._L.m2s_upload_scene(self._h, arr, scene.n_meshes))
         del keep
 
     def last_upload_ms(self) -> dict:
@@ -148,6 +154,11 @@ class Converter:
 
     def export_ply(self, path: str, fmt: int = 0, gaussian_std: float = 0.65):
         self._check(self._L.m2s_export_ply(self._h, os.fsencode(path), int(fmt), float(gaussian_std)))
+
+    def export_ply_slice(self, path: str, fmt: int, gaussian_std: float, first_row: int, n_rows: int, total_rows: int):
+        """This rank's rows of a .ply that several ranks write together (m2s_export_ply_slice)."""
+        self._check(self._L.m2s_export_ply_slice(self._h, os.fsencode(path), int(fmt), float(gaussian_std), int(first_row),
+                                                 int(n_rows), int(total_rows)))
 
     def sort_by_depth(self, world_to_view) -> np.ndarray:
         """RadixSortPass: sort the last conversion's records by floatBitsToUint(view-space z); returns them.
@@ -249,6 +260,15 @@ def write_ply(path: str, records: np.ndarray, fmt: int, scale_multiplier: float)
     if r.ndim != 2 or r.shape[1] != RECORD_FLOATS:
         raise ValueError("records must be (n, 24) float32")
     st = _lib.load().m2s_write_ply(os.fsencode(path), r.ctypes.data, r.shape[0], int(fmt), float(scale_multiplier))
+    if st != _lib.M2S_OK:
+        raise _lib.M2SError(st, f"could not write {path}")
+
+
+def write_ply_slice(path: str, records: np.ndarray, fmt: int, scale_multiplier: float, first_row: int, total_rows: int):
+    """One of several writers of one .ply (m2s_write_ply_slice): rows [first_row, first_row + len(records))."""
+    r = np.ascontiguousarray(records, np.float32).reshape(-1, RECORD_FLOATS)
+    st = _lib.load().m2s_write_ply_slice(os.fsencode(path), r.ctypes.data, r.shape[0], int(fmt), float(scale_multiplier),
+                                         int(first_row), int(total_rows))
     if st != _lib.M2S_OK:
         raise _lib.M2SError(st, f"could not write {path}")
 

@@ -1224,6 +1224,31 @@ m2s_status m2s_upload_records(m2s_ctx* c, const m2s_gaussian* records, uint64_t 
     return M2S_OK;
 }
 
+// Records that live in DEVICE memory already (e.g. the merged buffer of a multi-GPU exchange) become the context's current
+// records without a copy; R = the resolutionTarget they were converted at (m2s_export_ply's scale multiplier).
+m2s_status m2s_set_records(m2s_ctx* c, const void* d_records, uint64_t n, uint32_t R) {
+    if (!c || (!d_records && n)) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    c->last_records = d_records;
+    c->last_total = c->last_stored = n;
+    c->last_R = R;
+    c->records_stale = false;
+    c->sorted_n = 0; c->pp_visible = 0; c->sq_n = 0;
+    return M2S_OK;
+}
+
+// Room for n records in the context-owned pool (grow-only); *out_ptr = its device address.  For consumers that fill the
+// pool themselves (the root of m2s_dist_gather_records) and then call m2s_set_records.
+m2s_status m2s_reserve_records(m2s_ctx* c, uint64_t n, void** out_ptr) {
+    if (!c || !out_ptr) return M2S_ERR_INVALID;
+    if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const m2s_status s = ensure_records(c, std::max<uint64_t>(n, 1));
+    if (s != M2S_OK) return s;
+    *out_ptr = c->d_records;
+    return M2S_OK;
+}
+
 // GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) + the counter read-back that follows it (RadixSortPass.cpp:18-22).
 m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {
     if (!c || !p) return M2S_ERR_INVALID;

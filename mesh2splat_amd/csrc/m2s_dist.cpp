@@ -306,4 +306,12 @@ m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64
     return M2S_OK;
 }
 
+// Blocks until everything enqueued on hip_stream (e.g. the record exchange) has completed.
+m2s_status m2s_dist_wait(m2s_dist* d, void* hip_stream) {
+    if (!d) return M2S_ERR_INVALID;
+    DCHK(d, hipSetDevice(d->device));
+    DCHK(d, hipStreamSynchronize((hipStream_t)hip_stream));
+    return M2S_OK;
+}
+
 }  // extern "C"

@@ -143,6 +143,9 @@ bool get_accessor(const Glb& g, long long idx, Accessor& a, std::string& err) {
     // element range without forming off + (count-1)*stride + elem, which can wrap.
     const long long count = acc["count"].int_or(0), stride = bv["byteStride"].int_or(0);
     const long long bvo = bv["byteOffset"].int_or(0), aco = acc["byteOffset"].int_or(0);
+    if (acc["count"].bad_int() || bv["byteStride"].bad_int() || bv["byteOffset"].bad_int() || acc["byteOffset"].bad_int()) {
+        err = "accessor field out of range"; return false;
+    }
     if (count < 0 || stride < 0 || bvo < 0 || aco < 0) { err = "negative accessor field"; return false; }
     if ((unsigned long long)bvo > g.bin_len || (unsigned long long)aco > g.bin_len - (size_t)bvo) { err = "accessor exceeds the binary chunk"; return false; }
     const size_t off = (size_t)bvo + (size_t)aco;
@@ -159,6 +162,7 @@ bool get_accessor(const Glb& g, long long idx, Accessor& a, std::string& err) {
 // byteOffset/byteLength of a bufferView, validated against the binary chunk (both come from untrusted JSON)
 static bool view_range(const m2s_json::Value& bv, size_t bin_len, size_t& off, size_t& len) {
     const long long o = bv["byteOffset"].int_or(0), l = bv["byteLength"].int_or(0);
+    if (bv["byteOffset"].bad_int() || bv["byteLength"].bad_int()) return false;
     if (o < 0 || l < 0 || (unsigned long long)o > bin_len || (unsigned long long)l > bin_len - (size_t)o) return false;
     off = (size_t)o; len = (size_t)l;
     return true;

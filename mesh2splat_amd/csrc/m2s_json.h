@@ -44,6 +44,8 @@ struct Value {
     }
     size_t size() const { return kind == Arr ? arr->size() : kind == Obj ? obj->size() : 0; }
     double number_or(double d) const { return kind == Number ? num : d; }
+    // a number that no 64-bit integer can hold (or NaN): callers reject it where an index / size is expected
+    bool bad_int() const { return kind == Number && !(num > -9.0e18 && num < 9.0e18); }
     // NaN / out-of-range numbers (llround would be undefined) read as "absent"
     long long int_or(long long d) const {
         if (kind != Number || !(num > -9.0e18 && num < 9.0e18)) return d;

@@ -56,6 +56,82 @@ def shard_ranges(weights: np.ndarray, world: int, per_triangle_cost: float = 0.2
     return [(int(a), int(b - a)) for a, b in zip(cuts[:-1], cuts[1:])]
 
 
+def shard_ranges_native(scene: Scene, R: int, world: int) -> List[Tuple[int, int]]:
+    """The same plan from the C ABI (m2s_dist_shard_ranges): what the C++ command line and any non-Python host use."""
+    import ctypes as C
+    from . import _lib
+    from .converter import marshal_scene
+    L = _lib.load()
+    arr, keep = marshal_scene(scene)
+    first = (C.c_uint64 * world)()
+    count = (C.c_uint64 * world)()
+    st = L.m2s_dist_shard_ranges(arr, scene.n_meshes, int(R), int(world), first, count)
+    del keep
+    if st != _lib.M2S_OK:
+        raise _lib.M2SError(st, L.m2s_dist_last_error(None).decode())
+    return [(int(first[r]), int(count[r])) for r in range(world)]
+
+
+class RcclExchange:
+    """The multi-GPU exchange through the C ABI (m2s_dist_*: RCCL opened by libm2s_hip.so itself, no torch.distributed in
+    the data path).  `bootstrap` hands rank 0's 128-byte communicator id to the other ranks: a callable
+    bytes-or-None -> bytes (e.g. a torch.distributed / MPI broadcast, a file, a pipe)."""
+
+    def __init__(self, device: int, rank: int, world: int, bootstrap):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib, self._L = C, _lib, _lib.load()
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            st = self._L.m2s_dist_unique_id(buf)
+            if st != _lib.M2S_OK:
+                raise _lib.M2SError(st, self._L.m2s_dist_last_error(None).decode())
+            ident = bytes(buf)
+        ident = bootstrap(ident)
+        assert len(ident) == 128
+        h = C.c_void_p()
+        st = self._L.m2s_dist_create(int(device), C.c_char_p(ident), int(rank), int(world), C.byref(h))
+        if st != _lib.M2S_OK:
+            raise _lib.M2SError(st, self._L.m2s_dist_last_error(None).decode())
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def _check(self, st):
+        if st != self._lib.M2S_OK:
+            raise self._lib.M2SError(st, self._L.m2s_dist_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.m2s_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_counts(self, total: int):
+        counts = (self._C.c_uint64 * self.world)()
+        offs = (self._C.c_uint64 * (self.world + 1))()
+        self._check(self._L.m2s_dist_all_gather_counts(self._h, int(total), counts, offs))
+        return [int(x) for x in counts], [int(x) for x in offs]
+
+    def publish_count(self, total: int):
+        self._check(self._L.m2s_dist_publish_count(self._h, int(total)))
+
+    def collect_counts(self):
+        counts = (self._C.c_uint64 * self.world)()
+        offs = (self._C.c_uint64 * (self.world + 1))()
+        self._check(self._L.m2s_dist_collect_counts(self._h, counts, offs))
+        return [int(x) for x in counts], [int(x) for x in offs]
+
+    def gather_records(self, d_mine: int, counts: Sequence[int], d_merged: int, root: int = -1, stream: int = 0):
+        c = (self._C.c_uint64 * self.world)(*[int(x) for x in counts])
+        self._check(self._L.m2s_dist_gather_records(self._h, self._C.c_void_p(d_mine or None), c, self._C.c_void_p(d_merged or None),
+                                                    int(root), self._C.c_void_p(stream or None)))
+
+
 def even_ranges(T: int, world: int) -> List[Tuple[int, int]]:
     cuts = [T * r // world for r in range(world + 1)]
     return [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
