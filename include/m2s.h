@@ -102,6 +102,11 @@ m2s_status m2s_set_triangle_range(m2s_ctx* ctx, uint64_t first, uint64_t count);
  * RGBA8 textures and generates mip levels 1..4 (glUtils.cpp:292-313).  Replaces any previous scene. */
 m2s_status m2s_upload_scene(m2s_ctx* ctx, const m2s_mesh* meshes, uint32_t n_meshes);
 
+/* Optional: allocate now what the first upload (M2S_PREPARE_UPLOAD: pinned + device staging chunks) and the first export
+ * (M2S_PREPARE_EXPORT: pinned chunks for the device-to-host copies) would otherwise allocate on their own critical path. */
+enum { M2S_PREPARE_UPLOAD = 1, M2S_PREPARE_EXPORT = 2 };
+m2s_status m2s_prepare(m2s_ctx* ctx, uint32_t flags);
+
 /* Wall-clock breakdown (ms) of the last m2s_upload_scene: [0] whole call, [1] geometry (pinned staging + re-layout kernel),
  * [2] textures (staging, mip and combo kernels, final sync), [3] device / pinned allocations. */
 m2s_status m2s_last_upload_ms(const m2s_ctx* ctx, float out_ms[4]);

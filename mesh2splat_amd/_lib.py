@@ -32,7 +32,7 @@ EXPORTS = (
     "m2s_last_upload_ms", "m2s_write_ply_slice", "m2s_export_ply_slice",
     "m2s_dist_unique_id", "m2s_dist_create", "m2s_dist_destroy", "m2s_dist_rank", "m2s_dist_world", "m2s_dist_last_error",
     "m2s_dist_shard_ranges", "m2s_dist_all_gather_counts", "m2s_dist_publish_count", "m2s_dist_collect_counts",
-    "m2s_dist_clamp_to_cap", "m2s_dist_gather_records", "m2s_dist_wait", "m2s_set_records", "m2s_reserve_records",
+    "m2s_dist_clamp_to_cap", "m2s_dist_gather_records", "m2s_dist_wait", "m2s_set_records", "m2s_reserve_records", "m2s_prepare",
 )
 
 
@@ -165,6 +165,7 @@ def load():
         "m2s_dist_wait": (C.c_int, [vp, vp]),
         "m2s_set_records": (C.c_int, [vp, vp, u64, u32]),
         "m2s_reserve_records": (C.c_int, [vp, u64, C.POINTER(vp)]),
+        "m2s_prepare": (C.c_int, [vp, u32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

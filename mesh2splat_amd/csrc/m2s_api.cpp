@@ -545,6 +545,19 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     return M2S_OK;
 }
 
+// Allocates what the first upload / the first export would otherwise allocate inside their own timed paths (pinned and
+// device staging chunks, pinned export chunks): a caller that brings the context up on a second thread while it parses the
+// input file (the command line does) takes ~100 MB of pinned allocations off its critical path.
+m2s_status m2s_prepare(m2s_ctx* c, uint32_t flags) {
+    if (!c) return M2S_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (flags & M2S_PREPARE_UPLOAD) { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
+    if (flags & M2S_PREPARE_EXPORT)
+        for (int k = 0; k < 2; ++k)
+            if (!c->h_export[k]) HIPCHK(c, hipHostMalloc((void**)&c->h_export[k], m2s_ply::kChunkRows * sizeof(m2s_gaussian), hipHostMallocDefault));
+    return M2S_OK;
+}
+
 m2s_status m2s_last_upload_ms(const m2s_ctx* c, float out_ms[4]) {
     if (!c || !out_ms) return M2S_ERR_INVALID;
     memcpy(out_ms, c->last_upload_ms, sizeof c->last_upload_ms);

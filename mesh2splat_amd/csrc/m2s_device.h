@@ -146,10 +146,18 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
                          uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st);
 
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
-// fused kernel: triangles per wave.  64 as soon as that fills the GPU's 3072 wave slots once; smaller scenes get 32 or
-// 16 so that more CUs have work and each wave's serial chain of phases is shorter (C2 stand-in, 69 k triangles: 0.076 ->
-// 0.063 ms).  With the slots filled, fewer triangles per wave only adds instructions (500 k triangles: 0.126 -> 0.156 ms).
-inline uint32_t fused_tpw(uint32_t n_tri) { return n_tri >= 64u * 3072u ? 64u : n_tri >= 32u * 3072u ? 32u : 16u; }
+// fused kernel: triangles per wave.  64 as soon as that fills the GPU's 3072 wave slots once.  A smaller scene gets just
+// enough triangles per wave to occupy every slot ONCE (one round of waves instead of two: the C2 stand-in, 69 312
+// triangles, ran 16 per wave = 4332 waves = 1.4 rounds in round 1), in multiples of 8, at least 8.  With the slots
+// filled, fewer triangles per wave only adds instructions (500 k triangles: 0.126 -> 0.156 ms at 32).
+#ifndef M2S_TPW_SLOTS
+#define M2S_TPW_SLOTS 3072u
+#endif
+inline uint32_t fused_tpw(uint32_t n_tri) {
+    const uint32_t per = (n_tri + M2S_TPW_SLOTS - 1u) / M2S_TPW_SLOTS;
+    const uint32_t r8 = (per + 7u) & ~7u;
+    return r8 < 8u ? 8u : r8 > 64u ? 64u : r8;
+}
 inline uint32_t n_fused_waves(uint32_t n_tri) { const uint32_t w = fused_tpw(n_tri); return (n_tri + w - 1) / w; }
 
 }  // namespace m2s

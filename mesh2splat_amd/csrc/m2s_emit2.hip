@@ -29,7 +29,10 @@
 
 namespace m2s {
 
-constexpr int kSlice = 512;            // output records per wave in k_emit2
+#ifndef M2S_EMIT2_SLICE
+#define M2S_EMIT2_SLICE 512
+#endif
+constexpr int kSlice = M2S_EMIT2_SLICE;   // output records per wave in k_emit2
 constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_scan
 
 // What k_emit2 needs to know about a triangle: the fragment stage's constants plus the third edge function and the

@@ -264,6 +264,24 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
     if (alive && (unsigned long long)stream0 + total_c > kEntries) alive = false;   // does not fit the LDS stream
     if (!alive && lane == 0) lds_store(&S.error, 1u);
 
+    float4* stage = S.stage[wave];
+    unsigned long long base = 0;
+    bool have_base = false;
+    // The look-back (one round trip through memory shared by all XCDs, ~5 k cycles) is taken by ONE wave — the LAST one,
+    // and BEFORE it expands its own triangles: its entries sit at the end of the workgroup's stream and are the last ones
+    // a strip asks for, while the other three waves are already expanding and shading the front of the stream.  By the
+    // time anybody reaches a store, the base is there (round 1 took the look-back after the last wave's expansion: wave 0
+    // then waited 3.9 k cycles for the base on average).  The predecessors' aggregates are published right after THEIR
+    // counting, i.e. at about the time this workgroup has counted too.
+#ifndef M2S_LATE_LOOKBACK
+    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&S.error) == 0) {
+        const unsigned long long tb0 = F2_NOW();
+        have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+        if (!have_base) alive = false;
+        tk_base += F2_NOW() - tb0;
+    }
+#endif
+
     // ======================= my TriShade, tskip and entries =======================
     if (alive) {
         if (cntc) {
@@ -335,18 +353,12 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
         }
         tk_cnt += F2_NOW() - tw0;
     }
-    float4* stage = S.stage[wave];
-    unsigned long long base = 0;
-    bool have_base = false;
-    // The look-back (one round trip through memory shared by all XCDs, ~5 k cycles) is taken by ONE wave, now, while
-    // the other three are already shading: by the time they reach their first store the base is there.  The strips
-    // are handed out dynamically, so the resolving wave simply takes fewer of them.
+#ifdef M2S_LATE_LOOKBACK   // A/B switch: round 1's placement (after the last wave's own expansion)
     if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&S.error) == 0) {
-        const unsigned long long tb0 = F2_NOW();
         have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
         if (!have_base) alive = false;
-        tk_base += F2_NOW() - tb0;
     }
+#endif
     while (alive && lds_load(&S.error) == 0) {
         uint32_t s = 0;
         if (lane == 0) s = __hip_atomic_fetch_add(&S.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -11,10 +11,19 @@
 //     sample replication for every other ratio;
 //   * colour: 20-bit fixed point (y << 20) + (1 << 19) with the constants 1.40200, 0.71414, 0.34414, 1.77200 rounded
 //     at 12 bits, the Cb contribution to green truncated to its upper 16 bits.
+// ATTRIBUTION.  The three arithmetic recipes above are not ours: the fixed-point constants, rounding terms and shift
+// amounts are those of stb_image.h v2.29 (Sean Barrett et al., public domain / MIT; stbi__idct_block, stbi__resample_row_*,
+// stbi__YCbCr_to_RGB_row), whose inverse DCT in turn derives from the Independent JPEG Group's jidctint.c (Loeffler,
+// Ligtenberg, Moschytz; IJG licence: "this software is based in part on the work of the Independent JPEG Group").  They
+// are reproduced because the decoded bytes must equal the reference loader's; the code that evaluates them below is
+// written from the formulas (matrix form of the transform, one planar up-sampler, a per-pixel colour function), not
+// transcribed from stb_image.
 // Supported: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2) Huffman JPEG, 8 bits per sample,
 // 1 or 3 components, sampling factors 1..4, restart intervals, Adobe APP14 / component-id RGB detection.
 // Not supported (explicit error): arithmetic coding, lossless, 12-bit, 4-component (CMYK / YCCK) files.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "m2s_host.h"
 
@@ -240,57 +249,56 @@ struct Decoder {
     }
 
     // ---- inverse DCT (see the header comment) ------------------------------------------------------------------
-    static inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
+    // The 8-point transform as two 4x4 integer matrices (even and odd inputs): every entry is a sum of the 12-bit LLM
+    // constants, so in integer arithmetic the products below equal the butterfly network's results exactly (64-bit
+    // accumulators: no overflow for any coefficient a corrupt stream can hold).  out[k] = even[k] + odd[k],
+    // out[7 - k] = even[k] - odd[k].
     static inline uint8_t clamp8(long long x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
+    struct IdctMatrices {
+        long long even[4][4];   // rows: outputs 0..3, columns: inputs 0, 2, 4, 6
+        long long odd[4][4];    // rows: outputs 0..3, columns: inputs 1, 3, 5, 7
+        IdctMatrices() {
+            auto fx = [](double x) { return (long long)(int)(x * 4096 + 0.5); };
+            const long long A = fx(0.5411961), B = fx(-1.847759065), C = fx(0.765366865), one = 4096;
+            const long long k1175 = fx(1.175875602), k0298 = fx(0.298631336), k2053 = fx(2.053119869), k3072 = fx(3.072711026),
+                            k1501 = fx(1.501321110), m0899 = fx(-0.899976223), m2562 = fx(-2.562915447), m1961 = fx(-1.961570560),
+                            m0390 = fx(-0.390180644);
+            const long long r2 = A + C, r6 = A, q2 = A, q6 = A + B;            // the two rotated even terms
+            const long long e[4][4] = { { one, r2, one, r6 }, { one, q2, -one, q6 }, { one, -q2, -one, -q6 }, { one, -r2, one, -r6 } };
+            const long long o[4][4] = { { k1501 + k1175 + m0899 + m0390, k1175, k1175 + m0390, k1175 + m0899 },
+                                        { k1175, k3072 + k1175 + m2562 + m1961, k1175 + m2562, k1175 + m1961 },
+                                        { k1175 + m0390, k1175 + m2562, k2053 + k1175 + m2562 + m0390, k1175 },
+                                        { k1175 + m0899, k1175 + m1961, k1175, k0298 + k1175 + m0899 + m1961 } };
+            memcpy(even, e, sizeof even);
+            memcpy(odd, o, sizeof odd);
+        }
+    };
+    // one 8-point pass over in[0], in[step], ...: writes (value + bias) >> shift through `store`
+    template <class In, class Store>
+    static inline void idct_pass(const IdctMatrices& M, In in, long long bias, int shift, Store store) {
+        const long long ev[4] = { in(0), in(2), in(4), in(6) }, od[4] = { in(1), in(3), in(5), in(7) };
+        for (int k = 0; k < 4; ++k) {
+            const long long e = M.even[k][0] * ev[0] + M.even[k][1] * ev[1] + M.even[k][2] * ev[2] + M.even[k][3] * ev[3] + bias;
+            const long long o = M.odd[k][0] * od[0] + M.odd[k][1] * od[1] + M.odd[k][2] * od[2] + M.odd[k][3] * od[3];
+            store(k, (e + o) >> shift);
+            store(7 - k, (e - o) >> shift);
+        }
+    }
     static void idct(uint8_t* out, int stride, const short d[64]) {
-        static const int c0541 = f2f(0.5411961), cm1847 = f2f(-1.847759065), c0765 = f2f(0.765366865), c1175 = f2f(1.175875602),
-                         c0298 = f2f(0.298631336), c2053 = f2f(2.053119869), c3072 = f2f(3.072711026), c1501 = f2f(1.501321110),
-                         cm0899 = f2f(-0.899976223), cm2562 = f2f(-2.562915447), cm1961 = f2f(-1.961570560), cm0390 = f2f(-0.390180644);
-        // 64-bit temporaries: identical results for every valid stream (the 32-bit reference arithmetic cannot overflow
-        // there) and no undefined behaviour on corrupt coefficients
-        long long val[64];
-#define M2S_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                    \
-        long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                  \
-        p2 = s2; p3 = s6;                                                              \
-        p1 = (p2 + p3) * c0541;                                                        \
-        t2 = p1 + p3 * cm1847;                                                         \
-        t3 = p1 + p2 * c0765;                                                          \
-        p2 = s0; p3 = s4;                                                              \
-        t0 = (p2 + p3) * 4096;                                                         \
-        t1 = (p2 - p3) * 4096;                                                         \
-        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                        \
-        t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                            \
-        p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                        \
-        p5 = (p3 + p4) * c1175;                                                        \
-        t0 = t0 * c0298; t1 = t1 * c2053; t2 = t2 * c3072; t3 = t3 * c1501;            \
-        p1 = p5 + p1 * cm0899; p2 = p5 + p2 * cm2562; p3 = p3 * cm1961; p4 = p4 * cm0390; \
-        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
-        for (int i = 0; i < 8; ++i) {   // columns
-            const short* s = d + i;
-            long long* v = val + i;
-            if (s[8] == 0 && s[16] == 0 && s[24] == 0 && s[32] == 0 && s[40] == 0 && s[48] == 0 && s[56] == 0) {
-                const long long dcterm = s[0] * 4;
-                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
-            } else {
-                M2S_IDCT_1D(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56])
-                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-                v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
-                v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-                v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-                v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
-            }
+        static const IdctMatrices M;
+        long long mid[64];
+        for (int c = 0; c < 8; ++c) {   // columns; two extra fractional bits are kept (bias 512, >> 10)
+            const short* s = d + c;
+            bool ac = false;
+            for (int r = 1; r < 8; ++r) ac = ac || s[8 * r] != 0;
+            if (!ac) { for (int r = 0; r < 8; ++r) mid[8 * r + c] = (long long)s[0] * 4; continue; }   // DC only: the constant column
+            idct_pass(M, [&](int r) { return (long long)s[8 * r]; }, 512, 10, [&](int r, long long v) { mid[8 * r + c] = v; });
         }
-        for (int i = 0; i < 8; ++i) {   // rows
-            const long long* v = val + 8 * i;
-            uint8_t* o = out + (size_t)i * stride;
-            M2S_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-            x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
-            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17);
-            o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
-            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17);
-            o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+        for (int r = 0; r < 8; ++r) {   // rows; the level shift (+128) is folded into the rounding term
+            const long long* v = mid + 8 * r;
+            uint8_t* o = out + (size_t)r * stride;
+            idct_pass(M, [&](int c) { return v[c]; }, 65536 + (128 << 17), 17, [&](int c, long long x) { o[c] = clamp8(x); });
         }
-#undef M2S_IDCT_1D
     }
 
     // ---- markers ---------------------------------------------------------------------------------------------------
@@ -573,48 +581,70 @@ struct Decoder {
     }
 };
 
-// ---- upsampling (see the header comment) ----------------------------------------------------------------------------
-typedef uint8_t* (*ResampleFn)(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int hs);
-uint8_t* resample_1(uint8_t*, const uint8_t* in_near, const uint8_t*, int, int) { return const_cast<uint8_t*>(in_near); }
-uint8_t* resample_v2(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int) {
-    for (int i = 0; i < w; ++i) out[i] = (uint8_t)((3 * in_near[i] + in_far[i] + 2) >> 2);
-    return out;
-}
-uint8_t* resample_h2(uint8_t* out, const uint8_t* in_near, const uint8_t*, int w, int) {
-    const uint8_t* in = in_near;
-    if (w == 1) { out[0] = out[1] = in[0]; return out; }
-    out[0] = in[0];
-    out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
-    int i;
-    for (i = 1; i < w - 1; ++i) {
-        const int n = 3 * in[i] + 2;
-        out[i * 2 + 0] = (uint8_t)((n + in[i - 1]) >> 2);
-        out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2);
+// ---- upsampling and colour (see the header comment) ----------------------------------------------------------------------
+// One up-sampler for all ratios.  A component plane is (h_max / h) x (v_max / v) times smaller than the image.  For the
+// ratios 1 and 2 the output sample is the triangle-filtered blend of the nearest and the second-nearest source sample
+// in each direction, weights 3/4 and 1/4, evaluated vertically first, with ONE rounding per direction combination:
+//   v only:  (3 n + f + 2) >> 2        h only:  (3 c + side + 2) >> 2        both:  (3 (3 n + f)_c + (3 n + f)_side + 8) >> 4
+// (edge columns, which have no outer neighbour: the vertical blend alone, rounded as in "v only"); other ratios replicate.
+struct Plane {
+    const uint8_t* data;
+    int w2;            // row pitch
+    int w, h;          // valid samples
+    int hs, vs;        // up-sampling factors
+    // the row of the image-sized plane that output row j needs, written to `out` (W samples); rows are visited in order
+    void row(int j, int W, uint8_t* out) const {
+        if (!((hs == 1 || hs == 2) && (vs == 1 || vs == 2))) {                     // every other ratio: replicate
+            const uint8_t* src = data + (size_t)std::min(j / vs, h - 1) * w2;
+            for (int i = 0; i < W; ++i) out[i] = src[std::min(i / hs, w - 1)];
+            return;
+        }
+        // vertical neighbours of output row j: the source row it falls in, and the one on the side of the nearer edge
+        int near_r = 0, far_r = 0;
+        if (vs == 2) {
+            near_r = std::min(j >> 1, h - 1);
+            far_r = (j & 1) ? std::min(near_r + 1, h - 1) : std::max(near_r - 1, 0);
+        } else near_r = far_r = std::min(j, h - 1);
+        const uint8_t* n = data + (size_t)near_r * w2;
+        const uint8_t* f = data + (size_t)far_r * w2;
+        const int wl = (W + hs - 1) / hs;                                           // source samples this row uses
+        if (hs == 1) {
+            if (vs == 1) { memcpy(out, n, (size_t)W); return; }
+            for (int i = 0; i < W; ++i) out[i] = (uint8_t)((3 * n[i] + f[i] + 2) >> 2);
+            return;
+        }
+        // hs == 2: vertical blend kept unrounded (x4, or x1 when there is no vertical step), then the horizontal blend
+        auto vblend = [&](int i) { return vs == 2 ? 3 * n[i] + f[i] : (int)n[i]; };
+        const int unit = vs == 2 ? 4 : 1;                                           // scale of vblend
+        auto put = [&](int x, uint8_t v) { if (x < W + 3) out[x] = v; };           // (the scratch row has slack)
+        for (int i = 0; i < wl; ++i) {
+            const int c = vblend(i);
+            const int left = i > 0 ? vblend(i - 1) : -1, right = i + 1 < wl ? vblend(i + 1) : -1;
+            // (the horizontal-only filter of the decoder this reproduces weights its LAST interior sample the other way
+            // round: 3 * in[w-2] + in[w-1]; kept, or the decoded bytes would differ in one column)
+            if (vs == 1 && i == wl - 1 && i > 0) put(2 * i, (uint8_t)((3 * left + c + 2) >> 2));
+            else put(2 * i, left < 0 ? (uint8_t)((c + unit / 2) / unit) : (uint8_t)((3 * c + left + 2 * unit) / (4 * unit)));
+            put(2 * i + 1, right < 0 ? (uint8_t)((c + unit / 2) / unit) : (uint8_t)((3 * c + right + 2 * unit) / (4 * unit)));
+        }
     }
-    out[i * 2 + 0] = (uint8_t)((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
-    out[i * 2 + 1] = in[w - 1];
-    return out;
-}
-uint8_t* resample_hv2(uint8_t* out, const uint8_t* in_near, const uint8_t* in_far, int w, int) {
-    if (w == 1) { out[0] = out[1] = (uint8_t)((3 * in_near[0] + in_far[0] + 2) >> 2); return out; }
-    int t1 = 3 * in_near[0] + in_far[0];
-    out[0] = (uint8_t)((t1 + 2) >> 2);
-    for (int i = 1; i < w; ++i) {
-        const int t0 = t1;
-        t1 = 3 * in_near[i] + in_far[i];
-        out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
-        out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
-    }
-    out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
-    return out;
-}
-uint8_t* resample_generic(uint8_t* out, const uint8_t* in_near, const uint8_t*, int w, int hs) {
-    for (int i = 0; i < w; ++i)
-        for (int j = 0; j < hs; ++j) out[i * hs + j] = in_near[i];
-    return out;
-}
+};
 
-inline int float2fixed(double x) { return ((int)(x * 4096.0 + 0.5)) << 8; }
+// JFIF YCbCr -> RGB in 20-bit fixed point; the constants are rounded at 12 bits first, and the Cb term of green keeps only
+// its upper 16 bits (all three as in the decoder whose bytes this must reproduce)
+struct YccToRgb {
+    int cr_r, cr_g, cb_g, cb_b;
+    YccToRgb() {
+        auto fx = [](double x) { return ((int)(x * 4096.0 + 0.5)) << 8; };
+        cr_r = fx(1.40200); cr_g = -fx(0.71414); cb_g = -fx(0.34414); cb_b = fx(1.77200);
+    }
+    inline void operator()(int y, int cb, int cr, uint8_t* rgba) const {
+        const int base = (y << 20) + (1 << 19), u = cb - 128, v = cr - 128;
+        rgba[0] = Decoder::clamp8((base + v * cr_r) >> 20);
+        rgba[1] = Decoder::clamp8((base + v * cr_g + (int)(((unsigned)(u * cb_g)) & 0xffff0000u)) >> 20);
+        rgba[2] = Decoder::clamp8((base + u * cb_b) >> 20);
+        rgba[3] = 255;
+    }
+};
 
 }  // namespace
 
@@ -626,49 +656,25 @@ bool decode_jpeg(const uint8_t* data, size_t len, Image& img, std::string& err) 
     img.width = (uint32_t)W; img.height = (uint32_t)H;
     img.rgba.assign((size_t)W * H * 4, 255);
 
-    struct Res { ResampleFn fn; const uint8_t *line0, *line1; int hs, vs, w_lores, ystep, ypos; std::vector<uint8_t> buf; } res[3];
+    Plane plane[3];
+    std::vector<uint8_t> scratch[3];
     for (int k = 0; k < d.n_comp; ++k) {
-        Res& r = res[k];
         const Component& c = d.comp[k];
-        r.hs = d.h_max / c.h; r.vs = d.v_max / c.v;
-        r.ystep = r.vs >> 1;
-        r.w_lores = (W + r.hs - 1) / r.hs;
-        r.ypos = 0;
-        r.line0 = r.line1 = c.data.data();
-        r.buf.assign((size_t)W + 3 + 16, 0);
-        r.fn = (r.hs == 1 && r.vs == 1) ? resample_1 : (r.hs == 1 && r.vs == 2) ? resample_v2 : (r.hs == 2 && r.vs == 1) ? resample_h2
-               : (r.hs == 2 && r.vs == 2) ? resample_hv2 : resample_generic;
+        plane[k] = Plane{ c.data.data(), c.w2, c.x, c.y, d.h_max / c.h, d.v_max / c.v };
+        scratch[k].assign((size_t)W + 3 + 16, 0);
     }
     const bool is_rgb = d.n_comp == 3 && (d.rgb_ids == 3 || (d.app14_transform == 0 && !d.jfif));
-    const int k_cr_r = float2fixed(1.40200), k_cr_g = -float2fixed(0.71414), k_cb_g = -float2fixed(0.34414), k_cb_b = float2fixed(1.77200);
+    static const YccToRgb to_rgb;
     for (int j = 0; j < H; ++j) {
         const uint8_t* row[3] = { nullptr, nullptr, nullptr };
-        for (int k = 0; k < d.n_comp; ++k) {
-            Res& r = res[k];
-            const Component& c = d.comp[k];
-            const bool y_bot = r.ystep >= (r.vs >> 1);
-            row[k] = r.fn(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs);
-            if (++r.ystep >= r.vs) {
-                r.ystep = 0;
-                r.line0 = r.line1;
-                if (++r.ypos < c.y) r.line1 += c.w2;
-            }
-        }
+        for (int k = 0; k < d.n_comp; ++k) { plane[k].row(j, W, scratch[k].data()); row[k] = scratch[k].data(); }
         uint8_t* out = img.rgba.data() + (size_t)j * W * 4;
         if (d.n_comp == 1) {
             for (int i = 0; i < W; ++i) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = row[0][i]; out[4 * i + 3] = 255; }
         } else if (is_rgb) {
             for (int i = 0; i < W; ++i) { out[4 * i] = row[0][i]; out[4 * i + 1] = row[1][i]; out[4 * i + 2] = row[2][i]; out[4 * i + 3] = 255; }
         } else {
-            for (int i = 0; i < W; ++i) {
-                const int y_fixed = (row[0][i] << 20) + (1 << 19);
-                const int cr = row[2][i] - 128, cb = row[1][i] - 128;
-                int r = y_fixed + cr * k_cr_r;
-                int g = y_fixed + cr * k_cr_g + (int)(((unsigned)(cb * k_cb_g)) & 0xffff0000u);
-                int b = y_fixed + cb * k_cb_b;
-                r >>= 20; g >>= 20; b >>= 20;
-                out[4 * i] = Decoder::clamp8(r); out[4 * i + 1] = Decoder::clamp8(g); out[4 * i + 2] = Decoder::clamp8(b); out[4 * i + 3] = 255;
-            }
+            for (int i = 0; i < W; ++i) to_rgb(row[0][i], row[1][i], row[2][i], out + 4 * i);
         }
     }
     return true;

@@ -43,3 +43,62 @@ def assert_records_match(gpu: np.ndarray, ref: np.ndarray, what: str = ""):
         raise AssertionError(f"{what}: {bad.sum()} of {bad.size} floats differ; first at record {i} float {j}: "
                              f"gpu {gpu[i, j]!r} oracle {ref[i, j]!r}\n gpu {gpu[i]}\n ref {ref[i]}")
     return float((gpu.view(np.uint32) == ref.view(np.uint32)).mean())
+
+
+FIELD_NAMES = (("position", slice(0, 3)), ("color", slice(4, 8)), ("scale", slice(8, 10)), ("normal", slice(12, 15)),
+               ("rotation", slice(16, 20)), ("pbr", slice(20, 22)))
+
+
+def error_report(gpu: np.ndarray, ref: np.ndarray) -> dict:
+    """What the parity assertion above does not show: per field, the ACHIEVED errors.
+      max_rel_component       max |gpu - ref| / |ref| over components with |ref| >= 1e-3 (a relative error is meaningless on a
+                              component that happens to be ~0, e.g. one coordinate of a unit normal)
+      max_rel_to_vector       max |gpu - ref| / max|ref vector| (the rule used for position / normal / quaternion)
+      max_abs                 max |gpu - ref|
+      frac_within_1e-4_component   fraction of floats with |gpu - ref| <= 1e-4 |ref| + 1e-7, strictly per component
+      frac_bit_identical
+    and a histogram of the per-component relative error (decades)."""
+    out = {}
+    for name, sl in FIELD_NAMES:
+        g, r = gpu[:, sl].astype(np.float64), ref[:, sl].astype(np.float64)
+        fin = np.isfinite(g) & np.isfinite(r)
+        d = np.where(fin, np.abs(g - r), 0.0)
+        big = fin & (np.abs(r) >= 1e-3)
+        rel = np.where(big, d / np.maximum(np.abs(r), 1e-30), 0.0)
+        vec = np.abs(np.where(fin, r, 0.0)).max(axis=1, keepdims=True)
+        relv = d / np.maximum(vec, 1e-30)
+        edges = [0.0, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, np.inf]
+        hist, _ = np.histogram(rel[big], bins=edges)
+        out[name] = {"max_rel_component": float(rel.max()), "max_rel_to_vector": float(relv.max()), "max_abs": float(d.max()),
+                     "frac_within_1e-4_component": float((d <= 1e-4 * np.abs(r) + 1e-7)[fin].mean()),
+                     "frac_bit_identical": float((gpu[:, sl].view(np.uint32) == ref[:, sl].view(np.uint32)).mean()),
+                     "rel_error_histogram": {f"<{e:g}": int(h) for e, h in zip(edges[1:], hist)}}
+    return out
+
+
+def assert_ply_rows_match(mine: np.ndarray, ref: np.ndarray, what: str = ""):
+    """Format-1 .ply rows (19 floats: xyz | nxyz | f_dc 3 | metallic roughness | opacity | log-scale 3 | rot 4) written from
+    GPU records against the reference's file.  The rows are FUNCTIONS of the records, so the 1e-4 bar on the records becomes:
+      x y z, normal, rotation : 1e-4 of the vector (as for the records);
+      f_dc = (c - 0.5) / 0.2820948 : |d f_dc| = |dc| / 0.282 <= (1e-4 |c| + 1e-6) / 0.282;
+      log-scale = log(s sigma / R) : |d log s| = |ds| / s <= 1e-4 (+ 1e-6 / s: scales are >= 1e-7 by construction);
+      opacity = logit(a)          : |d logit| = |da| / (a (1 - a));  +inf (a = 1) must be +inf."""
+    assert mine.shape == ref.shape, what
+    m, r = mine.astype(np.float64), ref.astype(np.float64)
+    same_inf = np.isinf(m) & (m == r)
+    m = np.where(same_inf, 0, m); r = np.where(same_inf, 0, r)
+    tol = np.empty_like(r)
+    for sl in (slice(0, 3), slice(3, 6), slice(15, 19)):
+        tol[:, sl] = RTOL * np.abs(r[:, sl]).max(axis=1, keepdims=True) + ATOL_VECTOR
+    c = r[:, 6:9] * 0.28209479177387814 + 0.5
+    tol[:, 6:9] = (RTOL * np.abs(c) + ATOL_SCALAR) / 0.28209479177387814 + 1e-7
+    tol[:, 9:11] = RTOL * np.abs(r[:, 9:11]) + ATOL_SCALAR
+    a = 1.0 / (1.0 + np.exp(-r[:, 11]))
+    tol[:, 11] = (RTOL * a + ATOL_SCALAR) / np.maximum(a * (1.0 - a), 1e-12) + 1e-6
+    tol[:, 12:15] = RTOL + 2e-6
+    bad = ~(np.abs(m - r) <= tol)
+    if bad.any():
+        i, j = np.argwhere(bad)[0]
+        raise AssertionError(f"{what}: {bad.sum()} of {bad.size} row floats differ; first at row {i} column {j}: {mine[i, j]!r} vs {ref[i, j]!r}")
+    return {"max_abs_log_scale": float(np.abs(m[:, 12:15] - r[:, 12:15]).max()), "max_abs_opacity": float(np.abs(m[:, 11] - r[:, 11]).max()),
+            "max_abs_f_dc": float(np.abs(m[:, 6:9] - r[:, 6:9]).max())}

@@ -45,3 +45,40 @@ def test_cli_defaults_are_the_guis(tmp_path, hiplib):
     r = subprocess.run([EXE, glb, out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert resolution_from_quality(0.5, 1024) == 520 and "density 520 -> 270400 Gaussians" in r.stdout
+
+
+@pytest.mark.parametrize("fmt", [0, 2])
+def test_cli_sharded_code_path_with_one_rank(tmp_path, hiplib, fmt):
+    """`--gpus N` with N = 1 (--force-sharded): fork after the CPU-only load, shard plan, RCCL communicator and counter
+    exchange through libm2s_hip.so, the slice writer (and, with --gather, the record exchange to rank 0 + whole-file export)
+    — the same file, byte for byte, as the single-process path.  Also a scene above the reference's cap (global cap semantics)."""
+    scene = synth.sphere_grid(2, n=5, tex_size=32)
+    glb = str(tmp_path / "s.glb")
+    gltf_io.write_glb(scene, glb)
+    for density, cap in (("96", []), ("96", ["--cap", "20000"])):
+        one = str(tmp_path / "one.ply")
+        r = subprocess.run([EXE, glb, one, "--density", density, "--format", str(fmt)] + cap, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for extra in ([], ["--gather"]):
+            out = str(tmp_path / "sharded.ply")
+            r = subprocess.run([EXE, glb, out, "--density", density, "--format", str(fmt), "--force-sharded", "--timing"] + cap + extra,
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr + r.stdout
+            assert open(out, "rb").read() == open(one, "rb").read(), (fmt, cap, extra)
+
+
+def test_cli_batch_equals_single_runs(tmp_path, hiplib):
+    """--batch: loader thread | upload + convert | exporter thread over two alternating contexts; every output identical to
+    the one-file command's."""
+    ind, outd, single = tmp_path / "in", tmp_path / "out", tmp_path / "single"
+    for d in (ind, outd, single):
+        d.mkdir()
+    for i in range(5):
+        gltf_io.write_glb(synth.cube_sphere(8 + 3 * i, tex_size=32, seed=7 + i), str(ind / f"m{i}.glb"))
+    r = subprocess.run([EXE, "--batch", str(ind), "--out", str(outd), "--density", "200", "--format", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "5 file(s)" in r.stdout and "meshes/s" in r.stdout
+    for i in range(5):
+        r = subprocess.run([EXE, str(ind / f"m{i}.glb"), str(single / f"m{i}.ply"), "--density", "200", "--format", "1"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (outd / f"m{i}.ply").read_bytes() == (single / f"m{i}.ply").read_bytes()

@@ -47,7 +47,7 @@ struct Options {
     double quality = 0.5, std_dev = 0.65;
     long max_res = 1024, density = -1, device = 0, cap = -1, format = 0, gpus = 1;
     int pipeline = M2S_PIPELINE_AUTO;
-    bool timing = false, gather = false;
+    bool timing = false, gather = false, force_sharded = false;   // force_sharded: the --gpus code path with one rank (tests)
     uint32_t R() const { return density > 0 ? (uint32_t)density : (uint32_t)(int)(16 + quality * (double)(max_res - 16)); }  // ImGuiUI.cpp:512
 };
 
@@ -72,6 +72,7 @@ int convert_one(const Options& o) {
     std::thread init([&] {
         const auto a = Clock::now();
         create_status = m2s_create((int)o.device, &ctx);
+        if (create_status == M2S_OK) (void)m2s_prepare(ctx, M2S_PREPARE_UPLOAD | M2S_PREPARE_EXPORT);   // pinned buffers: off the critical path
         create_ms = ms_between(a, Clock::now());
     });
     m2s_host_scene* scene = nullptr;
@@ -340,6 +341,7 @@ int main(int argc, char** argv) {
         else if (a == "--cap") o.cap = std::atol(next());
         else if (a == "--gpus") o.gpus = std::atol(next());
         else if (a == "--gather") o.gather = true;
+        else if (a == "--force-sharded") o.force_sharded = true;
         else if (a == "--batch") o.batch_dir = next();
         else if (a == "--out") o.out_dir = next();
         else if (a == "--pipeline") o.pipeline = std::string(next()) == "multipass" ? M2S_PIPELINE_MULTIPASS : M2S_PIPELINE_AUTO;
@@ -354,5 +356,5 @@ int main(int argc, char** argv) {
     }
     if (pos.size() != 2) { usage(); return 2; }
     o.in = pos[0]; o.out = pos[1];
-    return o.gpus > 1 ? convert_sharded(o) : convert_one(o);
+    return (o.gpus > 1 || o.force_sharded) ? convert_sharded(o) : convert_one(o);
 }
