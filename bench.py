@@ -602,40 +602,65 @@ def main():
             del merged
         rig.close()
         strong = {}
-        for sname in (["c3"] + (["c4"] if not a.no_extra_workloads else [])):
-            sn, stex, sR = WORKLOADS[sname]
-            one = synth.sphere_grid(4, n=18, tex_size=stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
-            plan = m2d.shard_ranges_native(one, sR, world)
-            srig = Rig(torch, local_rank, one, sR, tri_range=plan[rank], cap=0, out_rows=0, exchange=exchange)
-            sdt, stotal = timed_loop(torch, dist, True, srig, a.steps, a.warmup)
-            scounts, soffs = exchange.all_gather_counts(stotal)
-            entry = {"scene": sname, "R": sR, "triangles": one.n_triangles, "gaussians": soffs[-1], "per_rank_gaussians": scounts,
-                     "per_rank_triangles": [c_ for _, c_ in plan],
-                     "no_gather": {"ms_per_step": sdt / a.steps * 1e3, "value": soffs[-1] / (sdt / a.steps),
-                                   "what": "shards by estimated fragments (m2s_dist_shard_ranges), convert + counter exchange; every rank "
-                                           "keeps its block and knows its offset (what per-rank .ply slice writers need)"}}
-            if not a.no_gather:
-                merged = torch.empty((max(soffs[-1], 1), 24), dtype=torch.float32, device="cuda")
-                exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
-                torch.cuda.synchronize(); dist.barrier()
-                g0 = time.perf_counter()
-                for _ in range(reps):
-                    srig.step_sync()
+        strong_scenes = ["c3"] + ([] if a.no_extra_workloads else ["c4"]) + (["c5p"] if (world == 8 and not a.no_extra_workloads) else [])
+        for sname in strong_scenes:
+            # every rank takes the same path through this block (collectives inside): an exception is recorded, not raised
+            try:
+                if sname == "c5p":
+                    # BASELINE config 5 at 1/8 of its triangle count (the full 50 M-triangle scene is 7.2 GB of vertices per rank to
+                    # generate on the host): 4 meshes x cube-sphere n=361 = 6.25 M triangles, 4096^2 maps, R = 2048, cap lifted,
+                    # + the depth sort of the MERGED buffer (m2s_set_records + m2s_sort_by_depth on every rank)
+                    one, sR = synth.sphere_row(4, 361, 4096), 2048
+                else:
+                    sn, stex, sR = WORKLOADS[sname]
+                    one = synth.sphere_grid(4, n=18, tex_size=stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
+                plan = m2d.shard_ranges_native(one, sR, world)
+                srig = Rig(torch, local_rank, one, sR, tri_range=plan[rank], cap=0, out_rows=0, exchange=exchange)
+                sdt, stotal = timed_loop(torch, dist, True, srig, a.steps, a.warmup)
+                scounts, soffs = exchange.all_gather_counts(stotal)
+                entry = {"scene": sname, "R": sR, "triangles": one.n_triangles, "gaussians": soffs[-1], "per_rank_gaussians": scounts,
+                         "per_rank_triangles": [c_ for _, c_ in plan],
+                         "no_gather": {"ms_per_step": sdt / a.steps * 1e3, "value": soffs[-1] / (sdt / a.steps),
+                                       "what": "shards by estimated fragments (m2s_dist_shard_ranges), convert + counter exchange; every rank "
+                                               "keeps its block and knows its offset (what per-rank .ply slice writers need)"}}
+                if not a.no_gather:
+                    merged = torch.empty((max(soffs[-1], 1), 24), dtype=torch.float32, device="cuda")
                     exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
-                srig.drain_counts()
-                torch.cuda.synchronize(); dist.barrier()
-                gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
-                dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-                entry["gather"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": soffs[-1] / float(gdt.item()),
-                                   "what": "convert + all-pairs record exchange into the merged buffer on every rank"}
-                # the merged buffer must be the single-GPU output: checksum of checksums across ranks
-                chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device="cuda")
-                allchk = [torch.zeros_like(chk) for _ in range(world)]
-                dist.all_gather(allchk, chk)
-                entry["gather"]["merged_identical_on_all_ranks"] = bool(all(int(x.item()) == int(chk.item()) for x in allchk))
-                del merged
-            strong[sname] = entry
-            srig.close()
+                    torch.cuda.synchronize(); dist.barrier()
+                    g0 = time.perf_counter()
+                    for _ in range(reps):
+                        srig.step_sync()
+                        exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
+                    srig.drain_counts()
+                    torch.cuda.synchronize(); dist.barrier()
+                    gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+                    entry["gather"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": soffs[-1] / float(gdt.item()),
+                                       "what": "convert + all-pairs record exchange into the merged buffer on every rank"}
+                    # the merged buffer must be the single-GPU output: checksum of checksums across ranks
+                    chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device="cuda")
+                    allchk = [torch.zeros_like(chk) for _ in range(world)]
+                    dist.all_gather(allchk, chk)
+                    entry["gather"]["merged_identical_on_all_ranks"] = bool(all(int(x.item()) == int(chk.item()) for x in allchk))
+                    if sname == "c5p":
+                        from mesh2splat_amd.converter import Converter
+                        sink = Converter(local_rank)
+                        sink.set_records(merged.data_ptr(), soffs[-1], sR)
+                        view = np.eye(4, dtype=np.float32)
+                        view[2, 3] = -6.0                          # camera on +z looking at the row of spheres
+                        sink.set_profiling(True)
+                        sms = []
+                        for _ in range(3):
+                            nsort = sink.sort_by_depth(view, download=False)
+                            sms.append(sink.last_sort_ms)
+                        entry["merged_depth_sort"] = {"records": int(nsort), "ms": float(np.median(sms)),
+                                                      "what": "m2s_set_records(merged) + m2s_sort_by_depth: key build + radix sort + 96-byte gather, on every rank"}
+                        sink.close()
+                    del merged
+                strong[sname] = entry
+                srig.close()
+            except Exception as e:  # noqa: BLE001
+                strong[sname] = {"error": repr(e)}
 
     copy_gbs = None
     if rank == 0:

@@ -160,12 +160,20 @@ class Converter:
         self._check(self._L.m2s_export_ply_slice(self._h, os.fsencode(path), int(fmt), float(gaussian_std), int(first_row),
                                                  int(n_rows), int(total_rows)))
 
-    def sort_by_depth(self, world_to_view) -> np.ndarray:
-        """RadixSortPass: sort the last conversion's records by floatBitsToUint(view-space z); returns them.
+    def set_records(self, device_ptr: int, n: int, R: int):
+        """Device-resident records from elsewhere (e.g. the merged buffer of a multi-GPU exchange) become the context's
+        current records, zero copy (m2s_set_records)."""
+        self._check(self._L.m2s_set_records(self._h, C.c_void_p(device_ptr or None), int(n), int(R)))
+
+    def sort_by_depth(self, world_to_view, download: bool = True):
+        """RadixSortPass: sort the last conversion's records by floatBitsToUint(view-space z); returns them (or, with
+        download=False, their number: the sorted records stay on the device).
         world_to_view: 4x4, applied as M @ (P,1) (stored column-major for the ABI, like glm)."""
         m = np.ascontiguousarray(np.asarray(world_to_view, np.float32).T.reshape(16))   # column-major
         n = C.c_uint64()
         self._check(self._L.m2s_sort_by_depth(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        if not download:
+            return int(n.value)
         out = np.empty((n.value, RECORD_FLOATS), np.float32)
         self._check(self._L.m2s_download_sorted(self._h, out.ctypes.data, n.value))
         return out

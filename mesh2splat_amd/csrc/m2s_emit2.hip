@@ -34,6 +34,13 @@ namespace m2s {
 #endif
 constexpr int kSlice = M2S_EMIT2_SLICE;   // output records per wave in k_emit2
 constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_scan
+// waves per SIMD the two kernels are compiled for (A/B switches; see DESIGN.md for the measurements behind the defaults)
+#ifndef M2S_COUNT_WAVES
+#define M2S_COUNT_WAVES 4
+#endif
+#ifndef M2S_EMIT2_WAVES
+#define M2S_EMIT2_WAVES 3
+#endif
 
 // What k_emit2 needs to know about a triangle: the fragment stage's constants plus the third edge function and the
 // pixel bounding box (the first two edges and the box origin are in the TriShade).  7 x 16 bytes.
@@ -63,7 +70,7 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
 // ============================================================================================
 // k_count_scan
 // ============================================================================================
-__global__ void __launch_bounds__(kCountBlock) k_count_scan(SceneDev sc, uint32_t R, uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(SceneDev sc, uint32_t R, uint32_t* __restrict__ off,
                                                             uint32_t* __restrict__ start, uint32_t n_start,
                                                             unsigned long long* __restrict__ chain, uint32_t epoch,
                                                             unsigned long long* __restrict__ total_out,
@@ -187,12 +194,15 @@ __global__ void __launch_bounds__(kCountBlock) k_count_scan(SceneDev sc, uint32_
 struct Emit2Lds {
     float4 tri[64 * 5];          // TriShade of the current batch of (up to) 64 triangles
     uint32_t entries[kSlice];    // slot << 24 | y << 12 | x, indexed by (record index - slice base)
-    float4 stage[32 * 6];        // half-wave record staging
-    uint32_t row_off[64];        // wave-cooperative expansion of tall triangles: row-length prefix ...
-    int row_xa[64];              // ... and first covered column of 64 consecutive rows
+    float4 stage[32 * 6];        // half-wave record staging; during the expansion its first 512 bytes hold, for the
+                                 // wave-cooperative expansion of tall triangles, the row-length prefix and the first covered
+                                 // column of 64 consecutive rows (row_off / row_xa below) — the two uses never overlap in time
+    __device__ __forceinline__ uint32_t* row_off() { return reinterpret_cast<uint32_t*>(stage); }
+    __device__ __forceinline__ int* row_xa() { return reinterpret_cast<int*>(stage) + 64; }
 };
+static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of four waves per CU");
 
-__global__ void __launch_bounds__(kBlock, 3) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
+__global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ start,
                                                      const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                      const float4* __restrict__ setup, float4* __restrict__ out) {
@@ -274,8 +284,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit2(SceneDev sc, uint32_t R, co
                 const uint32_t chunk = __shfl(incl, 63);
                 if (acc + chunk > pos) {
                     wave_lds_sync();
-                    L.row_off[lane] = incl - len;
-                    L.row_xa[lane] = xa;
+                    L.row_off()[lane] = incl - len;
+                    L.row_xa()[lane] = xa;
                     wave_lds_sync();
                     const uint32_t lo = acc < pos ? pos - acc : 0;
                     const uint32_t hi = acc + chunk > bend ? bend - acc : chunk;
@@ -283,8 +293,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_emit2(SceneDev sc, uint32_t R, co
                         int r = 0;  // largest r with row_off[r] <= k
 #pragma unroll
                         for (int step = 32; step >= 1; step >>= 1)
-                            if (L.row_off[r + step] <= k) r += step;
-                        const int x = L.row_xa[r] + (int)(k - L.row_off[r]);
+                            if (L.row_off()[r + step] <= k) r += step;
+                        const int x = L.row_xa()[r] + (int)(k - L.row_off()[r]);
                         L.entries[acc + k - wbase] = btag | ((uint32_t)(yc + r) << 12) | (uint32_t)x;
                     }
                 }

@@ -141,6 +141,17 @@ def sphere_grid(n_meshes_side: int = 4, n: int = 18, tex_size: int = 1024, spaci
     return Scene(meshes)
 
 
+def sphere_row(count: int = 4, n: int = 361, tex_size: int = 4096, seed: int = SEED, stride: int = 12) -> Scene:
+    """I-5 proxy (BASELINE config 5 at 1/8 of its triangles by default): `count` cube-spheres of 12 n^2 triangles in a row,
+    each with its own maps; the cumulative bbox grows mesh by mesh, so later meshes cover fewer pixels each."""
+    meshes = []
+    for k in range(count):
+        v = cube_sphere_vertices(n, radius=1.0, center=(2.5 * k, 0.0, 0.0), stride=stride)
+        tex = procedural_textures(tex_size, seed + k) if tex_size else {}
+        meshes.append(Mesh(name=f"sphere_{k}", vertices=v, base_color=(1.0, 1.0, 1.0, 1.0), textures=tex))
+    return Scene(meshes)
+
+
 def colocated_spheres(count: int, n: int, tex_size: int, seed: int = SEED, stride: int = 12) -> Scene:
     """Weak-scaling scene: `count` identical-geometry cube-spheres at the origin (so the cumulative
     bbox is the same for every mesh and every mesh yields the same number of Gaussians), one
