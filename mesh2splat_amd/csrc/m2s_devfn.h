@@ -784,4 +784,125 @@ __device__ __forceinline__ void nt_store(float4* p, float4 v) {
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // merged into one dwordx4 nt
 }
 
+// ============================================================================================
+// shade_from_tri for K fragments per lane at once (K = 2: "dual strip")
+// ============================================================================================
+// The same operations as shade_from_tri, per fragment, in the same order — hence the same bits — but written stage by stage
+// over K independent fragments so that ALL their loads of a stage are in flight together: K x the memory-level parallelism per
+// wave at the price of K x the registers (the single-fragment form keeps 3 waves per SIMD busy with one strip each; two
+// waves with two strips each have four strips in flight).  Fragment k of the 64 lanes forms strip k: wave-uniform decisions
+// (does any lane of the strip blend two mip levels?) are taken per k, exactly as the single-fragment code takes them per strip.
+// Fast path only: wave-uniform mesh WITH a combo texture (the caller falls back to shade_from_tri otherwise).
+template <int K, class MP>
+__device__ __forceinline__ void shade_from_tri_x(const TriPlanes& tp, const uint32_t t[K], const int x[K], const int y[K], MP mp,
+                                                 const TriShade* const ts[K], float4 rec[K][6]) {
+    float l1[K], l2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int dx256 = (x[k] - (int)(ts[k]->org & 0xFFFu)) * 256, dy256 = (y[k] - (int)(ts[k]->org >> 12)) * 256;
+        const long long E1 = ts[k]->e1 + (long long)ts[k]->a1 * dx256 + (long long)ts[k]->b1 * dy256;
+        const long long E2 = ts[k]->e2 + (long long)ts[k]->a2 * dx256 + (long long)ts[k]->b2 * dy256;
+        {
+#pragma clang fp contract(off)
+            l1[k] = i64_to_f32(E1) * ts[k]->inva;
+            l2[k] = i64_to_f32(E2) * ts[k]->inva;
+        }
+    }
+    // ---- attribute planes of all K fragments: UV first (the texel addresses depend on them) ----
+    float4 b0[K], a0[K], a1[K], c0[K], c1[K], d0[K], d1[K], d2[K];
+    float2 b1[K];
+    float a2[K], c2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { b0[k] = ld_plane(tp.B0, t[k]); b1[k] = ld_plane(tp.B1, t[k]); }
+    const auto ta = &mp->tex[0];
+    const uint32_t w = ta->w, h = ta->h;
+    const uint32_t* __restrict__ base = mp->combo.texels;
+    // ---- texel addresses of all K fragments ----
+    ComboTap tlo[K], thi[K];
+    float f[K];
+    bool two[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float U, V;
+        {
+#pragma clang fp contract(off)
+            U = (b0[k].x + l1[k] * (b0[k].z - b0[k].x)) + l2[k] * (b1[k].x - b0[k].x);
+            V = (b0[k].y + l1[k] * (b0[k].w - b0[k].y)) + l2[k] * (b1[k].y - b0[k].y);
+        }
+        const float uf = frac_repeat(U), vf = frac_repeat(V);
+        f[k] = ts[k]->lod0;
+        const uint32_t off0 = __float_as_uint(ts[k]->lod1), off1 = __float_as_uint(ts[k]->lod2);
+        const uint32_t lv0 = (ts[k]->mesh >> 24) & 15u, lv1 = ts[k]->mesh >> 28;
+        combo_tap(off0, max(1u, w >> lv0), max(1u, h >> lv0), uf, vf, tlo[k]);
+        two[k] = __ballot(f[k] != 0.0f) != 0ull;
+        thi[k] = tlo[k];
+        if (two[k]) combo_tap(off1, max(1u, w >> lv1), max(1u, h >> lv1), uf, vf, thi[k]);
+    }
+    // ---- ALL row reads of all fragments and levels before the first one is consumed ----
+    ComboPair pa0[K], pa1[K], pb0[K], pb1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        pa0[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo[k].o0 * 4u));
+        pa1[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo[k].o1 * 4u));
+        if (two[k]) {
+            pb0[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi[k].o0 * 4u));
+            pb1[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi[k].o1 * 4u));
+        } else { pb0[k] = pa0[k]; pb1[k] = pa1[k]; }
+    }
+    // the remaining planes (position, normal, tangent) are requested only now, behind the texel reads: with K strips in
+    // flight their latency hides behind the filter arithmetic below, and they do not occupy registers during the texel fetch
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        a0[k] = ld_plane(tp.A0, t[k]); a1[k] = ld_plane(tp.A1, t[k]); a2[k] = ld_plane(tp.A2, t[k]);
+        c0[k] = ld_plane(tp.C0, t[k]); c1[k] = ld_plane(tp.C1, t[k]); c2[k] = ld_plane(tp.C2, t[k]);
+        d0[k] = ld_plane(tp.D0, t[k]); d1[k] = ld_plane(tp.D1, t[k]); d2[k] = ld_plane(tp.D2, t[k]);
+    }
+    float acc[K][9];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (two[k]) {
+            const float klo = (1.0f - f[k]) * kUnorm8, khi = f[k] * kUnorm8;
+            ComboTap lo = tlo[k], hi = thi[k];
+            lo.w00 *= klo; lo.w10 *= klo; lo.w01 *= klo; lo.w11 *= klo;
+            hi.w00 *= khi; hi.w10 *= khi; hi.w01 *= khi; hi.w11 *= khi;
+            float vlo[9], vhi[9];
+            combo_filter(pa0[k], pa1[k], lo, vlo);
+            combo_filter(pb0[k], pb1[k], hi, vhi);
+#pragma unroll
+            for (int ch = 0; ch < 9; ch++) acc[k][ch] = vlo[ch] + vhi[ch];
+        } else {
+            ComboTap lo = tlo[k];
+            lo.w00 *= kUnorm8; lo.w10 *= kUnorm8; lo.w01 *= kUnorm8; lo.w11 *= kUnorm8;
+            combo_filter(pa0[k], pa1[k], lo, acc[k]);
+        }
+    }
+    const bool has_normal_map = mp->tex[1].texels != nullptr;   // (a combo texture implies all three maps)
+    (void)has_normal_map;
+#define M2S_LERPK(f0, f1, f2) fma_(l2[k], (f2) - (f0), fma_(l1[k], (f1) - (f0), (f0)))
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float Pxw = M2S_LERPK(a0[k].x, a0[k].w, a1[k].z), Pyw = M2S_LERPK(a0[k].y, a1[k].x, a1[k].w), Pzw = M2S_LERPK(a0[k].z, a1[k].y, a2[k]);
+        const float Nx = M2S_LERPK(c0[k].x, c0[k].w, c1[k].z), Ny = M2S_LERPK(c0[k].y, c1[k].x, c1[k].w), Nz = M2S_LERPK(c0[k].z, c1[k].y, c2[k]);
+        const float Tx = M2S_LERPK(d0[k].x, d1[k].x, d2[k].x), Ty = M2S_LERPK(d0[k].y, d1[k].y, d2[k].y), Tz = M2S_LERPK(d0[k].z, d1[k].z, d2[k].z);
+        const float Tw = M2S_LERPK(d0[k].w, d1[k].w, d2[k].w);
+        float rx = fma_(acc[k][4], 2.0f, -1.0f), ry = fma_(acc[k][5], 2.0f, -1.0f), rz = fma_(acc[k][6], 2.0f, -1.0f);
+        float inv = fast_rsq(dot3_(rx, ry, rz, rx, ry, rz));
+        rx *= inv; ry *= inv; rz *= inv;
+        float bx = fma_(Ny, Tz, -(Nz * Ty)), by = fma_(Nz, Tx, -(Nx * Tz)), bz = fma_(Nx, Ty, -(Ny * Tx));
+        inv = fast_rsq(dot3_(bx, by, bz, bx, by, bz)) * Tw;
+        bx *= inv; by *= inv; bz *= inv;
+        inv = fast_rsq(dot3_(Nx, Ny, Nz, Nx, Ny, Nz));
+        const float nnx = Nx * inv, nny = Ny * inv, nnz = Nz * inv;
+        const float wx = fma_(nnx, rz, fma_(bx, ry, Tx * rx)), wy = fma_(nny, rz, fma_(by, ry, Ty * rx)), wz = fma_(nnz, rz, fma_(bz, ry, Tz * rx));
+        inv = fast_rsq(dot3_(wx, wy, wz, wx, wy, wz));
+        rec[k][0] = make_float4(Pxw, Pyw, Pzw, 1.0f);
+        rec[k][1] = make_float4(acc[k][0] * mp->color[0], acc[k][1] * mp->color[1], acc[k][2] * mp->color[2], acc[k][3] * mp->color[3]);
+        rec[k][2] = make_float4(ts[k]->sx, ts[k]->sy, 1e-7f, 0.0f);
+        rec[k][3] = make_float4(wx * inv, wy * inv, wz * inv, 0.0f);
+        rec[k][4] = ts[k]->rot;
+        rec[k][5] = make_float4(acc[k][8], acc[k][7], 0.0f, 1.0f);
+    }
+#undef M2S_LERPK
+}
+
 }  // namespace m2s
