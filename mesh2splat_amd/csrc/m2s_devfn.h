@@ -369,6 +369,26 @@ __device__ __forceinline__ bool setup_raster_for(const SceneDev& sc, uint32_t t,
 // ============================================================================================
 constexpr float kUnorm8 = 0.003921568859368563f;  // fp32 nearest to 1/255
 
+struct __attribute__((packed, aligned(4))) ComboPair { uint32_t v[6]; };  // {A,N,M} of texel i and of texel i+1
+
+// Texel reads name the GLOBAL address space explicitly.  The texel base pointers come out of the mesh table (a load), so
+// to the compiler they are generic pointers and every texel fetch became a FLAT load (flat_load_dwordx4 + 64-bit address
+// arithmetic per lane; a flat load ties up the LDS counter as well: round 1's ISA had 32 of them per kernel).  With the
+// address space spelled out they are global loads with the (wave-uniform) base in scalar registers and a 32-bit offset per lane.
+typedef const __attribute__((address_space(1))) char* GlobalBytes;
+__device__ __forceinline__ GlobalBytes as_global(const void* p) { return (GlobalBytes)p; }
+__device__ __forceinline__ ComboPair ld_combo(GlobalBytes base, uint32_t dword_off) {
+    const __attribute__((address_space(1))) uint32_t* p = reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(base + (size_t)(dword_off * 4u));
+    ComboPair r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.v[i] = p[i];     // merged into one dwordx4 + one dwordx2 load
+    return r;
+}
+__device__ __forceinline__ uint32_t ld_texel(GlobalBytes base, uint32_t texel) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(base + (size_t)(texel * 4u));
+}
+
+
 // Per-triangle constants of the fragment stage: computed once per triangle (fused kernel: in the
 // triangle phase, kept in LDS; multi-pass emit: recomputed per fragment).  64 bytes = four float4.
 struct TriShade {
@@ -508,7 +528,8 @@ __device__ __forceinline__ void tex_state(TD t, float uf, float vf, float lambda
 
 template <int NCH>  // number of leading channels wanted (RGBA byte order)
 __device__ __forceinline__ void tap_fetch(const uint32_t* __restrict__ texels, const TexTap& t, float out[NCH]) {
-    const uint32_t t00 = texels[t.o00], t10 = texels[t.o10], t01 = texels[t.o01], t11 = texels[t.o11];
+    const GlobalBytes gb = as_global(texels);
+    const uint32_t t00 = ld_texel(gb, t.o00), t10 = ld_texel(gb, t.o10), t01 = ld_texel(gb, t.o01), t11 = ld_texel(gb, t.o11);
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const float c00 = (float)((t00 >> (8 * ch)) & 255u), c10 = (float)((t10 >> (8 * ch)) & 255u);
@@ -534,7 +555,6 @@ __device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, 
 }
 
 // ---- combo path -----------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) ComboPair { uint32_t v[6]; };  // {A,N,M} of texel i and of texel i+1
 
 // Address + weights of one level's footprint in the combo layout.
 struct ComboTap {
@@ -600,12 +620,13 @@ __device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, co
     // instead of two (measured: the texel phase was 73 % of a strip with the levels fetched back to back)
     // 32-bit byte offsets from the (scalar) base: saddr + voffset addressing, no 64-bit address arithmetic per lane
     // (m2s_upload_scene only builds a combo texture whose size fits)
-    const ComboPair a0 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo.o0 * 4u));
-    const ComboPair a1 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo.o1 * 4u));
+    const GlobalBytes gb = as_global(base);
+    const ComboPair a0 = ld_combo(gb, tlo.o0);
+    const ComboPair a1 = ld_combo(gb, tlo.o1);
     if (two) {
         combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
-        const ComboPair b0 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi.o0 * 4u));
-        const ComboPair b1 = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi.o1 * 4u));
+        const ComboPair b0 = ld_combo(gb, thi.o0);
+        const ComboPair b1 = ld_combo(gb, thi.o1);
         // fold the level blend (1-f, f) and the UNORM8 scale into the eight bilinear weights: 8 FMAs per
         // channel and nothing else (VALUE arithmetic: same quantity as (1-f)*tau_lo + f*tau_hi, other rounding)
         const float klo = (1.0f - f) * kUnorm8, khi = f * kUnorm8;
@@ -664,11 +685,13 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
 #else
     const float4 b0 = ld_plane(tp.B0, t);
     const float2 b1 = ld_plane(tp.B1, t);
+#ifndef M2S_LATE_ATTR
     const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
     const float a2 = ld_plane(tp.A2, t);
     const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
     const float c2 = ld_plane(tp.C2, t);
     const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
+#endif
 #endif
     float U, V;
     {   // texture coordinates: exact oracle sequence (no FMA), see tri_shade_setup
@@ -722,6 +745,15 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         }
     }
     if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();   // texels arrived and filtered
+#if defined(M2S_LATE_ATTR) && !defined(M2S_SKIP_ATTR)
+    // A/B switch: request position / normal / tangent only now (fewer registers live during the texel fetch; their latency is
+    // then exposed unless another wave covers it)
+    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
+    const float a2 = ld_plane(tp.A2, t);
+    const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
+    const float c2 = ld_plane(tp.C2, t);
+    const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
+#endif
     // the remaining varyings: by now their loads have had the whole texture fetch to arrive
     const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
     const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
@@ -842,11 +874,11 @@ __device__ __forceinline__ void shade_from_tri_x(const TriPlanes& tp, const uint
     ComboPair pa0[K], pa1[K], pb0[K], pb1[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        pa0[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo[k].o0 * 4u));
-        pa1[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(tlo[k].o1 * 4u));
+        pa0[k] = ld_combo(as_global(base), tlo[k].o0);
+        pa1[k] = ld_combo(as_global(base), tlo[k].o1);
         if (two[k]) {
-            pb0[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi[k].o0 * 4u));
-            pb1[k] = *reinterpret_cast<const ComboPair*>(reinterpret_cast<const char*>(base) + (size_t)(thi[k].o1 * 4u));
+            pb0[k] = ld_combo(as_global(base), thi[k].o0);
+            pb1[k] = ld_combo(as_global(base), thi[k].o1);
         } else { pb0[k] = pa0[k]; pb1[k] = pa1[k]; }
     }
     // the remaining planes (position, normal, tangent) are requested only now, behind the texel reads: with K strips in

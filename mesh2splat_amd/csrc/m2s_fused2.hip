@@ -26,9 +26,19 @@ namespace m2s {
 #ifndef M2S_TEAM_WAVES
 #define M2S_TEAM_WAVES 4
 #endif
+#ifndef M2S_FUSED2_WAVES
+#define M2S_FUSED2_WAVES 3                 // waves per SIMD the kernel is compiled for
+#endif
+#ifndef M2S_FUSED2_ENTRIES
+#define M2S_FUSED2_ENTRIES 1024            // entry-stream capacity per wave of the team (x4 bytes x kTeam of LDS)
+#endif
+#ifndef M2S_FUSED2_STAGE
+#define M2S_FUSED2_STAGE 32                // records staged per wave and round (32 = half a strip, 16 = a quarter)
+#endif
 constexpr int kTeam = M2S_TEAM_WAVES;      // waves (= batches of 64 triangles) per workgroup
 constexpr int kTeamThreads = kTeam * 64;
-constexpr uint32_t kEntries = 1024u * kTeam;   // entry stream capacity per workgroup (4 B each)
+constexpr uint32_t kEntries = (uint32_t)M2S_FUSED2_ENTRIES * kTeam;   // entry stream capacity per workgroup (4 B each)
+constexpr int kStageRec = M2S_FUSED2_STAGE;
 constexpr uint32_t kInvalidEntry = 0xFFFFFFFFu;
 constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
 #ifndef M2S_XCD_RUN2
@@ -52,7 +62,7 @@ struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
     uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
-    float4 stage[kTeam][32 * 6];           // half-wave record staging, one per wave
+    float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
     unsigned long long base;               // record index of stream position 0
     unsigned long long total_w[kTeam];     // fragments (all kinds) per batch
     uint32_t total_c[kTeam];               // entries per batch
@@ -98,7 +108,7 @@ __device__ __forceinline__ bool f2_get_base(F2Lds& S, const unsigned long long* 
     return true;
 }
 
-__global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                       unsigned long long limit, float4* __restrict__ out,
                                                       unsigned long long* __restrict__ total_out,
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
@@ -416,16 +426,16 @@ __global__ void __launch_bounds__(kTeamThreads, 3) k_fused2(SceneDev sc, uint32_
                 else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
             }
 #pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                if (have && (lane >> 5) == half) {
+            for (int part = 0; part < 64 / kStageRec; ++part) {
+                if (have && (lane / kStageRec) == part) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) stage[(lane & 31) * 6 + k] = rec[k];
+                    for (int k = 0; k < 6; ++k) stage[(lane % kStageRec) * 6 + k] = rec[k];
                 }
                 wave_lds_sync();
-                float4* __restrict__ dsto = out + (o0 + 32u * half) * 6;
-                const uint32_t nv = nvalid > 32u * half ? min(32u, nvalid - 32u * half) : 0u;
+                float4* __restrict__ dsto = out + (o0 + (uint32_t)kStageRec * part) * 6;
+                const uint32_t nv = nvalid > (uint32_t)kStageRec * part ? min((uint32_t)kStageRec, nvalid - (uint32_t)kStageRec * part) : 0u;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < (kStageRec * 6 + 63) / 64; ++j) {
                     const uint32_t q = (uint32_t)lane + 64u * j;
                     const uint32_t r = q / 6u;
                     if (r < nv) nt_store(&dsto[q], stage[q]);

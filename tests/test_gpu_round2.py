@@ -206,3 +206,29 @@ def test_rccl_exchange_through_the_c_abi_world_1(hiplib, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(merged.cpu().numpy().view(np.uint32), c.download().view(np.uint32))
     ex.close(); c.close()
+
+
+def test_set_records_adopts_device_memory(tmp_path, hiplib):
+    """m2s_set_records: records that live in somebody else's device memory (the merged buffer of a multi-GPU exchange) become a
+    context's current records without a copy — export, download and the depth sort then apply to them."""
+    import torch
+    scene = synth.cube_sphere(16, tex_size=32)
+    a = Converter(0)
+    a.upload_scene(scene)
+    a.convert(160)
+    rec = a.download()
+    want = tmp_path / "want.ply"
+    a.export_ply(str(want), 2, 0.65)
+    merged = torch.from_numpy(rec.copy()).cuda()            # "somebody else's" buffer
+    b = Converter(0)                                         # a context that never converted anything
+    b.set_records(merged.data_ptr(), len(rec), 160)
+    assert b.num_stored == len(rec)
+    assert np.array_equal(b.download().view(np.uint32), rec.view(np.uint32))
+    got = tmp_path / "got.ply"
+    b.export_ply(str(got), 2, 0.65)
+    assert got.read_bytes() == want.read_bytes()
+    view = np.eye(4, dtype=np.float32)
+    view[2, 3] = -3.0
+    assert np.array_equal(b.sort_by_depth(view).view(np.uint32), a.sort_by_depth(view).view(np.uint32))
+    assert b.sort_by_depth(view, download=False) == len(rec)
+    a.close(); b.close()
