@@ -130,7 +130,11 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
             if (lane == src) c = part;
         }
     }
+#ifdef M2S_CS_ABL_NO_SETUP   // timing ablation only (wrong output)
+    if (false) {
+#else
     if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
+#endif
         TriSetup s;
         tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
         s.ts.mesh |= m;
@@ -159,7 +163,11 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     if (wave == 0) {
         const uint32_t b = blockIdx.x;
         if (lane == 0) chain_store(&chain[b], (b == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+#ifdef M2S_CS_ABL_NO_LOOKBACK   // timing ablation only (wrong output)
+        const unsigned long long base = 0ull;
+#else
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
+#endif
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
             base_s = base;
@@ -178,6 +186,9 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     // start[m] = the triangle that owns output record m * kSlice.  A triangle covering many slices (up to 32 768 for a
     // 4096 x 4096 px one) has the whole wave write them.
     const unsigned long long mf = (o0 + kSlice - 1) / kSlice, ml = c ? (o0 + c - 1) / kSlice : 0;
+#ifdef M2S_CS_ABL_NO_START   // timing ablation only (wrong output)
+    if (true) return;
+#endif
     const bool few = valid && c && ml >= mf && (ml - mf) < 16;
     if (few)
         for (unsigned long long mm = mf; mm <= ml && mm < n_start; ++mm) start[mm] = t;

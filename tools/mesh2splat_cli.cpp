@@ -13,10 +13,11 @@
 //   --device d     first HIP device to use                     --timing  per-stage wall clock
 //   --gpus N       one process per GPU (devices d .. d+N-1):
 //                    one file : the triangle list is cut into N fragment-balanced ranges (m2s_dist_shard_ranges), every
-//                               rank converts its range, the counters are exchanged over RCCL (m2s_dist_all_gather_counts)
-//                               and every rank writes ITS rows of the one output file at their final offset
-//                               (m2s_export_ply_slice) — no record leaves its GPU.  --gather: instead, the blocks are
-//                               concatenated on rank 0 over xGMI (m2s_dist_gather_records) and rank 0 writes the file.
+//                               rank converts its range, the N counters are exchanged (8 bytes each: through the shared
+//                               mapping the forked ranks inherit) and every rank writes ITS rows of the one output file at
+//                               their final offset (m2s_export_ply_slice) — no record leaves its GPU, no RCCL needed.
+//                               --gather: instead, the counters go through RCCL (m2s_dist_all_gather_counts) and the blocks
+//                               are concatenated on rank 0 over xGMI (m2s_dist_gather_records), which writes the file.
 //                    --batch  : file k goes to GPU k mod N (independent replicas, no exchange).
 // One GPU, --batch: load(k+1) | upload + convert(k) | export(k-1) overlap (a loader thread, an exporter thread, two
 // contexts used alternately so that file k's records stay intact while file k+1 converts).
@@ -48,6 +49,7 @@ struct Options {
     long max_res = 1024, density = -1, device = 0, cap = -1, format = 0, gpus = 1;
     int pipeline = M2S_PIPELINE_AUTO;
     bool timing = false, gather = false, force_sharded = false;   // force_sharded: the --gpus code path with one rank (tests)
+    bool one_device = false;                                       // tests: every rank on --device (several processes share one GPU)
     uint32_t R() const { return density > 0 ? (uint32_t)density : (uint32_t)(int)(16 + quality * (double)(max_res - 16)); }  // ImGuiUI.cpp:512
 };
 
@@ -115,27 +117,33 @@ struct Shared {
     std::atomic<int> id_ready;
     uint8_t id[M2S_DIST_ID_BYTES];
     std::atomic<int> failed;
+    // the counters of a sharded conversion whose ranks write their own rows: N x 8 bytes through this mapping (the ranks
+    // are forked children of one process on one node); RCCL is only brought up when records have to move (--gather)
+    std::atomic<int> arrived;
+    std::atomic<unsigned long long> counts[64];
 };
 
 int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int rank, int world) {
     const m2s_mesh* meshes = m2s_host_scene_meshes(scene);
     const uint32_t n_meshes = m2s_host_scene_num_meshes(scene);
     const uint32_t R = o.R();
-    const int device = (int)o.device + rank;
+    const int device = (int)o.device + (o.one_device ? 0 : rank);
     auto fail = [&](const char* what, const char* msg) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, what, msg); sh->failed.store(1); return 1; };
     const auto t0 = Clock::now();
     std::vector<uint64_t> first((size_t)world), count((size_t)world);
     if (m2s_dist_shard_ranges(meshes, n_meshes, R, world, first.data(), count.data()) != M2S_OK) return fail("shard_ranges", m2s_dist_last_error(nullptr));
-    if (rank == 0) {
-        if (m2s_dist_unique_id(sh->id) != M2S_OK) return fail("unique_id", m2s_dist_last_error(nullptr));
-        sh->id_ready.store(1);
-    } else {
-        while (!sh->id_ready.load()) { if (sh->failed.load()) return 1; usleep(200); }
-    }
     m2s_ctx* ctx = nullptr;
     if (m2s_create(device, &ctx) != M2S_OK) return fail("create", m2s_last_error(nullptr));
     m2s_dist* d = nullptr;
-    if (m2s_dist_create(device, sh->id, rank, world, &d) != M2S_OK) return fail("dist_create", m2s_dist_last_error(nullptr));
+    if (o.gather) {   // records will move between GPUs: one RCCL communicator per rank, id through the shared mapping
+        if (rank == 0) {
+            if (m2s_dist_unique_id(sh->id) != M2S_OK) return fail("unique_id", m2s_dist_last_error(nullptr));
+            sh->id_ready.store(1);
+        } else {
+            while (!sh->id_ready.load()) { if (sh->failed.load()) return 1; usleep(200); }
+        }
+        if (m2s_dist_create(device, sh->id, rank, world, &d) != M2S_OK) return fail("dist_create", m2s_dist_last_error(nullptr));
+    }
     const auto t1 = Clock::now();
     // the merged scene may exceed the reference's cap envelope: every rank stores all of its records, the global cap is
     // applied to the row ranges below (the merged buffer keeps the first `cap` records in canonical order)
@@ -147,7 +155,14 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     uint64_t total = 0;
     if (m2s_convert(ctx, R, &total) != M2S_OK) return fail("convert", m2s_last_error(ctx));
     std::vector<uint64_t> counts((size_t)world), keep((size_t)world), offs((size_t)world + 1);
-    if (m2s_dist_all_gather_counts(d, total, counts.data(), nullptr) != M2S_OK) return fail("all_gather_counts", m2s_dist_last_error(d));
+    if (d) {
+        if (m2s_dist_all_gather_counts(d, total, counts.data(), nullptr) != M2S_OK) return fail("all_gather_counts", m2s_dist_last_error(d));
+    } else {
+        sh->counts[rank].store(total);
+        sh->arrived.fetch_add(1);
+        while (sh->arrived.load() < world) { if (sh->failed.load()) return 1; usleep(50); }
+        for (int r = 0; r < world; ++r) counts[(size_t)r] = sh->counts[r].load();
+    }
     uint64_t cap = 0;
     if (o.cap > 0) cap = (uint64_t)o.cap;
     else if (o.cap < 0) { const uint32_t mx = R * R * 6u * std::max<uint32_t>(1u, n_meshes); cap = std::min<uint32_t>(mx, 7000000u); }   // ConversionPass.cpp:21-24
@@ -182,10 +197,10 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
                     (unsigned long long)all, (unsigned long long)offs[(size_t)world], o.out.c_str(), o.format,
                     o.gather ? "gathered on rank 0 over RCCL" : "every rank wrote its rows");
     if (o.timing)
-        std::printf("[rank %d] triangles [%llu, +%llu) -> %llu Gaussians | init (HIP + RCCL) %.2f ms | upload %.2f ms | convert + counter exchange %.3f ms | export %.2f ms\n",
-                    rank, (unsigned long long)first[(size_t)rank], (unsigned long long)count[(size_t)rank], (unsigned long long)total, ms_between(t0, t1),
+        std::printf("[rank %d] triangles [%llu, +%llu) -> %llu Gaussians | init (HIP%s) %.2f ms | upload %.2f ms | convert + counter exchange %.3f ms | export %.2f ms\n",
+                    rank, (unsigned long long)first[(size_t)rank], (unsigned long long)count[(size_t)rank], (unsigned long long)total, o.gather ? " + RCCL" : "", ms_between(t0, t1),
                     ms_between(t1, t2), ms_between(t2, t3), ms_between(t3, t4));
-    m2s_dist_destroy(d);
+    if (d) m2s_dist_destroy(d);
     m2s_destroy(ctx);
     return 0;
 }
@@ -213,7 +228,7 @@ int convert_sharded(const Options& o) {
     Shared* sh = (Shared*)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (sh == MAP_FAILED) { std::perror("mmap"); return 1; }
     new (sh) Shared();
-    sh->id_ready.store(0); sh->failed.store(0);
+    sh->id_ready.store(0); sh->failed.store(0); sh->arrived.store(0);
     std::remove(o.out.c_str());
     const int world = (int)o.gpus;
     const int rc = fork_ranks(world, [&](int r) { return rank_main(o, scene, sh, r, world); });
@@ -342,6 +357,7 @@ int main(int argc, char** argv) {
         else if (a == "--gpus") o.gpus = std::atol(next());
         else if (a == "--gather") o.gather = true;
         else if (a == "--force-sharded") o.force_sharded = true;
+        else if (a == "--one-device") o.one_device = true;
         else if (a == "--batch") o.batch_dir = next();
         else if (a == "--out") o.out_dir = next();
         else if (a == "--pipeline") o.pipeline = std::string(next()) == "multipass" ? M2S_PIPELINE_MULTIPASS : M2S_PIPELINE_AUTO;
