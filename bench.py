@@ -61,6 +61,7 @@ def parse():
                          "default so that a rocprofv3 trace of the default command holds only isolated launches)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the C2 / mid-size / C4 lines (and the C4 strong-scaling run at N > 1)")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="N > 1: seconds after which the multi-GPU extras are abandoned and the headline line is printed")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
@@ -496,7 +497,20 @@ def main():
                 t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
             dist.broadcast(t, src=0)
             return bytes(t.cpu().numpy().tobytes())
-        exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
+        try:
+            if os.environ.get("M2S_BENCH_FORCE_TORCH_EXCHANGE"):      # (test hook for the fallback below)
+                raise RuntimeError("forced by M2S_BENCH_FORCE_TORCH_EXCHANGE")
+            exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
+            exchange, ok = None, 0
+        okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:           # on ANY rank: every rank switches, or the collectives would not match
+            if exchange is not None:
+                exchange.close()
+            exchange = m2d.TorchExchange(rank, world)
         # librccl announces itself through C stdio ("Librccl path : ..."); push that out now so that the JSON line
         # stays the LAST line of stdout
         import ctypes
@@ -576,6 +590,82 @@ def main():
         except Exception as e:  # noqa: BLE001 - an extra must not take the headline down
             viewer = {"error": str(e)}
 
+    copy_gbs = None
+    if rank == 0:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dstb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            dstb.copy_(src)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(10):
+            dstb.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * nbytes * 10 / (time.perf_counter() - c0) / 1e9
+        del src, dstb
+
+    res = None
+    if rank == 0:
+        dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
+        kname = {"team": "k_fused2", "wave": "k_fused"}.get(last_pipeline, "k_emit2")
+        emit_ms = kms[dom]
+        # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
+        # (SURVEY.md 8(d): B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
+        b_alg = 96.0 * stored_local + 144.0 * T_local
+        achieved = b_alg / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
+        res = {
+            "metric": "Gaussians/sec emitted (mesh->3DGS conversion pass, density 1024^2)" if R == 1024 else
+                      f"Gaussians/sec emitted (mesh->3DGS conversion pass, density {R}^2)",
+            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"I-4 64 meshes x cube-sphere n=18 ({tri_per_mesh} triangles), 64 materials with 3 procedural "
+                                    f"{tex}^2 RGBA8 maps each, R={R}") if n == "grid" else
+                                   (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
+                                    f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
+                       "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
+                       "rccl_ranks": (dist.get_world_size() if multi else 1),
+                       "exchange": ("per step: 8-byte counter all-gather, two in flight; transport: " + exchange.kind) if multi else "none (single GPU)",
+                       "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
+                       "submission": "one blocking call per step" if a.sync_steps else
+                                     "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
+            "sync_ms_per_step": sync_ms, "sync_ms_stats": sync_stats, "overlapped": overlapped, "viewer_passes": viewer,
+            "kernel_ms": kms,
+            "kernel_timing": f"HIP events on the launch stream around every 4th launch of the timed region ({n_prof} launches)",
+            "kernel_ms_dedicated": {"what": "64 blocking launches after the timed region, HIP events on every one", **dedicated},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "kernel": kname,
+                         "algorithmic_bytes": b_alg, "measured_copy_peak": copy_gbs,
+                         "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
+                         "frac_dedicated_sample": (b_alg / (dedicated[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dedicated[dom] > 0 else None,
+                         "write_only_frac": (96.0 * stored_local / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
+        }
+        tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tr):
+            try:
+                with open(tr) as f:
+                    t = json.load(f)
+                if t.get("workload") == a.workload and t.get(kname + "_hbm_bytes_per_launch"):
+                    res["roofline"]["traffic"] = t.get(kname + "_hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from the committed "
+                                                         "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
+            except Exception:
+                pass
+    # The multi-GPU extras below contain collectives that have never run on more than one GPU by the builder.  Should one of
+    # them hang, every rank leaves after --extras-timeout seconds and rank 0 still prints the (complete) headline line.
+    watchdog = None
+    if multi:
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["multi_gpu_extras"] = f"TIMED OUT after {a.extras_timeout:.0f} s: what had finished by then is in this line"
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(a.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
     # ---- multi-GPU extras: the record exchange of the weak-scaling run, then STRONG scaling of ONE scene --------------
     gather = None
     strong = None
@@ -585,12 +675,12 @@ def main():
         if not a.no_gather:
             merged = torch.empty((max(offs[-1], 1), 24), dtype=torch.float32, device="cuda")
             for _ in range(2):
-                exchange.gather_records(rig.out.data_ptr(), counts, merged.data_ptr(), -1, rig.stream)
+                exchange.gather_records_t(rig.out, counts, merged, -1, rig.stream)
             torch.cuda.synchronize(); dist.barrier()
             g0 = time.perf_counter()
             for _ in range(reps):
                 rig.step_sync()
-                exchange.gather_records(rig.out.data_ptr(), counts, merged.data_ptr(), -1, rig.stream)
+                exchange.gather_records_t(rig.out, counts, merged, -1, rig.stream)
             rig.drain_counts()
             torch.cuda.synchronize(); dist.barrier()
             gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
@@ -600,8 +690,12 @@ def main():
                       "what": "convert + exact-size all-pairs exchange of every rank's block to every rank (m2s_dist_gather_records: one "
                               "RCCL group of ncclSend/ncclRecv at the final offsets of the merged buffer)"}
             del merged
+            if rank == 0:
+                res["gather"] = gather
         rig.close()
         strong = {}
+        if rank == 0:
+            res["strong_scaling"] = strong
         strong_scenes = ["c3"] + ([] if a.no_extra_workloads else ["c4"]) + (["c5p"] if (world == 8 and not a.no_extra_workloads) else [])
         for sname in strong_scenes:
             # every rank takes the same path through this block (collectives inside): an exception is recorded, not raised
@@ -625,12 +719,12 @@ def main():
                                                "keeps its block and knows its offset (what per-rank .ply slice writers need)"}}
                 if not a.no_gather:
                     merged = torch.empty((max(soffs[-1], 1), 24), dtype=torch.float32, device="cuda")
-                    exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
+                    exchange.gather_records_t(srig.out, scounts, merged, -1, srig.stream)
                     torch.cuda.synchronize(); dist.barrier()
                     g0 = time.perf_counter()
                     for _ in range(reps):
                         srig.step_sync()
-                        exchange.gather_records(srig.out.data_ptr(), scounts, merged.data_ptr(), -1, srig.stream)
+                        exchange.gather_records_t(srig.out, scounts, merged, -1, srig.stream)
                     srig.drain_counts()
                     torch.cuda.synchronize(); dist.barrier()
                     gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
@@ -662,72 +756,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 strong[sname] = {"error": repr(e)}
 
-    copy_gbs = None
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        nbytes = 1 << 30
-        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        dstb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        for _ in range(2):
-            dstb.copy_(src)
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        for _ in range(10):
-            dstb.copy_(src)
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * nbytes * 10 / (time.perf_counter() - c0) / 1e9
-        del src, dstb
-
-    if rank == 0:
-        dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        kname = {"team": "k_fused2", "wave": "k_fused"}.get(last_pipeline, "k_emit2")
-        emit_ms = kms[dom]
-        # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
-        # (SURVEY.md 8(d): B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
-        b_alg = 96.0 * stored_local + 144.0 * T_local
-        achieved = b_alg / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
-        res = {
-            "metric": "Gaussians/sec emitted (mesh->3DGS conversion pass, density 1024^2)" if R == 1024 else
-                      f"Gaussians/sec emitted (mesh->3DGS conversion pass, density {R}^2)",
-            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"I-4 64 meshes x cube-sphere n=18 ({tri_per_mesh} triangles), 64 materials with 3 procedural "
-                                    f"{tex}^2 RGBA8 maps each, R={R}") if n == "grid" else
-                                   (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
-                                    f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
-                       "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
-                       "rccl_ranks": (dist.get_world_size() if multi else 1),
-                       "exchange": ("per step: 8-byte counter all-gather through the C ABI (m2s_dist_publish_count / collect_counts: "
-                                    "ncclAllGather on its own stream)") if multi else "none (single GPU)",
-                       "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
-                       "submission": "one blocking call per step" if a.sync_steps else
-                                     "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
-            "sync_ms_per_step": sync_ms, "sync_ms_stats": sync_stats, "overlapped": overlapped, "viewer_passes": viewer,
-            "kernel_ms": kms,
-            "kernel_timing": f"HIP events on the launch stream around every 4th launch of the timed region ({n_prof} launches)",
-            "kernel_ms_dedicated": {"what": "64 blocking launches after the timed region, HIP events on every one", **dedicated},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "kernel": kname,
-                         "algorithmic_bytes": b_alg, "measured_copy_peak": copy_gbs,
-                         "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                         "frac_dedicated_sample": (b_alg / (dedicated[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dedicated[dom] > 0 else None,
-                         "write_only_frac": (96.0 * stored_local / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if emit_ms > 0 else 0.0},
-        }
-        tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tr):
-            try:
-                with open(tr) as f:
-                    t = json.load(f)
-                if t.get("workload") == a.workload and t.get(kname + "_hbm_bytes_per_launch"):
-                    res["roofline"]["traffic"] = t.get(kname + "_hbm_bytes_per_launch")
-                    res["roofline"]["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from the committed "
-                                                         "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
-            except Exception:
-                pass
-        if gather:
-            res["gather"] = gather
-        if strong:
-            res["strong_scaling"] = strong
         if not multi:
             one = scene if n == "grid" else synth.colocated_spheres(1, n, tex)
             if not a.no_cold:

@@ -634,6 +634,7 @@ static m2s_status ensure_records(m2s_ctx* c, uint64_t want) {
     if (c->records_cap) grow = std::max(grow, 2 * c->records_cap);
     if (c->cap_policy < 0) grow = std::max(want, std::min<uint64_t>(grow, kMaxGaussiansToSort));
     drain_in_flight(c);   // nothing may still be writing the buffer that is about to be released
+    if (c->d_records && c->last_records == c->d_records) { c->last_records = nullptr; c->last_stored = 0; }   // they go with the old pool
     if (c->d_records) { (void)hipFree(c->d_records); c->d_records = nullptr; c->records_cap = 0; }
     hipError_t e = hipMalloc(&c->d_records, grow * sizeof(m2s_gaussian));
     if (e != hipSuccess && grow > want) { grow = want; e = hipMalloc(&c->d_records, grow * sizeof(m2s_gaussian)); }

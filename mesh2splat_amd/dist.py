@@ -132,6 +132,67 @@ class RcclExchange:
                                                     int(root), self._C.c_void_p(stream or None)))
 
 
+    def gather_records_t(self, mine, counts: Sequence[int], merged, root: int = -1, stream: int = 0):
+        """Tensor form (what bench.py calls, so that the torch.distributed stand-in below is interchangeable)."""
+        self.gather_records(mine.data_ptr(), counts, merged.data_ptr() if merged is not None else 0, root, stream)
+
+    kind = "C ABI (m2s_dist_*: RCCL opened by libm2s_hip.so)"
+
+
+class TorchExchange:
+    """The same exchange through torch.distributed (backend nccl = RCCL).  NOT the product path: bench.py falls back to it when
+    the C-ABI communicator cannot be created on some rank (so that a scaling run still yields its line), and says so."""
+
+    kind = "torch.distributed fallback (the C-ABI communicator could not be created)"
+
+    def __init__(self, rank: int, world: int, device: str = "cuda"):
+        import collections
+        import torch
+        self.rank, self.world, self.device = int(rank), int(world), device
+        self._torch = torch
+        self._pending = collections.deque()
+
+    def close(self):
+        pass
+
+    def all_gather_counts(self, total: int):
+        while self._pending:
+            self.collect_counts()
+        self.publish_count(total)
+        return self.collect_counts()
+
+    def publish_count(self, total: int):
+        import torch.distributed as dist
+        torch = self._torch
+        mine = torch.tensor([int(total)], dtype=torch.int64, device=self.device)
+        allc = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        self._pending.append((dist.all_gather_into_tensor(allc, mine, async_op=True), allc, mine))
+
+    def collect_counts(self):
+        work, allc, _ = self._pending.popleft()
+        work.wait()
+        counts = [int(x) for x in allc.tolist()]
+        return counts, offsets_from_counts(counts)
+
+    def gather_records_t(self, mine, counts: Sequence[int], merged, root: int = -1, stream: int = 0):
+        import torch.distributed as dist
+        off = offsets_from_counts(counts)
+        me, W = self.rank, self.world
+        receives = root < 0 or root == me
+        if receives and counts[me]:
+            merged[off[me]: off[me + 1]].copy_(mine[: counts[me]])
+        ops = []
+        for step in range(1, W):
+            dst, src = (me + step) % W, (me - step) % W
+            if counts[me] and (root < 0 or root == dst):
+                ops.append(dist.P2POp(dist.isend, mine[: counts[me]], dst))
+            if counts[src] and receives:
+                ops.append(dist.P2POp(dist.irecv, merged[off[src]: off[src + 1]], src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
 def even_ranges(T: int, world: int) -> List[Tuple[int, int]]:
     cuts = [T * r // world for r in range(world + 1)]
     return [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]

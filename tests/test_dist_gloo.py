@@ -134,3 +134,44 @@ def test_sample_sort_equals_single_stable_sort(tmp_path, world, case):
     assert keys.dtype == np.int64 and (keys >= 0).all() and (keys < 2 ** 32).all()
     z = ((rec[:, 0] * np.float32(0) + rec[:, 1] * np.float32(0)) + rec[:, 2] * np.float32(1)) + np.float32(-3.0)
     assert np.array_equal(keys, z.astype(np.float32).view(np.uint32).astype(np.int64))
+
+
+def _exchange_worker(rank, world, port, R, result_dir):
+    """bench.py's stand-in exchange (mesh2splat_amd.dist.TorchExchange: same schedule as m2s_dist_gather_records — every rank
+    sends its block to rank + step and receives from rank - step, exact sizes, final offsets) on CPU tensors."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        scene = synth.sphere_grid(2, n=4, tex_size=16)
+        first, count = m2d.shard_ranges_native(scene, R, world)[rank]
+        total, rec, _ = oracle.convert(scene, R, cap=0, tri_first=first, tri_count=count)
+        ex = m2d.TorchExchange(rank, world, device="cpu")
+        for k in range(3):                                   # pipelined counter exchanges complete in order
+            ex.publish_count(total + k)
+        got = [ex.collect_counts()[0][rank] for _ in range(3)]
+        assert got == [total, total + 1, total + 2]
+        counts, offs = ex.all_gather_counts(total)
+        assert counts[rank] == total and offs[-1] == sum(counts)
+        mine = torch.from_numpy(rec)
+        merged = torch.zeros((offs[-1], 24), dtype=torch.float32)
+        ex.gather_records_t(mine, counts, merged, -1)
+        np.save(os.path.join(result_dir, f"ex_all_{rank}.npy"), merged.numpy())
+        root_buf = torch.zeros((offs[-1], 24), dtype=torch.float32) if rank == 1 else None
+        ex.gather_records_t(mine, counts, root_buf, 1)        # to one root only
+        if rank == 1:
+            np.save(os.path.join(result_dir, "ex_root.npy"), root_buf.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_schedule_all_pairs_and_to_root(tmp_path, oracle, world):
+    R = 64
+    mp.spawn(_exchange_worker, args=(world, _free_port(), R, str(tmp_path)), nprocs=world, join=True)
+    scene = synth.sphere_grid(2, n=4, tex_size=16)
+    total, full, _ = oracle.convert(scene, R, cap=0)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"ex_all_{r}.npy").view(np.uint32), full.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "ex_root.npy").view(np.uint32), full.view(np.uint32))
