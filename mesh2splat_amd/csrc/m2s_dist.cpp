@@ -21,7 +21,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -94,6 +98,16 @@ struct m2s_dist {
     hipEvent_t done[kRing] = {};
     uint64_t published = 0, collected = 0;
     std::string err;
+    // The four runtime calls of one counter exchange (H2D, ncclAllGather, D2H, event) cost ~10 us of host time: too much to sit
+    // in the thread that submits 0.13 ms conversions back to back.  m2s_dist_publish_count only queues the value; this worker
+    // issues the calls.  Every use of the communicator (worker, m2s_dist_gather_records) holds comm_lock.
+    std::thread worker;
+    std::mutex q_lock, comm_lock;
+    std::condition_variable q_cv, issued_cv;
+    std::deque<std::pair<uint64_t, unsigned long long>> queue;   // (exchange number, value)
+    uint64_t issued = 0;                       // exchanges whose calls have been issued (guarded by q_lock)
+    bool stop = false;
+    std::string worker_err;                    // first failure inside the worker (guarded by q_lock)
 };
 
 #define DCHK(d, call)                                                                      \
@@ -109,6 +123,41 @@ struct m2s_dist {
             return M2S_ERR_HIP;                                                            \
         }                                                                                  \
     } while (0)
+
+// issues the runtime calls of queued counter exchanges, in order
+static void dist_worker(m2s_dist* d) {
+    (void)hipSetDevice(d->device);
+    for (;;) {
+        std::pair<uint64_t, unsigned long long> job;
+        {
+            std::unique_lock<std::mutex> l(d->q_lock);
+            d->q_cv.wait(l, [&] { return d->stop || !d->queue.empty(); });
+            if (d->queue.empty()) return;       // stop requested and nothing left
+            job = d->queue.front();
+            d->queue.pop_front();
+        }
+        const int k = (int)(job.first % kRing);
+        std::string err;
+        {
+            std::lock_guard<std::mutex> c(d->comm_lock);
+            d->h_mine[k] = job.second;
+            hipError_t e = hipMemcpyAsync(d->d_mine + k, d->h_mine + k, 8, hipMemcpyHostToDevice, d->stream);
+            int r = kNcclSuccess;
+            if (e == hipSuccess) r = g_rccl.AllGather(d->d_mine + k, d->d_all + (size_t)k * d->world, 1, kNcclUint64, d->comm, d->stream);
+            if (e == hipSuccess && r == kNcclSuccess)
+                e = hipMemcpyAsync(d->h_all + (size_t)k * d->world, d->d_all + (size_t)k * d->world, (size_t)d->world * 8, hipMemcpyDeviceToHost, d->stream);
+            if (e == hipSuccess && r == kNcclSuccess) e = hipEventRecord(d->done[k], d->stream);
+            if (r != kNcclSuccess) err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+            else if (e != hipSuccess) err = std::string("counter exchange: ") + hipGetErrorString(e);
+        }
+        {
+            std::lock_guard<std::mutex> l(d->q_lock);
+            if (!err.empty() && d->worker_err.empty()) d->worker_err = err;
+            d->issued = job.first + 1;
+        }
+        d->issued_cv.notify_all();
+    }
+}
 
 extern "C" {
 
@@ -149,12 +198,18 @@ m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int 
     }
     for (auto& ev : d->done)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { d->err = std::string("hipEventCreate: ") + hipGetErrorString(e); return bail(M2S_ERR_HIP); }
+    try { d->worker = std::thread(dist_worker, d); } catch (...) { d->err = "could not start the exchange thread"; return bail(M2S_ERR_OOM); }
     *out = d;
     return M2S_OK;
 }
 
 void m2s_dist_destroy(m2s_dist* d) {
     if (!d) return;
+    if (d->worker.joinable()) {
+        { std::lock_guard<std::mutex> l(d->q_lock); d->stop = true; }
+        d->q_cv.notify_all();
+        d->worker.join();
+    }
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
@@ -170,17 +225,17 @@ void m2s_dist_destroy(m2s_dist* d) {
 int m2s_dist_rank(const m2s_dist* d) { return d ? d->rank : -1; }
 int m2s_dist_world(const m2s_dist* d) { return d ? d->world : 0; }
 
-// Starts the exchange of this rank's counter for one conversion; returns at once.  Exchanges complete in order.
+// Starts the exchange of this rank's counter for one conversion; returns at once (the value is queued for the exchange
+// thread).  Exchanges complete in order.
 m2s_status m2s_dist_publish_count(m2s_dist* d, uint64_t my_total) {
     if (!d) return M2S_ERR_INVALID;
     if (d->published - d->collected >= (uint64_t)kRing) { d->err = "too many counter exchanges in flight: m2s_dist_collect_counts first"; return M2S_ERR_STATE; }
-    DCHK(d, hipSetDevice(d->device));
-    const int k = (int)(d->published % kRing);
-    d->h_mine[k] = my_total;
-    DCHK(d, hipMemcpyAsync(d->d_mine + k, d->h_mine + k, 8, hipMemcpyHostToDevice, d->stream));
-    NCHK(d, g_rccl.AllGather(d->d_mine + k, d->d_all + (size_t)k * d->world, 1, kNcclUint64, d->comm, d->stream));
-    DCHK(d, hipMemcpyAsync(d->h_all + (size_t)k * d->world, d->d_all + (size_t)k * d->world, (size_t)d->world * 8, hipMemcpyDeviceToHost, d->stream));
-    DCHK(d, hipEventRecord(d->done[k], d->stream));
+    {
+        std::lock_guard<std::mutex> l(d->q_lock);
+        if (!d->worker_err.empty()) { d->err = d->worker_err; return M2S_ERR_HIP; }
+        d->queue.emplace_back(d->published, (unsigned long long)my_total);
+    }
+    d->q_cv.notify_one();
     ++d->published;
     return M2S_OK;
 }
@@ -190,6 +245,11 @@ m2s_status m2s_dist_publish_count(m2s_dist* d, uint64_t my_total) {
 m2s_status m2s_dist_collect_counts(m2s_dist* d, uint64_t* counts, uint64_t* offsets) {
     if (!d || !counts) return M2S_ERR_INVALID;
     if (d->collected == d->published) { d->err = "no counter exchange in flight"; return M2S_ERR_STATE; }
+    {
+        std::unique_lock<std::mutex> l(d->q_lock);
+        d->issued_cv.wait(l, [&] { return d->issued > d->collected; });     // its calls have been issued
+        if (!d->worker_err.empty()) { d->err = d->worker_err; ++d->collected; return M2S_ERR_HIP; }
+    }
     DCHK(d, hipSetDevice(d->device));
     const int k = (int)(d->collected % kRing);
     DCHK(d, hipEventSynchronize(d->done[k]));
@@ -296,6 +356,13 @@ m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64
         DCHK(d, hipMemcpyAsync(merged + off[me] * rec, d_mine, counts[me] * rec, hipMemcpyDeviceToDevice, st));
     if (W == 1) return M2S_OK;
     // message sizes are in bytes (ncclUint8); a block beyond 2^31 records still fits size_t
+    // Operations on a communicator must be issued in the same order on every rank: first let the exchange thread issue every
+    // counter exchange published so far (program order on each rank), then the record exchange.
+    {
+        std::unique_lock<std::mutex> l(d->q_lock);
+        d->issued_cv.wait(l, [&] { return d->issued == d->published; });
+    }
+    std::lock_guard<std::mutex> comm_guard(d->comm_lock);
     NCHK(d, g_rccl.GroupStart());
     for (int step = 1; step < W; ++step) {
         const int dst = (me + step) % W, src = (me - step + W) % W;
