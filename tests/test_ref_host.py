@@ -210,7 +210,7 @@ def test_image_uris_match_reference_live(tmp_path, hiplib):
 
 
 # ---- glTF features that real assets (SciFiHelmet, Sponza) carry and the synthetic writer does not produce ------------
-def _rewrite_glb_json(src, dst, edit):
+def _edit_glb(src, dst, edit):
     """Re-pack a .glb with its JSON chunk edited by `edit(doc, bin_bytes) -> bin_bytes`."""
     import json
     import struct
@@ -306,5 +306,5 @@ def test_loader_matches_reference_on_real_asset_features(tmp_path, hiplib, featu
     base = str(tmp_path / "base.glb")
     gltf_io.write_glb(synth.sphere_grid(2, n=3, tex_size=16), base)
     glb = str(tmp_path / (name + ".glb"))
-    _rewrite_glb_json(base, glb, edit)
+    _edit_glb(base, glb, edit)
     assert_scene_equal(refhost.load_scene(glb, str(tmp_path)), gltf_io.load_glb(glb))
