@@ -662,7 +662,8 @@ __device__ __forceinline__ ConstMeshPtr kConstMesh(const MeshParams* p) { return
 
 template <class MP>
 __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, MP mp,
-                                               const TriShade& ts, float4 rec[6], unsigned long long* stamps = nullptr) {
+                                               const TriShade& ts, float4 rec[6], unsigned long long* stamps = nullptr,
+                                               const float2* uvl = nullptr /* (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0) kept by the caller */) {
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
     const int dx256 = (x - (int)(ts.org & 0xFFFu)) * 256, dy256 = (y - (int)(ts.org >> 12)) * 256;
@@ -683,8 +684,12 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     const float4 a0 = make_float4(ts.inva, 1, 2, 3), a1 = a0, b0 = make_float4(0.1f, 0.2f, 0.3f, ts.inva), c0 = a0, c1 = a0, d0 = a0, d1 = a0, d2 = a0;
     const float a2 = 1, c2 = 2; const float2 b1 = make_float2(0.5f, 0.7f);
 #else
-    const float4 b0 = ld_plane(tp.B0, t);
-    const float2 b1 = ld_plane(tp.B1, t);
+    float4 b0 = make_float4(0, 0, 0, 0);
+    float2 b1 = make_float2(0, 0);
+    if (uvl == nullptr) {
+        b0 = ld_plane(tp.B0, t);
+        b1 = ld_plane(tp.B1, t);
+    }
 #ifndef M2S_LATE_ATTR
     const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
     const float a2 = ld_plane(tp.A2, t);
@@ -696,8 +701,14 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     float U, V;
     {   // texture coordinates: exact oracle sequence (no FMA), see tri_shade_setup
 #pragma clang fp contract(off)
-        U = (b0.x + l1 * (b0.z - b0.x)) + l2 * (b1.x - b0.x);
-        V = (b0.y + l1 * (b0.w - b0.y)) + l2 * (b1.y - b0.y);
+        if (uvl != nullptr) {   // the same three roundings per coordinate: the differences were formed by the same subtraction
+            const float2 q0 = uvl[0], q1 = uvl[1], q2 = uvl[2];
+            U = (q0.x + l1 * q1.x) + l2 * q2.x;
+            V = (q0.y + l1 * q1.y) + l2 * q2.y;
+        } else {
+            U = (b0.x + l1 * (b0.z - b0.x)) + l2 * (b1.x - b0.x);
+            V = (b0.y + l1 * (b0.w - b0.y)) + l2 * (b1.y - b0.y);
+        }
     }
 #define M2S_LERP(f0, f1, f2) fma_(l2, (f2) - (f0), fma_(l1, (f1) - (f0), (f0)))
 

@@ -61,6 +61,9 @@ __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
+#ifdef M2S_FUSED2_LDS_UV
+    float2 uv[kTeam][64 * 3];              // per triangle: (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0): texture coordinates without a global round trip
+#endif
     uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
     float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
     unsigned long long base;               // record index of stream position 0
@@ -302,6 +305,11 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
 #pragma unroll
             for (int k = 0; k < 5; ++k) S.tri[wave][lane * 5 + k] = src[k];
             S.tskip[wave][lane] = (uint32_t)((out0 + toff) - ((unsigned long long)stream0 + ctoff));
+#ifdef M2S_FUSED2_LDS_UV
+            S.uv[wave][lane * 3 + 0] = make_float2(uvb0.x, uvb0.y);
+            S.uv[wave][lane * 3 + 1] = make_float2(uvb0.z - uvb0.x, uvb0.w - uvb0.y);
+            S.uv[wave][lane * 3 + 2] = make_float2(uvb1.x - uvb0.x, uvb1.y - uvb0.y);
+#endif
         }
         if (anybig) {   // deferred triangles: reserve their slice of the output, list them for k_emit_big
             unsigned long long base;
@@ -409,8 +417,13 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             const uint32_t tt = (b0 + ow) * tpw + tl;
             skip = S.tskip[ow][tl];
             // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
-            if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
-            else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
+#ifdef M2S_FUSED2_LDS_UV
+            const float2* uvl = &S.uv[ow][tl * 3];
+#else
+            const float2* uvl = nullptr;
+#endif
+            if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec, nullptr, uvl);
+            else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec, nullptr, uvl);
         }
         if (!have_base) {
             const unsigned long long tb0 = F2_NOW();
