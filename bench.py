@@ -696,7 +696,7 @@ def main():
         strong = {}
         if rank == 0:
             res["strong_scaling"] = strong
-        strong_scenes = ["c3"] + ([] if a.no_extra_workloads else ["c4"]) + (["c5p"] if (world == 8 and not a.no_extra_workloads) else [])
+        strong_scenes = ["c3"] + ([] if a.no_extra_workloads else ["c4"]) + (["c5p"] if ((world == 8 or os.environ.get("M2S_BENCH_FORCE_C5P")) and not a.no_extra_workloads) else [])
         for sname in strong_scenes:
             # every rank takes the same path through this block (collectives inside): an exception is recorded, not raised
             try:
@@ -704,7 +704,7 @@ def main():
                     # BASELINE config 5 at 1/8 of its triangle count (the full 50 M-triangle scene is 7.2 GB of vertices per rank to
                     # generate on the host): 4 meshes x cube-sphere n=361 = 6.25 M triangles, 4096^2 maps, R = 2048, cap lifted,
                     # + the depth sort of the MERGED buffer (m2s_set_records + m2s_sort_by_depth on every rank)
-                    one, sR = synth.sphere_row(4, 361, 4096), 2048
+                    one, sR = synth.sphere_row(4, int(os.environ.get("M2S_BENCH_C5P_N", "361")), int(os.environ.get("M2S_BENCH_C5P_TEX", "4096"))), 2048   # (env: test hooks)
                 else:
                     sn, stex, sR = WORKLOADS[sname]
                     one = synth.sphere_grid(4, n=18, tex_size=stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
@@ -750,6 +750,35 @@ def main():
                         entry["merged_depth_sort"] = {"records": int(nsort), "ms": float(np.median(sms)),
                                                       "what": "m2s_set_records(merged) + m2s_sort_by_depth: key build + radix sort + 96-byte gather, on every rank"}
                         sink.close()
+                        # the same sort WITHOUT merging on one GPU: sample sort across the ranks behind the C ABI (one exact-size record
+                        # exchange; every rank ends with its slice of the global order).  Checked against the merged buffer: same
+                        # multiset (checksum), sorted inside every slice, slices ordered across ranks.
+                        if hasattr(exchange, "sort_by_depth"):
+                            try:
+                                srig.drain_counts()
+                                torch.cuda.synchronize(); dist.barrier()
+                                d0 = time.perf_counter()
+                                dn, doff = exchange.sort_by_depth(srig.conv, view)
+                                ddt = torch.tensor([time.perf_counter() - d0], dtype=torch.float64, device="cuda")
+                                dist.all_reduce(ddt, op=dist.ReduceOp.MAX)
+                                sl = torch.from_numpy(srig.conv.download_sorted()).cuda() if dn else torch.zeros((0, 24), dtype=torch.float32, device="cuda")
+                                z = (sl[:, 2] + torch.tensor(-6.0, device="cuda")).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF   # key = bits of view-space z
+                                edge = torch.tensor([int(z[0].item()) if dn else -1, int(z[-1].item()) if dn else -1,
+                                                     int(sl.view(torch.int32).to(torch.int64).sum().item()), dn,
+                                                     int(bool((z[1:] >= z[:-1]).all().item())) if dn > 1 else 1], dtype=torch.int64, device="cuda")
+                                edges = [torch.zeros_like(edge) for _ in range(world)]
+                                dist.all_gather(edges, edge)
+                                E = [[int(v) for v in e.tolist()] for e in edges]
+                                nonempty = [e for e in E if e[3] > 0]
+                                entry["distributed_depth_sort"] = {
+                                    "ms": float(ddt.item()) * 1e3, "per_rank_records": [e[3] for e in E],
+                                    "same_multiset_as_merged": sum(e[2] for e in E) == int(chk.item()),
+                                    "sorted_inside_slices": all(e[4] == 1 for e in E),
+                                    "slices_ordered": all(nonempty[i][1] <= nonempty[i + 1][0] for i in range(len(nonempty) - 1)),
+                                    "what": "m2s_dist_sort_by_depth: local sort, 256 samples per rank, splitters, one all-pairs exchange of exact sizes, "
+                                            "local sort of what arrived; wall time of one call, max over ranks"}
+                            except Exception as e:  # noqa: BLE001
+                                entry["distributed_depth_sort"] = {"error": repr(e)}
                     del merged
                 strong[sname] = entry
                 srig.close()

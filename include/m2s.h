@@ -188,6 +188,11 @@ typedef struct m2s_dist m2s_dist;
 m2s_status m2s_dist_unique_id(uint8_t out_id[M2S_DIST_ID_BYTES]);
 /* Collective over all ranks (== ncclCommInitRank) on HIP device `device`. */
 m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int rank, int world, m2s_dist** out);
+/* The same exchange with the ranks as THREADS of one process (the shape of the reference: one executable), one context and
+ * one GPU each; no RCCL involved: counts go through a table of the group, records through hipMemcpyPeerAsync (the same xGMI
+ * links).  The id of a new group of `world` ranks; every rank then calls m2s_dist_create with it, every m2s_dist_* call
+ * below works unchanged, and the group is released by its last m2s_dist_destroy. */
+m2s_status m2s_dist_local_id(int world, uint8_t out_id[M2S_DIST_ID_BYTES]);
 void m2s_dist_destroy(m2s_dist* d);
 int m2s_dist_rank(const m2s_dist* d);
 int m2s_dist_world(const m2s_dist* d);
@@ -210,6 +215,14 @@ void m2s_dist_clamp_to_cap(const uint64_t* counts, int world, uint64_t cap, uint
  * d_merged on every rank (root < 0) or on `root` only (d_merged may be NULL elsewhere).  Device pointers; enqueued on
  * hip_stream (the stream the conversion ran on); returns without waiting for it. */
 m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64_t* counts, void* d_merged, int root, void* hip_stream);
+/* Depth sort (== m2s_sort_by_depth == RadixSortPass.cpp:8-90) of records spread over the ranks — BASELINE config 5's "final
+ * radix sort of the merged splat buffer" without merging it on one GPU: sample sort with one exact-size record exchange.
+ * Collective.  In: every rank's context holds its block (its last conversion, or m2s_set_records).  Out: the context's sorted
+ * buffer (m2s_device_sorted_records, m2s_download_sorted) holds this rank's contiguous slice of the globally sorted sequence —
+ * *out_n records starting at position *out_offset; the slices in rank order are bit-identical to one GPU sorting the
+ * rank-major concatenation (stable: ties keep rank, then original position).  The context's current records become the
+ * received, not yet sorted ones. */
+m2s_status m2s_dist_sort_by_depth(m2s_dist* d, m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n, uint64_t* out_offset);
 /* Blocks until everything enqueued on hip_stream (the record exchange) has completed. */
 m2s_status m2s_dist_wait(m2s_dist* d, void* hip_stream);
 
@@ -220,6 +233,9 @@ m2s_status m2s_dist_wait(m2s_dist* d, void* hip_stream);
  * *out_n = number of records sorted. */
 m2s_status m2s_sort_by_depth(m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n);
 const void* m2s_device_sorted_records(const m2s_ctx* ctx);
+const void* m2s_device_sorted_keys(const m2s_ctx* ctx);      /* uint32[n], ascending: the keys of those records */
+uint64_t m2s_num_sorted(const m2s_ctx* ctx);
+uint32_t m2s_last_resolution(const m2s_ctx* ctx);            /* R of the current records (0: none / uploaded records) */
 m2s_status m2s_download_sorted(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacity_records);
 /* Duration (ms) of the last profiled sort (key build + radix sort + gather). */
 float m2s_last_sort_ms(const m2s_ctx* ctx);

@@ -33,6 +33,7 @@ EXPORTS = (
     "m2s_dist_unique_id", "m2s_dist_create", "m2s_dist_destroy", "m2s_dist_rank", "m2s_dist_world", "m2s_dist_last_error",
     "m2s_dist_shard_ranges", "m2s_dist_all_gather_counts", "m2s_dist_publish_count", "m2s_dist_collect_counts",
     "m2s_dist_clamp_to_cap", "m2s_dist_gather_records", "m2s_dist_wait", "m2s_set_records", "m2s_reserve_records", "m2s_prepare",
+    "m2s_dist_local_id", "m2s_dist_sort_by_depth", "m2s_device_sorted_keys", "m2s_num_sorted", "m2s_last_resolution",
 )
 
 
@@ -166,6 +167,11 @@ def load():
         "m2s_set_records": (C.c_int, [vp, vp, u64, u32]),
         "m2s_reserve_records": (C.c_int, [vp, u64, C.POINTER(vp)]),
         "m2s_prepare": (C.c_int, [vp, u32]),
+        "m2s_dist_local_id": (C.c_int, [C.c_int, vp]),
+        "m2s_dist_sort_by_depth": (C.c_int, [vp, vp, C.POINTER(C.c_float), C.POINTER(u64), C.POINTER(u64)]),
+        "m2s_device_sorted_keys": (vp, [vp]),
+        "m2s_num_sorted": (u64, [vp]),
+        "m2s_last_resolution": (u32, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

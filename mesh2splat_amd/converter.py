@@ -178,6 +178,14 @@ class Converter:
         self._check(self._L.m2s_download_sorted(self._h, out.ctypes.data, n.value))
         return out
 
+    def download_sorted(self) -> np.ndarray:
+        """The context's sorted buffer (after sort_by_depth(download=False) or RcclExchange.sort_by_depth)."""
+        n = int(self._L.m2s_num_sorted(self._h))
+        out = np.empty((n, RECORD_FLOATS), np.float32)
+        if n:
+            self._check(self._L.m2s_download_sorted(self._h, out.ctypes.data, n))
+        return out
+
     @property
     def last_sort_ms(self) -> float:
         return float(self._L.m2s_last_sort_ms(self._h))

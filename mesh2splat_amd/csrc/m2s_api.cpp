@@ -734,6 +734,10 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
 
     if (sc.n_tri == 0) {
         c->last_total = c->last_stored = 0;
+        if (!d_user && !c->d_records) {   // (an empty shard is a conversion like any other: its consumers see zero records, not "no conversion")
+            const m2s_status s = ensure_records(c, 1);
+            if (s != M2S_OK) return s;
+        }
         c->last_records = d_user ? d_user : c->d_records;
         if (out_total) *out_total = 0;
         return M2S_OK;
@@ -1202,6 +1206,10 @@ m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t
 }
 
 const void* m2s_device_sorted_records(const m2s_ctx* c) { return c && c->sorted_n ? c->d_sorted : nullptr; }
+// the keys of those records (uint32, ascending): keys_out of the radix sort
+const void* m2s_device_sorted_keys(const m2s_ctx* c) { return c && c->sorted_n ? c->d_sort_u32 + 2 * c->sorted_n : nullptr; }
+uint64_t m2s_num_sorted(const m2s_ctx* c) { return c ? c->sorted_n : 0; }
+uint32_t m2s_last_resolution(const m2s_ctx* c) { return c ? c->last_R : 0; }
 
 m2s_status m2s_download_sorted(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_records) {
     if (!c) return M2S_ERR_INVALID;

@@ -145,6 +145,10 @@ size_t sort_temp_bytes(uint32_t n);
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                          uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st);
 
+// sample sort across ranks (m2s_dist.cpp): evenly spaced samples of sorted keys; split points of sorted keys
+void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st);
+void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long long* splitters, uint32_t m, unsigned long long* out, hipStream_t st);
+
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
 // fused kernel: triangles per wave.  64 as soon as that fills the GPU's 3072 wave slots once.  A smaller scene gets just
 // enough triangles per wave to occupy every slot ONCE (one round of waves instead of two: the C2 stand-in, 69 312

@@ -13,6 +13,12 @@
 // A consumer that writes files does not need the records on one GPU at all: see m2s_export_ply_slice (each rank writes its
 // rows at the right byte offset of one .ply).
 //
+// Two transports behind the same entry points: RCCL (one PROCESS per GPU: the id comes from m2s_dist_unique_id) and an
+// in-process one (one THREAD per GPU inside one process — the shape of the reference, a single executable: the id comes from
+// m2s_dist_local_id; all-gathers go through the group's shared table, record transfers are hipMemcpyPeerAsync, which takes
+// the same xGMI links).  Everything above the transport — shard plan, counter exchange, record exchange, the sample sort
+// of m2s_dist_sort_by_depth — is the same code for both.
+//
 // librccl is opened at run time (dlopen), not linked: a Python process that already carries PyTorch's bundled RCCL must
 // not end up with a second copy, and single-GPU users of libm2s_hip.so need no RCCL at all.
 #include "../../include/m2s.h"
@@ -22,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -31,6 +38,11 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+namespace m2s {   // m2s_sort.hip
+void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st);
+void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long long* splitters, uint32_t m, unsigned long long* out, hipStream_t st);
+}
 
 namespace {
 
@@ -84,13 +96,54 @@ bool rccl_ready() {
 }
 
 constexpr int kRing = 8;   // counter exchanges in flight
+constexpr uint32_t kSortSamples = 256;   // samples per rank for the splitters of m2s_dist_sort_by_depth
+
+// ---- the in-process transport: the ranks are threads of this process ----
+struct LocalGroup {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0, joined = 0, left = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    struct Post { const void* ptr = nullptr; int device = 0; size_t bytes = 0; };
+    std::vector<Post> gathered;                    // all-gather: what every rank contributes
+    struct Send { int dst = 0; const void* ptr = nullptr; size_t bytes = 0; int device = 0; };
+    std::vector<std::vector<Send>> sends;          // record exchange: what every rank sends, in its own order
+};
+constexpr char kLocalMagic[8] = { 'M', '2', 'S', 'L', 'O', 'C', 'A', 'L' };
+constexpr int kLocalBarrierSeconds = 120;
+
+// all ranks of the group; false if one of them never arrives (the group is then unusable for everybody)
+bool local_barrier(LocalGroup* g) {
+    std::unique_lock<std::mutex> l(g->m);
+    if (g->broken) return false;
+    const uint64_t gen = g->generation;
+    if (++g->arrived == g->world) {
+        g->arrived = 0;
+        ++g->generation;
+        g->cv.notify_all();
+        return true;
+    }
+    if (!g->cv.wait_for(l, std::chrono::seconds(kLocalBarrierSeconds), [&] { return g->generation != gen || g->broken; })) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return !g->broken;
+}
+
+struct Xfer { int peer; void* ptr; size_t bytes; };   // one message of a record exchange
 
 }  // namespace
 
 struct m2s_dist {
     int device = 0, rank = 0, world = 1;
-    ncclComm_p comm = nullptr;
+    ncclComm_p comm = nullptr;                 // RCCL transport ...
+    LocalGroup* local = nullptr;               // ... or the in-process one
     hipStream_t stream = nullptr;              // counter exchanges run here, off the conversion stream
+    unsigned long long* d_sort = nullptr;      // m2s_dist_sort_by_depth: samples | all samples | splitters, bounds | send counts | matrix
+    unsigned long long* h_sort = nullptr;      // pinned mirror
     unsigned long long* d_mine = nullptr;      // [kRing]
     unsigned long long* d_all = nullptr;       // [kRing][world]
     unsigned long long* h_mine = nullptr;      // pinned [kRing]
@@ -124,6 +177,84 @@ struct m2s_dist {
         }                                                                                  \
     } while (0)
 
+// ---- transport: all-gather of 64-bit words, exchange of byte ranges (both on device memory) ----
+#define TH(call)                                                                           \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return M2S_ERR_HIP; } \
+    } while (0)
+#define TN(call)                                                                           \
+    do {                                                                                   \
+        int r_ = (call);                                                                   \
+        if (r_ != kNcclSuccess) {                                                          \
+            err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error"); \
+            return M2S_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+// RCCL: enqueued on `st`, returns at once.  In-process: completed when it returns.
+// (errors go to `err`, not to d->err: the exchange thread calls these too)
+static m2s_status t_all_gather(m2s_dist* d, const unsigned long long* d_send, unsigned long long* d_recv, size_t count, hipStream_t st, std::string& err) {
+    if (!d->local) {
+        TN(g_rccl.AllGather(d_send, d_recv, count, kNcclUint64, d->comm, st));
+        return M2S_OK;
+    }
+    LocalGroup* g = d->local;
+    TH(hipStreamSynchronize(st));          // what I contribute is complete
+    {
+        std::lock_guard<std::mutex> l(g->m);
+        g->gathered[(size_t)d->rank] = LocalGroup::Post{ d_send, d->device, count * sizeof(unsigned long long) };
+    }
+    if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }
+    for (int r = 0; r < d->world; ++r) {
+        const LocalGroup::Post& p = g->gathered[(size_t)r];   // (stable between the two barriers)
+        if (p.bytes != count * sizeof(unsigned long long)) { err = "all-gather sizes differ between ranks"; (void)local_barrier(g); return M2S_ERR_STATE; }
+        TH(hipMemcpyPeerAsync(d_recv + (size_t)r * count, d->device, p.ptr, p.device, p.bytes, st));
+    }
+    TH(hipStreamSynchronize(st));
+    if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }   // nobody overwrites its contribution earlier
+    return M2S_OK;
+}
+
+// Every message is described on both sides (exact sizes).  sends[i].ptr is read, recvs[i].ptr written; messages between one
+// pair of ranks match in the order given.  `steps` interleaves them the way the caller staggered its peers.
+static m2s_status t_exchange(m2s_dist* d, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs, hipStream_t st, std::string& err) {
+    if (!d->local) {
+        TN(g_rccl.GroupStart());
+        const size_t n = std::max(sends.size(), recvs.size());
+        for (size_t i = 0; i < n; ++i) {
+            if (i < sends.size() && sends[i].bytes) TN(g_rccl.Send(sends[i].ptr, sends[i].bytes, kNcclUint8, sends[i].peer, d->comm, st));
+            if (i < recvs.size() && recvs[i].bytes) TN(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, kNcclUint8, recvs[i].peer, d->comm, st));
+        }
+        TN(g_rccl.GroupEnd());
+        return M2S_OK;
+    }
+    LocalGroup* g = d->local;
+    TH(hipStreamSynchronize(st));          // what I send is complete
+    {
+        std::lock_guard<std::mutex> l(g->m);
+        auto& mine = g->sends[(size_t)d->rank];
+        mine.clear();
+        for (const Xfer& x : sends) if (x.bytes) mine.push_back(LocalGroup::Send{ x.peer, x.ptr, x.bytes, d->device });
+    }
+    if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }
+    std::vector<size_t> next((size_t)d->world, 0);
+    m2s_status result = M2S_OK;
+    for (const Xfer& x : recvs) {
+        if (!x.bytes) continue;
+        const auto& theirs = g->sends[(size_t)x.peer];
+        size_t& k = next[(size_t)x.peer];
+        while (k < theirs.size() && theirs[k].dst != d->rank) ++k;
+        if (k == theirs.size() || theirs[k].bytes != x.bytes) { err = "record exchange: the two sides of a message disagree"; result = M2S_ERR_STATE; break; }
+        if (hipMemcpyPeerAsync(x.ptr, d->device, theirs[k].ptr, theirs[k].device, x.bytes, st) != hipSuccess) { err = "hipMemcpyPeerAsync failed"; result = M2S_ERR_HIP; break; }
+        ++k;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && result == M2S_OK) { err = "record exchange: stream failed"; result = M2S_ERR_HIP; }
+    if (!local_barrier(g) && result == M2S_OK) { err = "a rank of the in-process group did not arrive"; result = M2S_ERR_STATE; }
+    return result;
+}
+#undef TH
+#undef TN
+
 // issues the runtime calls of queued counter exchanges, in order
 static void dist_worker(m2s_dist* d) {
     (void)hipSetDevice(d->device);
@@ -142,12 +273,13 @@ static void dist_worker(m2s_dist* d) {
             std::lock_guard<std::mutex> c(d->comm_lock);
             d->h_mine[k] = job.second;
             hipError_t e = hipMemcpyAsync(d->d_mine + k, d->h_mine + k, 8, hipMemcpyHostToDevice, d->stream);
-            int r = kNcclSuccess;
-            if (e == hipSuccess) r = g_rccl.AllGather(d->d_mine + k, d->d_all + (size_t)k * d->world, 1, kNcclUint64, d->comm, d->stream);
-            if (e == hipSuccess && r == kNcclSuccess)
+            m2s_status r = M2S_OK;
+            std::string terr;
+            if (e == hipSuccess) r = t_all_gather(d, d->d_mine + k, d->d_all + (size_t)k * d->world, 1, d->stream, terr);
+            if (e == hipSuccess && r == M2S_OK)
                 e = hipMemcpyAsync(d->h_all + (size_t)k * d->world, d->d_all + (size_t)k * d->world, (size_t)d->world * 8, hipMemcpyDeviceToHost, d->stream);
-            if (e == hipSuccess && r == kNcclSuccess) e = hipEventRecord(d->done[k], d->stream);
-            if (r != kNcclSuccess) err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+            if (e == hipSuccess && r == M2S_OK) e = hipEventRecord(d->done[k], d->stream);
+            if (r != M2S_OK) err = std::string("counter all-gather: ") + terr;
             else if (e != hipSuccess) err = std::string("counter exchange: ") + hipGetErrorString(e);
         }
         {
@@ -174,25 +306,57 @@ m2s_status m2s_dist_unique_id(uint8_t out_id[M2S_DIST_ID_BYTES]) {
     return M2S_OK;
 }
 
+// The id of an in-process group of `world` ranks (threads of this process, one context each).  Every rank must then call
+// m2s_dist_create with it (the group is released by the last m2s_dist_destroy).
+m2s_status m2s_dist_local_id(int world, uint8_t out_id[M2S_DIST_ID_BYTES]) {
+    if (!out_id || world < 1) { g_dist_error = "bad argument"; return M2S_ERR_INVALID; }
+    LocalGroup* g = new (std::nothrow) LocalGroup();
+    if (!g) { g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
+    try {
+        g->world = world;
+        g->gathered.resize((size_t)world);
+        g->sends.resize((size_t)world);
+    } catch (...) { delete g; g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
+    memset(out_id, 0, M2S_DIST_ID_BYTES);
+    memcpy(out_id, kLocalMagic, sizeof kLocalMagic);
+    memcpy(out_id + 8, &g, sizeof g);
+    memcpy(out_id + 16, &world, sizeof world);
+    return M2S_OK;
+}
+
 m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int rank, int world, m2s_dist** out) {
     if (!out || !id || world < 1 || rank < 0 || rank >= world) { g_dist_error = "bad argument"; return M2S_ERR_INVALID; }
     *out = nullptr;
-    if (!rccl_ready()) return M2S_ERR_STATE;
+    const bool is_local = memcmp(id, kLocalMagic, sizeof kLocalMagic) == 0;
+    if (!is_local && !rccl_ready()) return M2S_ERR_STATE;
     m2s_dist* d = new (std::nothrow) m2s_dist();
     if (!d) { g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
     d->device = device; d->rank = rank; d->world = world;
     auto bail = [&](m2s_status s) { g_dist_error = d->err; m2s_dist_destroy(d); return s; };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) { d->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(M2S_ERR_NO_DEVICE); }
-    ncclUniqueId_t uid;
-    memcpy(&uid, id, sizeof uid);
-    const int r = g_rccl.CommInitRank(&d->comm, world, uid, rank);
-    if (r != kNcclSuccess) { d->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); d->comm = nullptr; return bail(M2S_ERR_HIP); }
+    if (is_local) {
+        LocalGroup* g = nullptr;
+        int gw = 0;
+        memcpy(&g, id + 8, sizeof g);
+        memcpy(&gw, id + 16, sizeof gw);
+        if (!g || gw != world) { d->err = "the in-process group was made for another world size"; return bail(M2S_ERR_INVALID); }
+        { std::lock_guard<std::mutex> l(g->m); ++g->joined; }
+        d->local = g;
+    } else {
+        ncclUniqueId_t uid;
+        memcpy(&uid, id, sizeof uid);
+        const int r = g_rccl.CommInitRank(&d->comm, world, uid, rank);
+        if (r != kNcclSuccess) { d->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); d->comm = nullptr; return bail(M2S_ERR_HIP); }
+    }
+    const size_t sort_words = (size_t)(kSortSamples + 1) * (1 + (size_t)world) + 3 * (size_t)world + (size_t)world * world;
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_mine, kRing * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_all, (size_t)kRing * world * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipHostMalloc((void**)&d->h_mine, kRing * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&d->h_all, (size_t)kRing * world * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void**)&d->h_all, (size_t)kRing * world * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void**)&d->d_sort, sort_words * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipHostMalloc((void**)&d->h_sort, sort_words * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) {
         d->err = std::string("allocation: ") + hipGetErrorString(e);
         return bail(M2S_ERR_HIP);
     }
@@ -218,7 +382,14 @@ void m2s_dist_destroy(m2s_dist* d) {
     if (d->d_all) (void)hipFree(d->d_all);
     if (d->h_mine) (void)hipHostFree(d->h_mine);
     if (d->h_all) (void)hipHostFree(d->h_all);
+    if (d->d_sort) (void)hipFree(d->d_sort);
+    if (d->h_sort) (void)hipHostFree(d->h_sort);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (LocalGroup* g = d->local) {   // the group goes with its last member (every rank of it is expected to have joined)
+        bool last;
+        { std::lock_guard<std::mutex> l(g->m); last = ++g->left == g->world; }
+        if (last) delete g;
+    }
     delete d;
 }
 
@@ -363,14 +534,114 @@ m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64
         d->issued_cv.wait(l, [&] { return d->issued == d->published; });
     }
     std::lock_guard<std::mutex> comm_guard(d->comm_lock);
-    NCHK(d, g_rccl.GroupStart());
+    std::vector<Xfer> sends, recvs;
     for (int step = 1; step < W; ++step) {
         const int dst = (me + step) % W, src = (me - step + W) % W;
-        if (counts[me] && (root < 0 || root == dst)) NCHK(d, g_rccl.Send(d_mine, counts[me] * rec, kNcclUint8, dst, d->comm, st));
-        if (counts[src] && receives) NCHK(d, g_rccl.Recv(merged + off[src] * rec, counts[src] * rec, kNcclUint8, src, d->comm, st));
+        sends.push_back(Xfer{ dst, const_cast<void*>(d_mine), (counts[me] && (root < 0 || root == dst)) ? (size_t)(counts[me] * rec) : 0 });
+        recvs.push_back(Xfer{ src, merged ? merged + off[src] * rec : nullptr, (counts[src] && receives) ? (size_t)(counts[src] * rec) : 0 });
     }
-    NCHK(d, g_rccl.GroupEnd());
-    return M2S_OK;
+    return t_exchange(d, sends, recvs, st, d->err);
+}
+
+// Depth sort of records that are spread over the ranks (BASELINE config 5: "final radix sort of the merged splat buffer";
+// the single-GPU pass is m2s_sort_by_depth == RadixSortPass.cpp:8-90).  Sample sort with ONE record exchange:
+//   local sort -> 256 evenly spaced keys per rank, all-gathered -> world - 1 splitters (every rank picks the same) ->
+//   rank j receives the keys in [splitter j-1, splitter j) from everybody (equal keys never straddle ranks), exact sizes,
+//   all pairs at once -> local sort of what arrived (runs arrive in source-rank order, each sorted, and the local sort is
+//   stable, so ties keep (source rank, original position) order).
+// Concatenating the ranks' results in rank order IS the stable sort of the rank-major concatenation of the inputs, i.e. what
+// one GPU produces from the merged buffer.  Keys are never sent: they are a function of the record (key kernel of m2s_sort.hip).
+// Collective: every rank calls it, in the same order relative to the other m2s_dist_* calls.  Afterwards the context's
+// current records are the received ones, its sorted buffer (m2s_device_sorted_records / m2s_download_sorted) holds this
+// rank's slice of the sorted sequence: *out_n records starting at position *out_offset.
+m2s_status m2s_dist_sort_by_depth(m2s_dist* d, m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n, uint64_t* out_offset) {
+    if (!d || !ctx || !world_to_view) return M2S_ERR_INVALID;
+    DCHK(d, hipSetDevice(d->device));
+    uint64_t n = 0;
+    m2s_status s = m2s_sort_by_depth(ctx, world_to_view, &n);
+    if (s != M2S_OK) { d->err = std::string("local sort: ") + m2s_last_error(ctx); return s; }
+    const int W = d->world, me = d->rank;
+    if (out_n) *out_n = n;
+    if (out_offset) *out_offset = 0;
+    if (W == 1) return M2S_OK;
+    const uint32_t R = m2s_last_resolution(ctx);
+    const uint32_t* keys = static_cast<const uint32_t*>(m2s_device_sorted_keys(ctx));
+    const char* sorted = static_cast<const char*>(m2s_device_sorted_records(ctx));
+    const size_t S = kSortSamples, S1 = S + 1, rec = sizeof(m2s_gaussian);
+    unsigned long long *d_samples = d->d_sort, *d_all = d_samples + S1, *d_split = d_all + (size_t)W * S1, *d_bounds = d_split + W,
+                       *d_sendc = d_bounds + W, *d_matrix = d_sendc + W;
+    unsigned long long *h_samples = d->h_sort, *h_all = h_samples + S1, *h_split = h_all + (size_t)W * S1, *h_bounds = h_split + W,
+                       *h_sendc = h_bounds + W, *h_matrix = h_sendc + W;
+    {   // same order of communicator operations on every rank: counter exchanges published so far go first
+        std::unique_lock<std::mutex> l(d->q_lock);
+        d->issued_cv.wait(l, [&] { return d->issued == d->published; });
+    }
+    std::lock_guard<std::mutex> comm_guard(d->comm_lock);
+    hipStream_t st = d->stream;
+    try {
+        // 1. samples of my sorted keys, gathered
+        if (n) m2s::launch_pick_samples(keys, n, (uint32_t)S, d_samples, st);
+        else {
+            for (size_t i = 0; i < S; ++i) h_samples[i] = ~0ull;
+            h_samples[S] = 0;
+            DCHK(d, hipMemcpyAsync(d_samples, h_samples, S1 * 8, hipMemcpyHostToDevice, st));
+        }
+        if ((s = t_all_gather(d, d_samples, d_all, S1, st, d->err)) != M2S_OK) return s;
+        DCHK(d, hipMemcpyAsync(h_all, d_all, (size_t)W * S1 * 8, hipMemcpyDeviceToHost, st));
+        DCHK(d, hipStreamSynchronize(st));
+        // 2. splitters: the same on every rank
+        std::vector<unsigned long long> valid;
+        for (int r = 0; r < W; ++r) {
+            const size_t take = (size_t)std::min<unsigned long long>(h_all[(size_t)r * S1 + S], S);
+            valid.insert(valid.end(), h_all + (size_t)r * S1, h_all + (size_t)r * S1 + take);
+        }
+        std::sort(valid.begin(), valid.end());
+        const size_t m = valid.size();
+        for (int j = 1; j < W; ++j) h_split[j - 1] = m ? valid[std::min((size_t)j * m / (size_t)W, m - 1)] : ~0ull;
+        // 3. where my sorted block is cut: keys < splitter[0] stay with rank 0, [splitter[j-1], splitter[j]) go to rank j
+        for (int j = 0; j < W; ++j) h_bounds[j] = 0;
+        if (n) {
+            DCHK(d, hipMemcpyAsync(d_split, h_split, (size_t)(W - 1) * 8, hipMemcpyHostToDevice, st));
+            m2s::launch_lower_bounds(keys, n, d_split, (uint32_t)(W - 1), d_bounds, st);
+            DCHK(d, hipMemcpyAsync(h_bounds, d_bounds, (size_t)(W - 1) * 8, hipMemcpyDeviceToHost, st));
+            DCHK(d, hipStreamSynchronize(st));
+        }
+        std::vector<uint64_t> edges((size_t)W + 1, 0);
+        for (int j = 1; j < W; ++j) edges[(size_t)j] = std::max<uint64_t>(edges[(size_t)j - 1], std::min<uint64_t>(h_bounds[j - 1], n));
+        edges[(size_t)W] = n;
+        for (int j = 0; j < W; ++j) h_sendc[j] = edges[(size_t)j + 1] - edges[(size_t)j];
+        // 4. everybody's send counts: row r of the matrix = what rank r sends to each rank
+        DCHK(d, hipMemcpyAsync(d_sendc, h_sendc, (size_t)W * 8, hipMemcpyHostToDevice, st));
+        if ((s = t_all_gather(d, d_sendc, d_matrix, (size_t)W, st, d->err)) != M2S_OK) return s;
+        DCHK(d, hipMemcpyAsync(h_matrix, d_matrix, (size_t)W * W * 8, hipMemcpyDeviceToHost, st));
+        DCHK(d, hipStreamSynchronize(st));
+        std::vector<uint64_t> roff((size_t)W + 1, 0);
+        uint64_t offset = 0;
+        for (int r = 0; r < W; ++r) roff[(size_t)r + 1] = roff[(size_t)r] + h_matrix[(size_t)r * W + me];
+        for (int q = 0; q < me; ++q)
+            for (int r = 0; r < W; ++r) offset += h_matrix[(size_t)r * W + q];
+        const uint64_t total_recv = roff[(size_t)W];
+        // 5. the exchange, into the context's record pool (my sorted block stays where it is: a separate buffer)
+        void* pool = nullptr;
+        if ((s = m2s_reserve_records(ctx, total_recv, &pool)) != M2S_OK) { d->err = std::string("receive buffer: ") + m2s_last_error(ctx); return s; }
+        char* dst = static_cast<char*>(pool);
+        if (h_sendc[me]) DCHK(d, hipMemcpyAsync(dst + roff[(size_t)me] * rec, sorted + edges[(size_t)me] * rec, h_sendc[me] * rec, hipMemcpyDeviceToDevice, st));
+        std::vector<Xfer> sends, recvs;
+        for (int step = 1; step < W; ++step) {
+            const int to = (me + step) % W, from = (me - step + W) % W;
+            sends.push_back(Xfer{ to, const_cast<char*>(sorted) + edges[(size_t)to] * rec, (size_t)(h_sendc[to] * rec) });
+            recvs.push_back(Xfer{ from, dst + roff[(size_t)from] * rec, (size_t)(h_matrix[(size_t)from * W + me] * rec) });
+        }
+        if ((s = t_exchange(d, sends, recvs, st, d->err)) != M2S_OK) return s;
+        DCHK(d, hipStreamSynchronize(st));
+        // 6. what arrived, sorted (stable): my slice of the global order
+        if ((s = m2s_set_records(ctx, pool, total_recv, R)) != M2S_OK) { d->err = m2s_last_error(ctx); return s; }
+        uint64_t n2 = 0;
+        if ((s = m2s_sort_by_depth(ctx, world_to_view, &n2)) != M2S_OK) { d->err = std::string("final sort: ") + m2s_last_error(ctx); return s; }
+        if (out_n) *out_n = total_recv;
+        if (out_offset) *out_offset = offset;
+        return M2S_OK;
+    } catch (...) { d->err = "host allocation failed"; return M2S_ERR_OOM; }
 }
 
 // Blocks until everything enqueued on hip_stream (e.g. the record exchange) has completed.

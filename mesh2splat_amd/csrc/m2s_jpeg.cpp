@@ -402,6 +402,12 @@ struct Decoder {
         mcu_x = (img_x + mcu_w - 1) / mcu_w;
         mcu_y = (img_y + mcu_h - 1) / mcu_h;
         if ((uint64_t)mcu_x * mcu_w * (uint64_t)mcu_y * mcu_h > (1ull << 30)) return fail("JPEG too large");
+        {   // a header must not be able to demand gigabytes that the file cannot fill: every 8x8 block costs at least one bit
+            // of entropy-coded data (a Huffman code has no zero-length words), so fewer bits than blocks is not an image
+            uint64_t blocks = 0;
+            for (int i = 0; i < n_comp; ++i) blocks += (uint64_t)mcu_x * comp[i].h * (uint64_t)mcu_y * comp[i].v;
+            if (blocks > (uint64_t)(end - p) * 8u) return fail("JPEG data too short for its dimensions");
+        }
         for (int i = 0; i < n_comp; ++i) {
             Component& c = comp[i];
             c.x = (img_x * c.h + h_max - 1) / h_max;

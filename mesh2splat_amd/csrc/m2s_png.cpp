@@ -106,6 +106,8 @@ bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err) {
     } else { err = "unsupported PNG interlace method"; return false; }
     // Streamed inflate: the image needs exactly raw_len bytes; what the zlib stream holds beyond them (trailing bytes some
     // encoders leave, which stb_image ignores) is not an error, a stream that ends early is.
+    // (deflate expands by at most 1032 : 1: a header must not be able to demand gigabytes that the IDAT bytes cannot fill)
+    if (raw_len / 1032 > idat.size() + 1) { err = "PNG data too short for its dimensions"; return false; }
     std::vector<uint8_t> raw(raw_len);
     {
         z_stream zs;

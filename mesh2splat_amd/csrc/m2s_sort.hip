@@ -76,4 +76,46 @@ hipError_t sort_prepass(const float* depths, const float4* quads, uint32_t n, ui
     return hipGetLastError();
 }
 
+// ---- pieces of the sample sort across ranks (m2s_dist_sort_by_depth, m2s_dist.cpp) ----
+// out[i] = the key at position ((i + 1) * n) / (take + 1) of the rank's SORTED keys, i < take = min(s, n); the remaining
+// slots hold the "no sample" value 2^64 - 1; out[s] = take.
+__global__ void k_pick_samples(const uint32_t* __restrict__ keys, unsigned long long n, uint32_t s, unsigned long long* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long take = n < s ? n : s;
+    if (i < s) {
+        unsigned long long v = ~0ull;
+        if (i < take) {
+            unsigned long long pos = ((unsigned long long)(i + 1) * n) / (take + 1);
+            if (pos > n - 1) pos = n - 1;
+            v = keys[pos];
+        }
+        out[i] = v;
+    } else if (i == s) {
+        out[s] = take;
+    }
+}
+
+// out[j] = number of keys < splitter[j] (keys ascending): where the block that goes to rank j + 1 starts
+__global__ void k_lower_bounds(const uint32_t* __restrict__ keys, unsigned long long n, const unsigned long long* __restrict__ splitters, uint32_t m,
+                               unsigned long long* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const unsigned long long sp = splitters[j];
+    unsigned long long lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        if ((unsigned long long)keys[mid] < sp) lo = mid + 1; else hi = mid;
+    }
+    out[j] = lo;
+}
+
+void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_pick_samples, dim3((s + 1 + 255) / 256), dim3(256), 0, st, keys, (unsigned long long)n, s, out);
+}
+
+void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long long* splitters, uint32_t m, unsigned long long* out, hipStream_t st) {
+    if (!m) return;
+    hipLaunchKernelGGL(k_lower_bounds, dim3((m + 63) / 64), dim3(64), 0, st, keys, (unsigned long long)n, splitters, m, out);
+}
+
 }  // namespace m2s

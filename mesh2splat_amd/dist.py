@@ -82,7 +82,7 @@ class RcclExchange:
         from . import _lib
         self._C, self._lib, self._L = C, _lib, _lib.load()
         ident = None
-        if rank == 0:
+        if rank == 0 and not getattr(bootstrap, "local_group", False):
             buf = (C.c_uint8 * 128)()
             st = self._L.m2s_dist_unique_id(buf)
             if st != _lib.M2S_OK:
@@ -136,7 +136,41 @@ class RcclExchange:
         """Tensor form (what bench.py calls, so that the torch.distributed stand-in below is interchangeable)."""
         self.gather_records(mine.data_ptr(), counts, merged.data_ptr() if merged is not None else 0, root, stream)
 
+    def wait(self, stream: int = 0):
+        self._check(self._L.m2s_dist_wait(self._h, self._C.c_void_p(stream or None)))
+
+    def sort_by_depth(self, converter, world_to_view):
+        """m2s_dist_sort_by_depth: sample sort of the ranks' current records (collective).  -> (n, offset): this rank's slice
+        of the globally sorted sequence is `converter`'s sorted buffer (converter.download_sorted())."""
+        import numpy as np
+        m = np.ascontiguousarray(np.asarray(world_to_view, np.float32).T.reshape(16))   # column-major, like glm
+        n, off = self._C.c_uint64(), self._C.c_uint64()
+        self._check(self._L.m2s_dist_sort_by_depth(self._h, converter._h, m.ctypes.data_as(self._C.POINTER(self._C.c_float)),
+                                                   self._C.byref(n), self._C.byref(off)))
+        return int(n.value), int(off.value)
+
     kind = "C ABI (m2s_dist_*: RCCL opened by libm2s_hip.so)"
+
+
+def local_bootstrap(ident: bytes):
+    """bootstrap argument of RcclExchange for a rank of an in-process group (see local_group_id)."""
+    def hand_over(_):
+        return ident
+    hand_over.local_group = True      # rank 0 must not ask RCCL for an id
+    return hand_over
+
+
+def local_group_id(world: int) -> bytes:
+    """m2s_dist_local_id: the id of an in-process group (ranks = threads of this process, one Converter each).  Hand the
+    same bytes to every rank's RcclExchange(device, rank, world, local_bootstrap(ident))."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.load()
+    buf = (C.c_uint8 * 128)()
+    st = L.m2s_dist_local_id(int(world), buf)
+    if st != _lib.M2S_OK:
+        raise _lib.M2SError(st, L.m2s_dist_last_error(None).decode())
+    return bytes(buf)
 
 
 class TorchExchange:
