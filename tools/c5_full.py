@@ -1,0 +1,127 @@
+"""BASELINE config 5 at FULL size on ONE MI355X: 4 meshes x cube-sphere n=1021 = 50 037 168 triangles (7.2 GB of live vertex data),
+4096^2 maps, R = 2048, cap lifted (the reference's 7 M envelope is exceeded), + the depth sort of the whole buffer.
+The multi-GPU form of this config shards exactly this scene by triangle range; here one GPU takes all of it, which its 288 GB
+allow.  Checked against the oracle (the checker, not the product): the counter on the whole scene, the per-triangle counts and
+the records on sampled triangle ranges of every mesh.  usage: python tools/c5_full.py [out.json] [n] [tex]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from mesh2splat_amd import synth                      # noqa: E402
+from mesh2splat_amd.converter import Converter        # noqa: E402
+from mesh2splat_amd.scene import Mesh, Scene          # noqa: E402
+
+
+def log(*a):
+    print(f"[{time.time() - T0:7.1f}s]", *a, flush=True)
+
+
+T0 = time.time()
+out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "c5_full.json")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1021
+tex = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+R, count = 2048, 4
+
+base = synth.cube_sphere_vertices(n, radius=1.0, center=(0.0, 0.0, 0.0), stride=12)
+log("one sphere generated", base.shape)
+meshes = []
+for k in range(count):          # synth.sphere_row, without generating the same sphere four times
+    v = base.copy()
+    v[:, 0] += np.float32(2.5 * k)
+    meshes.append(Mesh(name=f"sphere_{k}", vertices=v, base_color=(1.0, 1.0, 1.0, 1.0), textures=synth.procedural_textures(tex, synth.SEED + k)))
+del base
+scene = Scene(meshes)
+T = scene.n_triangles
+log("scene ready:", T, "triangles,", sum(m.vertices.nbytes for m in scene.meshes) / 1e9, "GB of vertices")
+
+res = {"scene": f"{count} x cube-sphere n={n} ({T} triangles), {tex}^2 maps, R={R}, cap lifted", "triangles": T}
+conv = Converter(0)
+t = time.perf_counter()
+conv.upload_scene(scene)
+res["upload_s"] = time.perf_counter() - t
+log("uploaded in", round(res["upload_s"], 3), "s")
+conv.set_max_gaussians(0)
+conv.set_profiling(True)
+t = time.perf_counter()
+total = conv.convert(R)
+res["first_convert_ms"] = (time.perf_counter() - t) * 1e3
+res["gaussians"] = int(total)
+res["pipeline"] = conv.last_pipeline
+log("first conversion:", total, "Gaussians,", round(res["first_convert_ms"], 2), "ms,", conv.last_pipeline)
+wall, kern = [], []
+for _ in range(10):
+    t = time.perf_counter()
+    assert conv.convert(R) == total
+    wall.append((time.perf_counter() - t) * 1e3)
+    kern.append(conv.last_kernel_ms())
+res["convert_ms_blocking"] = {"median": float(np.median(wall)), "min": float(np.min(wall))}
+res["kernel_ms"] = {k: float(np.median([x[k] for x in kern])) for k in kern[0]}
+alg = 96.0 * total + 144.0 * T
+res["algorithmic_bytes"] = alg
+res["gaussians_per_s"] = total / (np.median(wall) * 1e-3)
+res["roofline_frac_whole_conversion"] = alg / (np.median(wall) * 1e-3) / 8e12
+log("steady:", res["convert_ms_blocking"], res["kernel_ms"], "frac", round(res["roofline_frac_whole_conversion"], 3))
+
+# the depth sort of the whole buffer (BASELINE config 5: "final radix sort of the merged splat buffer")
+view = np.eye(4, dtype=np.float32)
+view[2, 3] = -6.0
+sms = []
+for _ in range(3):
+    ns = conv.sort_by_depth(view, download=False)
+    sms.append(conv.last_sort_ms)
+res["depth_sort"] = {"records": int(ns), "ms": float(np.median(sms))}
+log("depth sort:", res["depth_sort"])
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+with open(out_path, "w") as f:          # (timings first: the oracle part below takes a while)
+    json.dump(res, f, indent=1)
+
+# ---- against the oracle ----
+from oracle import oracle                              # noqa: E402
+from parity import assert_records_match                # noqa: E402
+
+cnt = conv.download_triangle_counts().astype(np.int64)
+assert int(cnt.sum()) == total
+off = np.concatenate([[0], np.cumsum(cnt)])
+prepared = oracle.PreparedScene(scene)
+L = oracle.lib()
+threads = os.cpu_count() or 1
+t = time.perf_counter()
+ototal = int(L.orc_scene_convert(prepared._h, R, 0, (1 << 64) - 1, 0, None, 0, None, threads))
+res["oracle_count_s"] = time.perf_counter() - t
+res["oracle_total"] = ototal
+log("oracle counter:", ototal, "in", round(res["oracle_count_s"], 1), "s on", threads, "threads")
+assert ototal == total, (ototal, total)
+per_mesh = T // count
+import ctypes                                          # noqa: E402
+import torch                                           # noqa: E402
+hip = ctypes.CDLL("libamdhip64.so")
+checked = 0
+rng = np.random.default_rng(5)
+for k in range(count):
+    for first in (k * per_mesh, k * per_mesh + int(rng.integers(0, per_mesh - 60_000)), (k + 1) * per_mesh - 60_000):
+        m = 60_000
+        want = int(off[first + m] - off[first])
+        orec = np.zeros((want, 24), np.float32)
+        got_total = int(L.orc_scene_convert(prepared._h, R, first, m, 0, orec.ctypes.data, want, None, threads))
+        assert got_total == want, (k, first, got_total, want)
+        buf = torch.empty((want, 24), dtype=torch.float32, device="cuda")
+        hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(conv.device_records + int(off[first]) * 96), ctypes.c_size_t(want * 96), 3)   # device to device
+        rec = buf.cpu().numpy()
+        assert_records_match(rec, orec, f"C5 mesh {k} range @{first}")
+        checked += want
+res["records_checked_against_oracle"] = checked
+res["count_identical_to_oracle"] = True
+log("records checked:", checked)
+prepared.close()
+conv.close()
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+with open(out_path, "w") as f:
+    json.dump(res, f, indent=1)
+print(json.dumps(res))

@@ -7,10 +7,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mesh2splat_amd import _lib, synth
 from mesh2splat_amd.converter import Converter
-scene = synth.cube_sphere(289, tex_size=2048)
+N, R = int(os.environ.get('TT_N', 289)), int(os.environ.get('TT_R', 1024))
+scene = synth.cube_sphere(N, tex_size=2048)
 c = Converter(0); c.set_pipeline("team"); c.upload_scene(scene)
-for _ in range(3): c.convert(1024)
-c.set_profiling(True); n = c.convert(1024); print("gaussians", n, c.last_kernel_ms())
+c.set_max_gaussians(0)
+for _ in range(3): c.convert(R)
+c.set_profiling(True); n = c.convert(R); print('n', N, 'R', R, 'triangles', scene.n_triangles, "gaussians", n, c.last_kernel_ms())
 L = _lib.load(); S, B = 16, 8192
 buf = np.zeros(S * B, np.uint64)
 assert L.m2s_debug_read_timing2(buf.ctypes.data_as(C.c_void_p), C.c_size_t(S * B)) == 0
