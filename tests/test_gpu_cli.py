@@ -102,3 +102,26 @@ def test_cli_several_ranks_on_one_gpu(tmp_path, hiplib, ranks):
         assert r.returncode == 0, r.stderr + r.stdout
         assert f"{ranks} GPUs" in r.stdout and r.stdout.count("[rank ") == ranks
         assert open(many, "rb").read() == open(one, "rb").read(), (fmt, cap)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_cli_ranks_as_threads_with_gather(tmp_path, hiplib, ranks):
+    """`--gpus N --threads [--gather] --one-device`: the ranks are threads of ONE process (the reference's shape); with --gather the
+    blocks travel to rank 0 over the in-process transport (m2s_dist_local_id) and rank 0 writes the whole file — the C++ consumer
+    of the same code the RCCL transport runs, with more than one rank, on the one GPU this box has.  Same bytes as one process."""
+    scene = synth.sphere_grid(2, n=6, tex_size=32)
+    glb = str(tmp_path / "s.glb")
+    gltf_io.write_glb(scene, glb)
+    for fmt, cap in ((0, []), (2, ["--cap", "30000"])):
+        one = str(tmp_path / "one.ply")
+        r = subprocess.run([EXE, glb, one, "--density", "128", "--format", str(fmt)] + cap, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for extra in ([], ["--gather"]):
+            many = str(tmp_path / "many.ply")
+            r = subprocess.run([EXE, glb, many, "--density", "128", "--format", str(fmt), "--gpus", str(ranks), "--threads", "--one-device", "--timing"] + cap + extra,
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr + r.stdout
+            assert r.stdout.count("[rank ") == ranks
+            if extra:
+                assert "in-process transport" in r.stdout
+            assert open(many, "rb").read() == open(one, "rb").read(), (fmt, cap, extra)

@@ -18,6 +18,9 @@
 //                               their final offset (m2s_export_ply_slice) — no record leaves its GPU, no RCCL needed.
 //                               --gather: instead, the counters go through RCCL (m2s_dist_all_gather_counts) and the blocks
 //                               are concatenated on rank 0 over xGMI (m2s_dist_gather_records), which writes the file.
+//                               --threads: the N ranks are THREADS of this process instead of forked processes (the reference's
+//                               shape: one executable); with --gather the exchange then runs on the in-process transport
+//                               (m2s_dist_local_id: hipMemcpyPeer over the same links, no RCCL).
 //                    --batch  : file k goes to GPU k mod N (independent replicas, no exchange).
 // One GPU, --batch: load(k+1) | upload + convert(k) | export(k-1) overlap (a loader thread, an exporter thread, two
 // contexts used alternately so that file k's records stay intact while file k+1 converts).
@@ -50,6 +53,7 @@ struct Options {
     int pipeline = M2S_PIPELINE_AUTO;
     bool timing = false, gather = false, force_sharded = false;   // force_sharded: the --gpus code path with one rank (tests)
     bool one_device = false;                                       // tests: every rank on --device (several processes share one GPU)
+    bool threads = false;                                          // ranks as threads of this process
     uint32_t R() const { return density > 0 ? (uint32_t)density : (uint32_t)(int)(16 + quality * (double)(max_res - 16)); }  // ImGuiUI.cpp:512
 };
 
@@ -136,7 +140,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     if (m2s_create(device, &ctx) != M2S_OK) return fail("create", m2s_last_error(nullptr));
     m2s_dist* d = nullptr;
     if (o.gather) {   // records will move between GPUs: one RCCL communicator per rank, id through the shared mapping
-        if (rank == 0) {
+        if (rank == 0 && !o.threads) {   // (with --threads the parent made the in-process group's id before starting the ranks)
             if (m2s_dist_unique_id(sh->id) != M2S_OK) return fail("unique_id", m2s_dist_last_error(nullptr));
             sh->id_ready.store(1);
         } else {
@@ -195,7 +199,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     if (rank == 0)
         std::printf("%s: %u mesh(es), density %u, %d GPUs -> %llu Gaussians (%llu stored) -> %s (format %ld, %s)\n", o.in.c_str(), n_meshes, R, world,
                     (unsigned long long)all, (unsigned long long)offs[(size_t)world], o.out.c_str(), o.format,
-                    o.gather ? "gathered on rank 0 over RCCL" : "every rank wrote its rows");
+                    o.gather ? (o.threads ? "gathered on rank 0, in-process transport" : "gathered on rank 0 over RCCL") : "every rank wrote its rows");
     if (o.timing)
         std::printf("[rank %d] triangles [%llu, +%llu) -> %llu Gaussians | init (HIP%s) %.2f ms | upload %.2f ms | convert + counter exchange %.3f ms | export %.2f ms\n",
                     rank, (unsigned long long)first[(size_t)rank], (unsigned long long)count[(size_t)rank], (unsigned long long)total, o.gather ? " + RCCL" : "", ms_between(t0, t1),
@@ -231,7 +235,19 @@ int convert_sharded(const Options& o) {
     sh->id_ready.store(0); sh->failed.store(0); sh->arrived.store(0);
     std::remove(o.out.c_str());
     const int world = (int)o.gpus;
-    const int rc = fork_ranks(world, [&](int r) { return rank_main(o, scene, sh, r, world); });
+    int rc = 0;
+    if (o.threads) {
+        if (o.gather) {
+            if (m2s_dist_local_id(world, sh->id) != M2S_OK) { std::fprintf(stderr, "local_id: %s\n", m2s_dist_last_error(nullptr)); return 1; }
+            sh->id_ready.store(1);
+        }
+        std::vector<int> rcs((size_t)world, 1);
+        std::vector<std::thread> ranks;
+        for (int r = 0; r < world; ++r) ranks.emplace_back([&, r] { rcs[(size_t)r] = rank_main(o, scene, sh, r, world); });
+        for (auto& t : ranks) t.join();
+        for (int r = 0; r < world; ++r) rc |= rcs[(size_t)r];
+    } else
+        rc = fork_ranks(world, [&](int r) { return rank_main(o, scene, sh, r, world); });
     munmap(sh, sizeof(Shared));
     m2s_free_host_scene(scene);
     return rc;
@@ -358,6 +374,7 @@ int main(int argc, char** argv) {
         else if (a == "--gather") o.gather = true;
         else if (a == "--force-sharded") o.force_sharded = true;
         else if (a == "--one-device") o.one_device = true;
+        else if (a == "--threads") o.threads = true;
         else if (a == "--batch") o.batch_dir = next();
         else if (a == "--out") o.out_dir = next();
         else if (a == "--pipeline") o.pipeline = std::string(next()) == "multipass" ? M2S_PIPELINE_MULTIPASS : M2S_PIPELINE_AUTO;
