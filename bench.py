@@ -489,22 +489,32 @@ def main():
         dist.barrier()
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
-        def bootstrap(ident):
-            # rank 0's RCCL id reaches the other ranks through the process group that torchrun set up; from here on the
-            # data path talks to RCCL through the C ABI (m2s_dist_*), not through torch.distributed
-            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if ident is not None:
-                t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
-            dist.broadcast(t, src=0)
-            return bytes(t.cpu().numpy().tobytes())
-        try:
-            if os.environ.get("M2S_BENCH_FORCE_TORCH_EXCHANGE"):      # (test hook for the fallback below)
-                raise RuntimeError("forced by M2S_BENCH_FORCE_TORCH_EXCHANGE")
-            exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
-            ok = 1
-        except Exception as e:  # noqa: BLE001
-            print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
-            exchange, ok = None, 0
+        # rank 0's RCCL id reaches the other ranks through the process group that torchrun set up — together with a flag: if rank 0
+        # cannot get one (no librccl), EVERY rank learns it here, before anybody enters a collective of the C-ABI communicator.
+        # From here on the data path talks to RCCL through the C ABI (m2s_dist_*), not through torch.distributed.
+        idt = torch.zeros(129, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            try:
+                if os.environ.get("M2S_BENCH_FORCE_TORCH_EXCHANGE"):      # (test hook for the fallback below)
+                    raise RuntimeError("forced by M2S_BENCH_FORCE_TORCH_EXCHANGE")
+                ident0 = m2d.RcclExchange.unique_id()
+                idt[1:].copy_(torch.frombuffer(bytearray(ident0), dtype=torch.uint8))
+                idt[0] = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
+        dist.broadcast(idt, src=0)
+        idh = idt.cpu().numpy()
+        exchange, ok = None, 0
+        if int(idh[0]) == 1:
+            def bootstrap(_):
+                return bytes(idh[1:].tobytes())
+            bootstrap.provides_id = True
+            try:
+                exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
+                exchange, ok = None, 0
         okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 0:           # on ANY rank: every rank switches, or the collectives would not match

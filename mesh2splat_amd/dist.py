@@ -82,7 +82,7 @@ class RcclExchange:
         from . import _lib
         self._C, self._lib, self._L = C, _lib, _lib.load()
         ident = None
-        if rank == 0 and not getattr(bootstrap, "local_group", False):
+        if rank == 0 and not getattr(bootstrap, "local_group", False) and not getattr(bootstrap, "provides_id", False):
             buf = (C.c_uint8 * 128)()
             st = self._L.m2s_dist_unique_id(buf)
             if st != _lib.M2S_OK:
@@ -95,6 +95,20 @@ class RcclExchange:
         if st != _lib.M2S_OK:
             raise _lib.M2SError(st, self._L.m2s_dist_last_error(None).decode())
         self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """m2s_dist_unique_id (rank 0): the 128 bytes the other ranks need.  Separate from the constructor so that a launcher can
+        tell the other ranks about a failure HERE before anybody enters a collective (hand the id to the constructor through a
+        bootstrap callable with the attribute provides_id = True)."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        st = L.m2s_dist_unique_id(buf)
+        if st != _lib.M2S_OK:
+            raise _lib.M2SError(st, L.m2s_dist_last_error(None).decode())
+        return bytes(buf)
 
     def _check(self, st):
         if st != self._lib.M2S_OK:
