@@ -236,3 +236,37 @@ def test_prepass_full_size_against_oracle(conv, oracle):
     assert_prepass_matches(got, want, 0, "C3")
     assert 0.3 * total < got[0] <= total
     assert 0.0 < conv.last_prepass_ms < 50.0
+
+
+def _needles(n, seed=11):
+    """Needle-shaped Gaussians in front of the default camera: one scale 10^4..10^6 times the others, random orientation.  Their
+    screen-space covariance is numerically rank 1, so lambda2 = (mid - delta) / 2 is pure rounding noise and comes out negative
+    for part of them — the shader's LAST cull test (gaussianSplattingPrepassCS.glsl:183) then removes them."""
+    rng = np.random.default_rng(seed)
+    r = np.zeros((n, 24), np.float32)
+    r[:, 0:3] = rng.uniform(-0.6, 0.6, (n, 3))
+    r[:, 3] = 1
+    r[:, 4:8] = rng.uniform(0.2, 1, (n, 4))
+    r[:, 8] = np.exp(rng.uniform(np.log(3e2), np.log(3e4), n))
+    r[:, 9:11] = 1e-2
+    q = rng.normal(size=(n, 4))
+    r[:, 16:20] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    r[:, 12:15] = (0, 0, 1)
+    r[:, 20:22] = 0.5
+    r[:, 23] = 1
+    return r
+
+
+def test_the_last_cull_test_is_reproduced_on_needles(conv, oracle):
+    """lambda2 < 0 (the shader's last test) only ever triggers through rounding; on 20 000 needle-shaped Gaussians, all inside the
+    frustum, it removes thousands.  Which ones is a matter of single roundings in the covariance projection: count, order and every
+    bit must be the oracle's."""
+    import torch
+    p = dict(CASES)[CASES[0][0]]
+    ordinary = prepass_cases.base_records(oracle, 14, 64)
+    rec = np.concatenate([ordinary, _needles(20000), ordinary[::-1]])
+    want = oracle.prepass(p, rec)
+    only_early = oracle.prepass(p, np.concatenate([ordinary, ordinary[::-1]]))
+    assert only_early[0] + 10000 < want[0] < only_early[0] + 19000          # most needles survive, thousands fail the last test
+    got = conv.prepass(p, records=torch.from_numpy(rec).cuda())
+    assert_prepass_matches(got, want, p.render_mode, "needles")
