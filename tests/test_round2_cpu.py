@@ -175,3 +175,52 @@ def test_read_ply_distrusts_the_header(tmp_path, hiplib):
     trunc = tmp_path / "trunc.ply"
     trunc.write_bytes(data[:-10])
     assert read(trunc)[0] != 0
+
+
+def test_in_process_group_ids_and_image_header_guards(tmp_path, hiplib):
+    """(a) m2s_dist_local_id: argument checks and the shape of the id, without touching a device; a world-size mismatch is
+    refused before any device call matters.  (b) The readers refuse images whose header demands far more pixels than their data
+    can describe (a 100-byte file must not make the loader allocate gigabytes)."""
+    import ctypes as C
+    from mesh2splat_amd import _lib
+    L = _lib.load()
+    buf = (C.c_uint8 * 128)()
+    assert L.m2s_dist_local_id(0, buf) == 1   # M2S_ERR_INVALID
+    assert L.m2s_dist_local_id(2, None) == 1   # M2S_ERR_INVALID
+    assert L.m2s_dist_local_id(3, buf) == _lib.M2S_OK
+    assert bytes(buf[:8]) == b"M2SLOCAL" and bytes(buf) != bytes(128)
+    ident = m2d.local_group_id(2)
+    assert len(ident) == 128 and ident[:8] == b"M2SLOCAL"
+    # (b) a JPEG whose frame header claims 60000 x 60000 pixels, followed by a few bytes of "scan"; and the PNG counterpart
+    import zlib
+    from mesh2splat_amd import gltf_io
+    sof = b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, 20000, 20000, 3) + b"\x01\x22\x00\x02\x11\x01\x03\x11\x01"
+    dqt = b"\xff\xdb" + struct.pack(">H", 67) + b"\x00" + bytes([16] * 64)
+    jpg = b"\xff\xd8" + dqt + sof + b"\xff\xda" + struct.pack(">HB", 12, 3) + b"\x01\x00\x02\x11\x03\x11\x00\x3f\x00" + b"\x00" * 64 + b"\xff\xd9"
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 30000, 30000, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    for name, blob, mime in (("bomb.jpg", jpg, "image/jpeg"), ("bomb.png", png, "image/png")):
+        scene = synth.unit_quad(textures={"baseColorTexture": np.full((4, 4, 4), 200, np.uint8)})
+        glb = str(tmp_path / (name + ".glb"))
+        gltf_io.write_glb(scene, glb)
+        raw = open(glb, "rb").read()
+        jl = struct.unpack_from("<I", raw, 12)[0]
+        doc = json.loads(raw[20:20 + jl])
+        pos = 20 + jl
+        bl = struct.unpack_from("<I", raw, pos)[0]
+        binc = bytearray(raw[pos + 8: pos + 8 + bl])
+        off = len(binc)
+        binc += blob
+        doc["bufferViews"].append({"buffer": 0, "byteOffset": off, "byteLength": len(blob)})
+        doc["images"][0] = {"bufferView": len(doc["bufferViews"]) - 1, "mimeType": mime}
+        doc["buffers"][0]["byteLength"] = len(binc)
+        js = json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        binc += b"\0" * (-len(binc) % 4)
+        body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(binc), 0x004E4942) + bytes(binc)
+        open(glb, "wb").write(struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body)
+        with pytest.raises(Exception) as e:
+            gltf_io.load_glb(glb)
+        assert "too short for its dimensions" in str(e.value) or "too large" in str(e.value), str(e.value)
