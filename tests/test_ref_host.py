@@ -308,3 +308,62 @@ def test_loader_matches_reference_on_real_asset_features(tmp_path, hiplib, featu
     glb = str(tmp_path / (name + ".glb"))
     _edit_glb(base, glb, edit)
     assert_scene_equal(refhost.load_scene(glb, str(tmp_path)), gltf_io.load_glb(glb))
+
+
+def test_decoders_match_reference_on_generated_images(tmp_path):
+    """Differential test of the PNG / JPEG decoders against the reference's loader (tiny_gltf -> stb_image, compiled from the
+    reference) on ~150 VALID files written by Pillow: noise / gradient / checker content, odd sizes, qualities 1..100, 4:4:4 /
+    4:2:2 / 4:2:0, baseline and progressive, optimised tables, restart intervals; PNG grey / grey+alpha / RGB / RGBA / palette
+    (+ tRNS) / 1-bit at several compression levels.  Every decoded byte must be the reference's."""
+    PIL = pytest.importorskip("PIL")
+    if not refhost.available():
+        pytest.skip("oracle/_ref/ref_host_check not built (needs /root/reference at build time)")
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import diff_decoders
+    rng = np.random.default_rng(321)
+    d = tmp_path / "img"
+    d.mkdir()
+    n = 0
+
+    def pic(w, h, kind):
+        y, x = np.mgrid[0:h, 0:w]
+        if kind == 0:
+            return rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if kind == 1:
+            return np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x ^ y) * 8) % 256, 255 - (x + y) % 256], -1).astype(np.uint8)
+        return np.full((h, w, 4), ((x + y) % 2 * 255)[..., None], np.uint8)
+
+    for (w, h) in ((1, 1), (9, 7), (17, 33), (64, 40), (130, 67)):
+        for kind in (0, 1, 2):
+            a = pic(w, h, kind)
+            for mode in ("L", "RGB"):
+                im = Image.fromarray(a, "RGBA").convert(mode)
+                for q, ss in ((1, 0), (35, 2), (75, 1), (100, 0)):
+                    if mode == "L" and ss:
+                        ss = 0
+                    kw = dict(quality=q, subsampling=ss)
+                    r = rng.random()
+                    if r < 0.35:
+                        kw["progressive"] = True
+                    if r > 0.7:
+                        kw["optimize"] = True
+                    if w * h > 64 and rng.random() < 0.3:
+                        kw["restart_marker_blocks"] = int(rng.integers(1, 5))
+                    im.save(str(d / f"v{n}.jpg"), **kw)
+                    n += 1
+            for mode in ("L", "LA", "RGB", "RGBA"):
+                Image.fromarray(a, "RGBA").convert(mode).save(str(d / f"v{n}.png"), compress_level=int(rng.choice([0, 1, 6, 9])))
+                n += 1
+            p = Image.fromarray(a, "RGBA").convert("RGB").convert("P", palette=Image.ADAPTIVE, colors=int(rng.choice([2, 16, 200])))
+            p.save(str(d / f"v{n}.png"), **({"transparency": 0} if rng.random() < 0.5 else {}))
+            n += 1
+            Image.fromarray(a, "RGBA").convert("1").save(str(d / f"v{n}.png"))
+            n += 1
+    old_argv = sys.argv
+    sys.argv = ["diff_decoders", str(d)]
+    try:
+        assert diff_decoders.main() == 0, "a decoded image differs from the reference's (see the captured output)"
+    finally:
+        sys.argv = old_argv
