@@ -9,6 +9,10 @@
 #include "m2s_host.h"
 #include "m2s_json.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -115,9 +119,11 @@ struct Accessor {
     bool normalized = false;
 };
 
+using FileBytes = std::vector<uint8_t, DefaultInit<uint8_t>>;
+
 struct Glb {
     m2s_json::Value doc;
-    std::vector<uint8_t> file;
+    FileBytes file;
     const uint8_t* bin = nullptr;
     size_t bin_len = 0;
 };
@@ -178,7 +184,7 @@ void read_uv(const Accessor& a, size_t i, float out[2]) {
     out[0] = out[1] = 0.0f;
 }
 
-bool base64_decode(const char* s, size_t n, std::vector<uint8_t>& out) {
+bool base64_decode(const char* s, size_t n, FileBytes& out) {
     out.clear();
     out.reserve(n / 4 * 3);
     uint32_t acc = 0;
@@ -209,19 +215,6 @@ std::string uri_decode(const std::string& u) {   // %XX escapes
     return r;
 }
 
-bool read_file(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    if (n < 0) { std::fclose(f); return false; }
-    out.resize((size_t)n);
-    const bool ok = n == 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-    std::fclose(f);
-    return ok;
-}
-
 }  // namespace
 
 // Splits [0, n) into contiguous chunks, one per thread (at most 16, at least `grain` items each); f(begin, end) must only
@@ -249,10 +242,31 @@ static void parallel_for(size_t n, size_t grain, F f) {
     if (first_error) std::rethrow_exception(first_error);
 }
 
+// The whole file into memory: sized without a zero fill, read by several threads (each pread copies its own part out of the
+// page cache).
+static bool read_file(const std::string& path, FileBytes& out) {
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size < 0) { ::close(fd); return false; }
+    const size_t n = (size_t)st.st_size;
+    try { out.resize(n); } catch (...) { ::close(fd); return false; }
+    std::atomic<bool> ok{ true };
+    parallel_for(n, (size_t)4 << 20, [&](size_t b, size_t e) {
+        while (b < e) {
+            const ssize_t r = ::pread(fd, out.data() + b, e - b, (off_t)b);
+            if (r <= 0) { ok.store(false); return; }
+            b += (size_t)r;
+        }
+    });
+    ::close(fd);
+    return ok.load();
+}
+
 bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
     Glb g;
     if (!read_file(path, g.file)) { err = "cannot read " + path; return false; }
-    const std::vector<uint8_t>& f = g.file;
+    const FileBytes& f = g.file;
     auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, &f[o], 4); return v; };
     if (f.size() < 20 || u32(0) != 0x46546C67u) { err = "not a binary glTF (.glb) file"; return false; }
     if (u32(4) != 2) { err = "unsupported glTF container version"; return false; }
@@ -372,7 +386,7 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         // the encoded image: a bufferView of the binary chunk, or (like tiny_gltf) a data: URI / a file next to the .glb
         const uint8_t* enc = nullptr;
         size_t len = 0;
-        std::vector<uint8_t> ext;
+        FileBytes ext;
         const long long bvi = im["bufferView"].int_or(-1);
         const auto& bv = doc["bufferViews"][(size_t)bvi];
         if (bvi >= 0 && bv.is_object()) {
@@ -419,7 +433,6 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
         out_slot = image_slot[src] = (int)scene.images.size() - 1;
         return true;
     };
-
     // ---- primitives -> meshes: SceneManager.cpp:283-457 ----------------------------------------------------
     int mesh_counter = 0;
     for (const Inst& inst : insts) {
@@ -451,18 +464,28 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
                     continue;
                 }
                 idx.resize(ia.count);
-                for (size_t i = 0; i < ia.count; ++i) {
-                    const uint8_t* p = ia.base + i * ia.stride;
-                    if (ia.component == 5121) idx[i] = *p;
-                    else if (ia.component == 5123) { uint16_t v; std::memcpy(&v, p, 2); idx[i] = v; }
-                    else { uint32_t v; std::memcpy(&v, p, 4); idx[i] = v; }
-                }
+                parallel_for(ia.count, 1u << 18, [&](size_t i_begin, size_t i_end) {
+                    for (size_t i = i_begin; i < i_end; ++i) {
+                        const uint8_t* p = ia.base + i * ia.stride;
+                        if (ia.component == 5121) idx[i] = *p;
+                        else if (ia.component == 5123) { uint16_t v; std::memcpy(&v, p, 2); idx[i] = v; }
+                        else { uint32_t v; std::memcpy(&v, p, 4); idx[i] = v; }
+                    }
+                });
             } else {
                 idx.resize(pos_a.count);
                 for (size_t i = 0; i < pos_a.count; ++i) idx[i] = (uint32_t)i;
             }
             if (idx.size() < 3 || idx.size() % 3 != 0) { scene.warnings.push_back("invalid index count, primitive skipped"); continue; }
-            for (uint32_t v : idx) if (v >= pos_a.count) { err = "vertex index out of range in mesh " + hm.name; return false; }
+            {
+                std::atomic<bool> out_of_range{ false };
+                parallel_for(idx.size(), 1u << 18, [&](size_t i_begin, size_t i_end) {
+                    bool bad = false;
+                    for (size_t i = i_begin; i < i_end; ++i) bad |= idx[i] >= pos_a.count;
+                    if (bad) out_of_range.store(true);
+                });
+                if (out_of_range.load()) { err = "vertex index out of range in mesh " + hm.name; return false; }
+            }
 
             Accessor nrm_a, uv_a, tan_a;
             const bool has_n = attrs.has("NORMAL"), has_uv = attrs.has("TEXCOORD_0"), has_t = attrs.has("TANGENT");
@@ -474,9 +497,13 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
             }
 
             const size_t n_tri = idx.size() / 3;
-            hm.vertices.assign(n_tri * 3 * 17, 0.0f);
-            // every triangle is independent and writes its own 51 floats: large meshes are de-indexed by several threads
+            hm.vertices.resize(n_tri * 3 * 17);   // (not zero-filled: DefaultInit; every float is written below)
+            // every triangle is independent and writes its own 51 floats: large meshes are de-indexed by several threads,
+            // each of which also keeps the bounding box of what it wrote (min / max do not depend on the order of evaluation)
+            float pmn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, pmx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            std::mutex box_lock;
             parallel_for(n_tri, 32768, [&](size_t t_begin, size_t t_end) {
+            float lmn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, lmx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
             for (size_t t = t_begin; t < t_end; ++t) {
                 V3 p[3], n[3];
                 float uv[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, tg[3][4];
@@ -519,9 +546,16 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
                     v[3] = n[e].x; v[4] = n[e].y; v[5] = n[e].z;
                     v[6] = tg[e][0]; v[7] = tg[e][1]; v[8] = tg[e][2]; v[9] = tg[e][3];
                     v[10] = uv[e][0]; v[11] = uv[e][1];
+                    v[12] = v[13] = v[14] = v[15] = v[16] = 0.0f;   // normalizedUv, scale: always 0 in the reference's VBO
+                    lmn[0] = std::min(lmn[0], v[0]); lmn[1] = std::min(lmn[1], v[1]); lmn[2] = std::min(lmn[2], v[2]);
+                    lmx[0] = std::max(lmx[0], v[0]); lmx[1] = std::max(lmx[1], v[1]); lmx[2] = std::max(lmx[2], v[2]);
                 }
             }
+            std::lock_guard<std::mutex> lk(box_lock);
+            for (int k = 0; k < 3; ++k) { pmn[k] = std::min(pmn[k], lmn[k]); pmx[k] = std::max(pmx[k], lmx[k]); }
             });
+            std::memcpy(hm.bbox_min, pmn, 12);   // this primitive's own box; made cumulative below
+            std::memcpy(hm.bbox_max, pmx, 12);
 
             // material: SceneManager.cpp:99-193 (factors other than baseColorFactor are parsed but never used by the pass)
             hm.base_color[0] = hm.base_color[1] = hm.base_color[2] = hm.base_color[3] = 1.0f;
@@ -542,16 +576,8 @@ bool load_glb(const std::string& path, HostScene& scene, std::string& err) {
     // ---- cumulative bbox (:476-477,514-527: minBB/maxBB live outside the mesh loop) + C view ----------------
     float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     scene.c_meshes.clear();
-    for (HostMesh& hm : scene.meshes) {
-        // min / max do not depend on the order of evaluation: per-thread partial boxes, merged under a lock
-        std::mutex box_lock;
-        parallel_for(hm.vertices.size() / 17, 1u << 17, [&](size_t v_begin, size_t v_end) {
-            float lmn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, lmx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-            for (size_t v = v_begin; v < v_end; ++v)
-                for (int k = 0; k < 3; ++k) { lmn[k] = std::min(lmn[k], hm.vertices[v * 17 + k]); lmx[k] = std::max(lmx[k], hm.vertices[v * 17 + k]); }
-            std::lock_guard<std::mutex> lk(box_lock);
-            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], lmn[k]); mx[k] = std::max(mx[k], lmx[k]); }
-        });
+    for (HostMesh& hm : scene.meshes) {   // (each mesh's own box was reduced while its vertices were written)
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hm.bbox_min[k]); mx[k] = std::max(mx[k], hm.bbox_max[k]); }
         std::memcpy(hm.bbox_min, mn, 12);
         std::memcpy(hm.bbox_max, mx, 12);
     }

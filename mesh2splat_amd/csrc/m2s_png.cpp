@@ -7,6 +7,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -20,28 +21,35 @@ inline int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// un-filter `h` scanlines of `stride` bytes (each preceded by its filter byte) in place into out
+// un-filter `h` scanlines of `stride` bytes (each preceded by its filter byte) into out.  One loop per filter type and row
+// (PNG spec 9.2), the first pixel of a row — which has no left neighbour — apart; the row above the first one is all zero.
 bool unfilter(const uint8_t* in, size_t in_len, uint8_t* out, uint32_t h, size_t stride, int bpp_bytes) {
     if (in_len < (stride + 1) * (size_t)h) return false;
-    const uint8_t* prev = nullptr;
+    const size_t bpp = (size_t)bpp_bytes, head = std::min(bpp, stride);
+    std::vector<uint8_t> zero_row(stride, 0);
+    const uint8_t* prev = zero_row.data();
     for (uint32_t y = 0; y < h; ++y) {
         const uint8_t ft = in[0];
         const uint8_t* src = in + 1;
         uint8_t* dst = out + (size_t)y * stride;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)bpp_bytes ? dst[i - bpp_bytes] : 0;
-            const int b = prev ? prev[i] : 0;
-            const int c = (prev && i >= (size_t)bpp_bytes) ? prev[i - bpp_bytes] : 0;
-            int v = src[i];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += paeth(a, b, c); break;
-                default: return false;
-            }
-            dst[i] = (uint8_t)v;
+        switch (ft) {
+            case 0: std::memcpy(dst, src, stride); break;
+            case 1:
+                for (size_t i = 0; i < head; ++i) dst[i] = src[i];
+                for (size_t i = bpp; i < stride; ++i) dst[i] = (uint8_t)(src[i] + dst[i - bpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < stride; ++i) dst[i] = (uint8_t)(src[i] + prev[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < head; ++i) dst[i] = (uint8_t)(src[i] + (prev[i] >> 1));
+                for (size_t i = bpp; i < stride; ++i) dst[i] = (uint8_t)(src[i] + ((dst[i - bpp] + prev[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < head; ++i) dst[i] = (uint8_t)(src[i] + prev[i]);   // paeth(0, b, 0) = b
+                for (size_t i = bpp; i < stride; ++i) dst[i] = (uint8_t)(src[i] + paeth(dst[i - bpp], prev[i], prev[i - bpp]));
+                break;
+            default: return false;
         }
         prev = dst;
         in += stride + 1;
@@ -108,7 +116,7 @@ bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err) {
     // encoders leave, which stb_image ignores) is not an error, a stream that ends early is.
     // (deflate expands by at most 1032 : 1: a header must not be able to demand gigabytes that the IDAT bytes cannot fill)
     if (raw_len / 1032 > idat.size() + 1) { err = "PNG data too short for its dimensions"; return false; }
-    std::vector<uint8_t> raw(raw_len);
+    std::vector<uint8_t, DefaultInit<uint8_t>> raw(raw_len);   // (filled by inflate; no zero fill)
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -131,6 +139,25 @@ bool decode_png(const uint8_t* data, size_t len, Image& img, std::string& err) {
     }
 
     img.width = w; img.height = h;
+    // The common kinds — 8 bits per sample, not interlaced, no tRNS — without the per-pixel dispatch below: RGBA is un-filtered
+    // straight into the image; RGB, grey and grey + alpha are un-filtered into a line buffer and widened row by row.
+    if (interlace == 0 && depth == 8 && ctype != 3 && trns.empty()) {
+        const size_t stride = (size_t)w * channels;
+        img.rgba.resize((size_t)w * h * 4);
+        if (ctype == 6) {
+            if (!unfilter(raw.data(), raw.size(), img.rgba.data(), h, stride, bpp_bytes)) { err = "bad PNG filter"; return false; }
+            return true;
+        }
+        std::vector<uint8_t, DefaultInit<uint8_t>> lines(stride * h);
+        if (!unfilter(raw.data(), raw.size(), lines.data(), h, stride, bpp_bytes)) { err = "bad PNG filter"; return false; }
+        const uint8_t* in = lines.data();
+        uint8_t* o = img.rgba.data();
+        const size_t n = (size_t)w * h;
+        if (ctype == 2) for (size_t i = 0; i < n; ++i, in += 3, o += 4) { o[0] = in[0]; o[1] = in[1]; o[2] = in[2]; o[3] = 255; }
+        else if (ctype == 0) for (size_t i = 0; i < n; ++i, in += 1, o += 4) { o[0] = o[1] = o[2] = in[0]; o[3] = 255; }
+        else for (size_t i = 0; i < n; ++i, in += 2, o += 4) { o[0] = o[1] = o[2] = in[0]; o[3] = in[1]; }   // ctype 4
+        return true;
+    }
     img.rgba.assign((size_t)w * h * 4, 255);
 
     auto put_pixel = [&](const uint8_t* line, uint32_t x_in_line, uint32_t X, uint32_t Y) {
