@@ -341,14 +341,19 @@ const char* m2s_io_last_error(void);
  *     kernel (k_emit_big, one workgroup per 1024-fragment chunk); a scene DOMINATED by such triangles falls through
  *     to the multi-pass pipeline;
  *   - otherwise the MULTI-PASS pipeline count -> scan -> offsets -> emit (output-range balanced, any triangle size).
- * MULTIPASS forces the latter, WAVE / TEAM force the single-pass kernel in one of its two forms.  Every setting produces
- * bit-identical output.  Changing the setting forgets the remembered decisions. */
+ *   - fewer than ONE fragment per triangle on average (a mesh far finer than the density asked for; BASELINE config 5):
+ *     the SPARSE form of the single-pass kernel (k_sparse): a cheap conservative test drops the triangles that cannot cover
+ *     a pixel centre before the exact per-triangle phase runs on the survivors; k_fused2 where a workgroup does not fit.
+ * MULTIPASS forces the multi-pass pipeline, WAVE / TEAM / SPARSE force the single-pass kernel in one of its forms.  Every
+ * setting produces bit-identical output.  Changing the setting forgets the remembered decisions. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
        M2S_PIPELINE_WAVE = 2 /* always the single-pass kernel, one-wave-per-batch form (k_fused); multi-pass only if it hands off */,
        M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2), k_fused where a workgroup
-                                does not fit its LDS stream */ };
+                                does not fit its LDS stream */,
+       M2S_PIPELINE_SPARSE = 4 /* always the sparse form of the single-pass kernel (k_sparse) where the scene is large enough for
+                                  it (>= ~172 k triangles), k_fused2 / k_fused where a workgroup does not fit its LDS stream */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
-/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused) or _TEAM (k_fused2); 0 before any. */
+/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2) or _SPARSE (k_sparse); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

@@ -62,6 +62,8 @@ struct m2s_ctx {
     struct RInfo {
         bool decided = false;      // AUTO: single-pass / multi-pass decision taken
         bool multipass = false;    // ... and it was "multi-pass"
+        bool sparse = false;       // AUTO: fewer fragments than triangles, the sparse form of the single-pass kernel (k_sparse)
+        bool sparse_off = false;   // k_sparse reported a workgroup that did not fit its LDS stream: use k_fused2
         bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
@@ -179,6 +181,7 @@ static void free_scene(m2s_ctx* c) {
 // What is remembered about this scene at resolution R (created on first use; the table is bounded: a slider dragged
 // through hundreds of densities simply starts over).
 constexpr int kBandSlots = 64;
+constexpr double kSparseFragsPerTriangle = 1.0;   // AUTO: below this many fragments per triangle the sparse kernel runs
 static m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     auto it = c->rinfo.find(R);
     if (it != c->rinfo.end()) return it->second;
@@ -585,6 +588,11 @@ static hipError_t next_epoch(m2s_ctx* c, uint32_t* out) {
 static bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
     return !(c->pipeline == M2S_PIPELINE_WAVE || ri.team_off);
 }
+// ... or its sparse form (m2s_sparse.hip): meshes with fewer fragments than triangles, large enough for 64-triangle batches
+static bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    return (c->pipeline == M2S_PIPELINE_SPARSE || (c->pipeline == M2S_PIPELINE_AUTO && ri.sparse)) && !ri.sparse_off &&
+           sparse_supported(c->scene.n_tri);
+}
 
 // XCD bands of k_fused2 for this launch: read them if an earlier launch at this R left them behind, otherwise ask this
 // launch to leave them (second lane: never asked to write — two lanes could race on the slot)
@@ -762,7 +770,11 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
     const double predicted = c->frag_per_R2 >= 0.0 ? c->frag_per_R2 * (double)R * (double)R : 0.0;
     if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) {
         ri.decided = true;
-        ri.multipass = (counted ? (double)c->h_total[0] : predicted) >= 11.0 * (double)sc.n_tri;
+        const double frags = counted ? (double)c->h_total[0] : predicted;
+        ri.multipass = frags >= 11.0 * (double)sc.n_tri;
+        // fewer fragments than triangles: most triangles cover no pixel centre, the sparse form drops them cheaply
+        // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
+        ri.sparse = !ri.multipass && frags < kSparseFragsPerTriangle * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
     }
 
     // ---- where do the records go, and how many may be stored? ------------------------------------
@@ -791,14 +803,17 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         // counter and its two status words straight into pinned host memory.
         uint32_t any_big = 0, err = 0;
         bool wrote_bands = false;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const bool team = use_team(c, ri);
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const bool sparse = use_sparse(c, ri);
+            const bool team = !sparse && use_team(c, ri);
             c->h_total[0] = 0;
             c->h_total[1] = 0;
             uint32_t epoch;
             HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
-            if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+            if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                                      c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
+            else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
@@ -808,12 +823,15 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
-            c->last_pipeline = team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-            if (team && !err && wrote_bands) ri.bands_ready = true;
-            if (!(err && team)) break;
-            // a workgroup's fragments did not fit the team kernel's LDS stream (or a wait timed out): the one-wave-per-batch
-            // form has no such limit.  Remember it for this scene and R, forget what the aborted launch listed, try again.
-            ri.team_off = true;
+            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+            if ((team || sparse) && !err && wrote_bands) ri.bands_ready = true;
+            if (err && std::getenv("M2S_DEBUG"))
+                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
+            if (!(err && (team || sparse))) break;
+            // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
+            // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
+            // launch listed, try again.
+            if (sparse) ri.sparse_off = true; else ri.team_off = true;
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
         }
         done = true;
@@ -1013,9 +1031,12 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     uint32_t epoch;
     HIPCHK(c, next_epoch(c, &epoch));
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
-    const bool team = use_team(c, ri);
-    c->last_pipeline = team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-    if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
+    const bool sparse = use_sparse(c, ri);
+    const bool team = !sparse && use_team(c, ri);
+    c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+    if (sparse) launch_sparse(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
+                              c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
+    else if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                             c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
@@ -1414,7 +1435,7 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
 
 m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (!c) return M2S_ERR_INVALID;
-    if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_TEAM) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_SPARSE) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
         c->rinfo.clear();

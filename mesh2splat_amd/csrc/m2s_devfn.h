@@ -50,6 +50,11 @@ __device__ __forceinline__ long long floordiv_pos(long long num, long long den) 
 // ============================================================================================
 // geometry-shader restatement (converterGS.glsl:326-443)
 // ============================================================================================
+// The mesh table is written at upload and never while a conversion runs: a wave-uniform entry may be read through the constant
+// address space (scalar loads, even after the kernel's own stores — see shade_from_tri).
+typedef const __attribute__((address_space(4))) MeshParams* ConstMeshPtr;
+__device__ __forceinline__ ConstMeshPtr kConstMesh(const MeshParams* p) { return (ConstMeshPtr)p; }
+
 struct Geo {
     float xx, xy, xz;  // xAxis = normalised longest edge  (GS:345, 401)
     float nx, ny, nz;  // face normal                      (GS:347)
@@ -95,6 +100,16 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
         g.ou[i] = (pa - bminA) / range;
         g.ov[i] = (pb - bminB) / range;
     }
+}
+
+// geo_setup with the mesh uniforms taken from a mesh-table entry.  MP is `const MeshParams*` (per-lane pointer: six vector
+// loads per lane) or the same pointer in the CONSTANT address space (kConstMesh; wave-uniform mesh: scalar loads, once).
+// Round 3: the triangle phase used the per-lane form everywhere — on BASELINE config 5 its descriptor loads (here and in
+// tri_shade_setup) were 8 k of a 18 k-cycle round (tools/sparse_timing.py).
+template <class MP>
+__device__ __forceinline__ void geo_setup_mp(const float p[9], MP mp, Geo& g) {
+    const float bmin[3] = { mp->bmin[0], mp->bmin[1], mp->bmin[2] }, bmax[3] = { mp->bmax[0], mp->bmax[1], mp->bmax[2] };
+    geo_setup(p, bmin, bmax, g);
 }
 
 // ---- value arithmetic helpers -------------------------------------------------------------------
@@ -404,6 +419,20 @@ struct TriShade {
 };
 static_assert(sizeof(TriShade) == 80, "TriShade must be five float4");
 
+// The same record for triangles whose pixel box is at most 8 x 8 and whose sub-pixel extent is at most 2304 (the only ones the
+// sparse kernel shades itself, m2s_sparse.hip): edge coefficients are differences of snapped coordinates (|.| <= 2304: int16)
+// and the edge values at the box origin stay below 2^24 (int32).  Same field names, same values: shade_from_tri is a template.
+struct TriShadeS {
+    short a1, b1, a2, b2;
+    int e1, e2;
+    float inva, sx, sy, lod0;
+    float4 rot;
+    float lod1, lod2;
+    uint32_t org;
+    uint32_t mesh;
+};
+static_assert(sizeof(TriShadeS) == 64, "TriShadeS must be four float4");
+
 __device__ __forceinline__ float lod_from_grad(float fw, float fh, float dudx, float dvdx, float dudy, float dvdy) {
     const float sx = dudx * fw, tx = dvdx * fh, sy = dudy * fw, ty = dvdy * fh;
     const float r2 = fmaxf(fma_(tx, tx, sx * sx), fma_(ty, ty, sy * sy));
@@ -605,8 +634,8 @@ __device__ __forceinline__ float frac_repeat(float u) {
     return fminf(f, 1.0f);
 }
 
-template <class MP, class TD>
-__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, const TriShade& ts, float out[9]) {
+template <class MP, class TD, class TS>
+__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, const TS& ts, float out[9]) {
     // level selection was done per triangle (tri_shade_setup)
     const uint32_t w = t->w, h = t->h;
     const float f = ts.lod0;
@@ -657,12 +686,10 @@ __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
 // written at upload and never while a conversion runs; saying so lets the compiler use scalar loads (s_load) for the
 // descriptor fields when the pointer is wave-uniform, even after the kernel's own record stores (which otherwise make
 // every later global read a vector load: alias analysis cannot tell the records from the table).
-typedef const __attribute__((address_space(4))) MeshParams* ConstMeshPtr;
-__device__ __forceinline__ ConstMeshPtr kConstMesh(const MeshParams* p) { return (ConstMeshPtr)p; }
 
-template <class MP>
+template <class MP, class TS = TriShade>   // TS: TriShade, or the 64-byte TriShadeS of the sparse kernel (same field names)
 __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, MP mp,
-                                               const TriShade& ts, float4 rec[6], unsigned long long* stamps = nullptr,
+                                               const TS& ts, float4 rec[6], unsigned long long* stamps = nullptr,
                                                const float2* uvl = nullptr /* (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0) kept by the caller */) {
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)

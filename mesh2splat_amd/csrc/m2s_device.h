@@ -111,6 +111,11 @@ uint32_t fused2_band_width(uint32_t n_tri);
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const BandInfo& bands, hipStream_t st);
+// sparse form of the single-pass kernel (m2s_sparse.hip); `bands` as for launch_fused2 (k_fused2's band width: rescaled inside)
+void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
+                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
+                   const BandInfo& bands, hipStream_t st);
+bool sparse_supported(uint32_t n_tri);
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                   unsigned long long* total, uint32_t* status /* [0]=any big [1]=error */, uint32_t epoch, BigItem* biglist,
                   uint32_t* bigmeta /* [0]=count [1]=max fragments [2]=sum of fragments */, hipStream_t st);

@@ -99,8 +99,9 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         load_positions(sc.tri, t, p);
         uvb0 = sc.tri.B0[t];
         uvb1 = sc.tri.B1[t];
-        if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
-        geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+        // (a workgroup inside one mesh — the common case — reads the mesh uniforms with scalar loads)
+        if (uniform_mesh) geo_setup_mp(p, kConstMesh(sc.meshes + m0), g);
+        else { m = find_mesh(sc, sc.tri_first + t); geo_setup_mp(p, sc.meshes + m, g); }
         ok = raster_setup(g, R, rs);
     }
     const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         chain_store(&chain[blockIdx.x], (blockIdx.x == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
     if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
-        tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
+        if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
+        else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
         s.ts.mesh |= m;
         const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
         s.a0 = rs.a[0]; s.b0 = rs.b[0];

@@ -109,8 +109,9 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         load_positions(sc.tri, t, p);
         uvb0 = sc.tri.B0[t];   // only needed for the LODs of covered triangles, but requesting it here
         uvb1 = sc.tri.B1[t];   // puts it in the same memory round trip as the positions
-        if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
-        geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+        // (a wave inside one mesh — the common case — reads the mesh uniforms with scalar loads)
+        if (uniform_mesh) geo_setup_mp(p, kConstMesh(sc.meshes + m0), g);
+        else { m = find_mesh(sc, sc.tri_first + t); geo_setup_mp(p, sc.meshes + m, g); }
         ok = raster_setup(g, R, rs);
     }
     M2S_STAMP(1);  // positions loaded + GS/raster setup
@@ -212,7 +213,8 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     // ---------------- per-triangle fragment constants -> LDS ----------------
     if (cntc) {
         TriShade ts;
-        tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
+        if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, ts);
+        else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
         ts.mesh |= m;   // low 24 bits; the top byte carries the combo sampler's mip levels
         const float4* src = reinterpret_cast<const float4*>(&ts);
 #pragma unroll

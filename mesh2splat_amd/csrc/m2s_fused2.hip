@@ -169,17 +169,21 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     uint32_t m = 0;
     float4 uvb0 = make_float4(0, 0, 0, 0);
     float2 uvb1 = make_float2(0, 0);
+    bool uniform_mesh_w = false;   // the wave's batch lies inside one mesh (m0w): mesh uniforms through scalar loads
+    uint32_t m0w = 0;
     if (has_batch) {
         const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
         const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
         const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+        uniform_mesh_w = uniform_mesh; m0w = m0;
         m = m0;
         if (valid) {
             load_positions(sc.tri, t, p);
             uvb0 = sc.tri.B0[t];
             uvb1 = sc.tri.B1[t];
-            if (!uniform_mesh) m = find_mesh(sc, sc.tri_first + t);
-            geo_setup(p, sc.meshes[m].bmin, sc.meshes[m].bmax, g);
+            // (a wave inside one mesh — the common case — reads the mesh uniforms with scalar loads)
+            if (uniform_mesh) geo_setup_mp(p, kConstMesh(sc.meshes + m0), g);
+            else { m = find_mesh(sc, sc.tri_first + t); geo_setup_mp(p, sc.meshes + m, g); }
             ok = raster_setup(g, R, rs);
         }
     }
@@ -254,7 +258,14 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         const unsigned long long before = band_first ? bands.base[xcd] : 0ull;
         chain_store(&chain[b], (knows ? kFlagPrefix : kFlagAgg) | etag | (((knows ? before : 0ull) + total_w) & kValMask));
     }
-    if (lane == 0) { S.total_w[wave] = total_w; S.total_c[wave] = total_c; }
+    if (lane == 0) {
+        S.total_w[wave] = total_w; S.total_c[wave] = total_c;
+        // deferred triangles make record index != base + stream position for everything after them.  The flag travels WITH
+        // the counts — the fragment phase starts only after every wave has counted — and not with the later expansion: a
+        // strip made of ANOTHER wave's entries does not wait for this wave's expansion and must not read "not yet set"
+        // (round 3: it used to be set after the look-back below; a strip of the next wave's entries could run before that)
+        if (anybig) __hip_atomic_fetch_or(&S.irregular, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     lds_store(&S.counted[wave], 1u);
 
     // ======================= where do my entries go?  counts of the waves before me =======================
@@ -299,7 +310,8 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     if (alive) {
         if (cntc) {
             TriShade ts;
-            tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
+            if (uniform_mesh_w) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0w), uvb0, uvb1, ts);
+            else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, ts);
             ts.mesh |= m;
             const float4* src = reinterpret_cast<const float4*>(&ts);
 #pragma unroll
@@ -322,10 +334,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
                     it.t = t; it.cnt = cnt; it.off = base + out0 + toff;
                     biglist[slot] = it;
                 }
-                if (lane == 0) {
-                    lds_store(&S.irregular, 1u);
-                    __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                if (lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else alive = false;
         }
         const uint32_t tag = (uint32_t)lane << 24;

@@ -1,0 +1,128 @@
+"""-m gpu: the sparse form of the single-pass kernel (k_sparse, m2s_sparse.hip) — meshes with more triangles than fragments.
+Its tier-1 test may only drop triangles that the exact arithmetic leaves without a fragment, so everything here is compared
+with the oracle (counter, records) and, bit for bit, with the workgroup-cooperative kernel on the same scene."""
+import numpy as np
+import pytest
+
+from mesh2splat_amd import synth
+from mesh2splat_amd.converter import Converter
+from mesh2splat_amd.scene import Mesh, Scene
+from parity import assert_records_match
+
+pytestmark = pytest.mark.gpu
+
+
+def convert_with(pipeline, scene, R, cap=0, tri_range=None):
+    c = Converter(0)
+    c.set_pipeline(pipeline)
+    if tri_range:
+        c.set_triangle_range(*tri_range)
+    c.upload_scene(scene)
+    c.set_max_gaussians(cap)
+    total = c.convert(R)
+    total2 = c.convert(R)             # the second conversion reads the XCD band bases the first one left behind
+    rec = c.download()
+    ran = c.last_pipeline
+    c.close()
+    assert total == total2
+    return total, rec, ran
+
+
+def check(scene, R, oracle, what, cap=0, expect="sparse"):
+    total, rec, ran = convert_with("sparse", scene, R, cap)
+    assert ran == expect, (what, ran)
+    ototal, orec, _ = oracle.convert(scene, R, cap=cap, n_threads=8)
+    assert total == ototal, (what, total, ototal)
+    assert_records_match(rec, orec, what)
+    t2, rec2, ran2 = convert_with("team", scene, R, cap)
+    assert t2 == total and np.array_equal(rec.view(np.uint32), rec2.view(np.uint32)), f"{what}: sparse and team kernels differ"
+    return total
+
+
+@pytest.mark.parametrize("n,R,tex", [(128, 256, 256), (128, 97, 64), (150, 450, 0)])
+def test_sub_pixel_sphere(hiplib, oracle, n, R, tex):
+    """0.87 / 0.12 / 2.0 fragments per triangle: most, few and nearly none of the triangles are dropped by tier 1."""
+    check(synth.cube_sphere(n, tex_size=tex), R, oracle, f"sphere n={n} R={R}")
+
+
+@pytest.mark.parametrize("seed,R,size", [(1, 333, 0.004), (2, 1024, 0.002), (3, 64, 0.02)])
+def test_sub_pixel_soup(hiplib, oracle, seed, R, size):
+    """Random triangles: every projection axis, both windings, slivers, uv outside [0, 1]."""
+    scene = synth.random_soup(200_000, seed=seed, tri_size=size, textures=synth.procedural_textures(64, seed))
+    check(scene, R, oracle, f"soup seed={seed} R={R}")
+
+
+def test_flattened_soup_near_axis_ties(hiplib, oracle):
+    """Near-degenerate triangles and near-ties of the projection axis: tier 1 must keep what it cannot decide."""
+    scene = synth.random_soup(200_000, seed=12, tri_size=0.01)
+    scene.meshes[0].vertices[:, 2] *= np.float32(1e-3)
+    v = scene.meshes[0].vertices.reshape(-1, 3, 12)
+    v[::7, :, 2] = v[::7, :, 0] - v[::7, :, 1]          # normals with |nx| = |ny| = |nz| up to rounding
+    m = scene.meshes[0]
+    scene = Scene([Mesh(name=m.name, vertices=m.vertices, base_color=m.base_color, textures=m.textures)])   # new bounding box
+    check(scene, 512, oracle, "flattened soup")
+
+
+def test_several_meshes_cumulative_bbox(hiplib, oracle):
+    """Workgroups that straddle a mesh boundary skip tier 1; later meshes see a larger cumulative bounding box."""
+    meshes = []
+    for k in range(3):
+        v = synth.cube_sphere_vertices(80, radius=1.0, center=(2.5 * k, 0.0, 0.0))
+        meshes.append(Mesh(name=f"s{k}", vertices=v, base_color=(1.0, 0.9, 0.8, 1.0), textures=synth.procedural_textures(64, 5 + k)))
+    check(Scene(meshes), 160, oracle, "three spheres")
+
+
+def test_big_triangles_among_sub_pixel_ones(hiplib, oracle):
+    """Triangles beyond an 8 x 8 pixel box are only counted by k_sparse and emitted by the second stage; order preserved."""
+    soup = synth.random_soup(190_000, seed=21, tri_size=0.003).meshes[0].vertices
+    quad = synth.unit_quad(stride=12).meshes[0].vertices.copy()
+    quad[:, 0:2] = quad[:, 0:2] * 0.3 + 0.2
+    mid = synth.random_soup(200, seed=22, tri_size=0.08).meshes[0].vertices      # (at most 256 deferred triangles: more would send AUTO to the multi-pass pipeline)
+    v = np.concatenate([soup[:300_000], quad, soup[300_000:], mid], 0)
+    scene = Scene([Mesh(name="mix", vertices=v, base_color=(1, 1, 1, 1), textures=synth.procedural_textures(32, 3))])
+    check(scene, 400, oracle, "mixed sizes")
+
+
+def test_cap_and_triangle_range(hiplib, oracle):
+    scene = synth.cube_sphere(128, tex_size=32)
+    total, rec, ran = convert_with("sparse", scene, 256, cap=50_000)
+    ototal, orec, _ = oracle.convert(scene, 256, cap=50_000, n_threads=8)
+    assert ran == "sparse" and total == ototal > 50_000 and len(rec) == 50_000
+    assert_records_match(rec, orec, "cap")
+    # a shard (multi-GPU path): triangles [10 000, 10 000 + 180 000) of the 196 608
+    total, rec, ran = convert_with("sparse", scene, 256, cap=0, tri_range=(10_000, 180_000))
+    ototal, orec, _ = oracle.convert(scene, 256, cap=0, tri_first=10_000, tri_count=180_000, n_threads=8)
+    assert ran == "sparse" and total == ototal
+    assert_records_match(rec, orec, "shard")
+
+
+def test_falls_back_when_a_workgroup_overflows(hiplib, oracle):
+    """A dense scene forced through k_sparse: a workgroup's 512 triangles yield more entries than its LDS stream holds; the
+    conversion is repeated with k_fused2 (and the decision remembered)."""
+    scene = synth.cube_sphere(128, tex_size=32)
+    total, rec, ran = convert_with("sparse", scene, 2048, cap=0)
+    ototal = oracle.convert(scene, 2048, cap=0, count_only=True, n_threads=8)[0]
+    assert ran in ("team", "wave", "multipass") and total == ototal
+
+
+def test_auto_picks_sparse_and_async_submissions(hiplib, oracle):
+    scene = synth.cube_sphere(128, tex_size=64)
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    total = c.convert(200)
+    assert c.last_pipeline == "sparse"
+    want = c.download()
+    ototal, orec, _ = oracle.convert(scene, 200, cap=0, n_threads=8)
+    assert total == ototal
+    assert_records_match(want, orec, "auto")
+    for depth in (1, 3):
+        for _ in range(depth):
+            c.submit(200)
+        for _ in range(depth):
+            assert c.wait() == total
+    assert c.last_pipeline == "sparse"
+    assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32))
+    assert c.convert(1024) == oracle.convert(scene, 1024, cap=0, count_only=True, n_threads=8)[0]      # 14 fragments per triangle
+    assert c.last_pipeline != "sparse"
+    c.close()
