@@ -18,7 +18,8 @@ merged splat buffer.  Reported next to it, outside `value`:
   strong_scaling   ONE scene (C3, and the C4 stand-in) cut into N fragment-balanced triangle ranges: convert + counter
                    exchange ("no_gather": what per-rank .ply slice writers need) and convert + record exchange ("gather").
 N == 1 adds: cold_path (first call on a fresh context, densities never seen before, three rotating scene copies that
-do not fit the Infinity Cache), extra_workloads (C2 stand-in, a 26-fragments-per-triangle mesh, the C4 stand-in),
+do not fit the Infinity Cache), extra_workloads (C2 stand-in, a 26-fragments-per-triangle mesh, the C4 stand-in, BASELINE config 5
+at full size), overlapped (two asynchronous lanes),
 viewer_passes, cpu_baseline.
 
 Prints ONE JSON line on rank 0.
@@ -41,7 +42,7 @@ WORKLOADS = {
     "c3": (289, 2048, 1024),   # BASELINE configs[2] — default
     "c2": (76, 2048, 512),     # SciFiHelmet stand-in (I-2)
     "small": (24, 256, 256),   # CI-sized
-    "c4": ("grid", 1024, 1024),  # Sponza stand-in (I-4): 64 meshes x cube-sphere n=18, 64 materials (single GPU only)
+    "c4": ("grid", 1024, 1024),  # Sponza stand-in (I-4): 64 meshes x cube-sphere n=18 (radius 0.12 s: 6.6 M Gaussians, under the 7 M cap), 64 materials
     "mid": (94, 2048, 1024),   # one mesh, 106 032 triangles, ~26 fragments per triangle (Sponza-like triangle sizes)
 }
 
@@ -56,9 +57,10 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the post-run record all-gather measurement")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline leg")
     ap.add_argument("--no-viewer-extra", action="store_true", help="skip the prepass / depth-sort measurement after the timed region")
-    ap.add_argument("--overlap-extra", action="store_true",
-                    help="after the timed region, also measure two-lane overlapped submission (reported as 'overlapped'; off by "
-                         "default so that a rocprofv3 trace of the default command holds only isolated launches)")
+    ap.add_argument("--no-overlap-extra", action="store_true",
+                    help="skip the two-lane overlapped submission measured after the timed region (reported as 'overlapped'); use it "
+                         "under rocprofv3 --kernel-trace so that the trace holds only isolated launches")
+    ap.add_argument("--no-c5", action="store_true", help="skip BASELINE config 5 at full size (50 M triangles: ~15 s of host-side generation)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the C2 / mid-size / C4 lines (and the C4 strong-scaling run at N > 1)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="N > 1: seconds after which the multi-GPU extras are abandoned and the headline line is printed")
@@ -448,18 +450,56 @@ def cold_path(torch, local_rank, scene, R, steady_sync_ms):
 def extra_workload(torch, dist, local_rank, name, steps=24, warmup=3):
     """One more BASELINE config on this GPU: whole-conversion ms, Gaussians/s, roofline fraction by algorithmic bytes."""
     from mesh2splat_amd import synth
+    if name == "c5":
+        return c5_workload(torch, local_rank)
     n, tex, R = WORKLOADS[name]
-    scene = synth.sphere_grid(4, n=18, tex_size=tex) if n == "grid" else synth.colocated_spheres(1, n, tex)
+    scene = synth.sponza_standin(tex) if n == "grid" else synth.colocated_spheres(1, n, tex)
     rig = Rig(torch, local_rank, scene, R)
     dt, total = timed_loop(torch, dist, False, rig, steps, warmup)
     ms = dt / steps * 1e3
     k = rig.kernel_ms()
     kern = sum(k.values())
     res = {"workload": name, "R": R, "triangles": scene.n_triangles, "meshes": scene.n_meshes, "gaussians": int(total),
-           "stored": int(stored_of(rig)), "ms_per_step": ms, "value": total / (ms * 1e-3), "pipeline": rig.conv.last_pipeline,
+           "stored": int(stored_of(rig)), "ms_per_step": ms, "value": total / (ms * 1e-3), "value_stored": stored_of(rig) / (ms * 1e-3),
+           "pipeline": rig.conv.last_pipeline,
            "kernel_ms": {a: b for a, b in k.items() if b > 0}, "kernels_total_ms": kern,
            "roofline_whole_conversion": whole_conversion_roofline(stored_of(rig), scene.n_triangles, kern)}
     rig.close()
+    return res
+
+
+def c5_workload(torch, local_rank, steps=8):
+    """BASELINE config 5 at FULL size on this one GPU: 4 x cube-sphere n = 1021 = 50 037 168 triangles (7.2 GB of live vertex
+    data), 4096^2 maps, R = 2048, cap lifted (the reference's 7 M envelope is exceeded).  Blocking conversions, kernel times by
+    HIP events; whole-conversion roofline by algorithmic bytes (96 N + 144 T = 9.53 GB)."""
+    import numpy as np
+    from mesh2splat_amd import synth
+    from mesh2splat_amd.converter import Converter
+    t0 = time.perf_counter()
+    scene = synth.c5_scene(1021, 4096)
+    gen_s = time.perf_counter() - t0
+    T = scene.n_triangles
+    conv = Converter(local_rank)
+    t0 = time.perf_counter()
+    conv.upload_scene(scene)
+    up_s = time.perf_counter() - t0
+    conv.set_max_gaussians(0)
+    conv.set_profiling(True)
+    total = conv.convert(2048)
+    conv.convert(2048)
+    wall, kern = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        conv.convert(2048)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        kern.append(sum(conv.last_kernel_ms().values()))
+    ms, kms = float(np.median(wall)), float(np.median(kern))
+    res = {"workload": "c5 (BASELINE config 5 at full size, one GPU)", "R": 2048, "triangles": T, "meshes": scene.n_meshes, "gaussians": int(total),
+           "stored": int(conv.num_stored), "ms_per_step": ms, "value": total / (ms * 1e-3), "value_stored": conv.num_stored / (ms * 1e-3),
+           "pipeline": conv.last_pipeline, "kernels_total_ms": kms, "submission": "one blocking call per step",
+           "host_generation_s": gen_s, "upload_s": up_s,
+           "roofline_whole_conversion": whole_conversion_roofline(conv.num_stored, T, kms)}
+    conv.close()
     return res
 
 
@@ -531,7 +571,7 @@ def main():
     if n == "grid":
         if world > 1:
             raise SystemExit("workload c4 as the headline is single-GPU (it is part of the strong-scaling section at N > 1)")
-        scene = synth.sphere_grid(4, n=18, tex_size=tex)
+        scene = synth.sponza_standin(tex)
         tri_per_mesh = scene.n_triangles
     else:
         scene = synth.colocated_spheres(world, n, tex)
@@ -573,7 +613,7 @@ def main():
     dedicated = rig.kernel_ms()
 
     overlapped = None
-    if a.overlap_extra and not multi and last_pipeline in ("team", "wave"):
+    if not a.no_overlap_extra and not multi and last_pipeline in ("team", "wave", "sparse"):
         conv = rig.conv
         conv.set_async_lanes(2)
         n_ov = max(min(a.steps, 60), 6)
@@ -618,7 +658,7 @@ def main():
     res = None
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        kname = {"team": "k_fused2", "wave": "k_fused"}.get(last_pipeline, "k_emit2")
+        kname = {"team": "k_fused2", "wave": "k_fused", "sparse": "k_sparse"}.get(last_pipeline, "k_emit2")
         emit_ms = kms[dom]
         # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
@@ -658,6 +698,13 @@ def main():
                     t = json.load(f)
                 if t.get("workload") == a.workload and t.get(kname + "_hbm_bytes_per_launch"):
                     res["roofline"]["traffic"] = t.get(kname + "_hbm_bytes_per_launch")
+                    # the counters were taken on ONE build of the library: say which, and whether it is the one running now
+                    from mesh2splat_amd import _lib as _m2slib
+                    import hashlib
+                    with open(_m2slib.LIB_PATH, "rb") as fb:
+                        sha_now = hashlib.sha256(fb.read()).hexdigest()[:16]
+                    res["roofline"]["traffic_binary_sha"] = {"when_measured": t.get("binary_sha", {}).get(kname), "now": sha_now,
+                                                             "same_binary": t.get("binary_sha", {}).get(kname) == sha_now}
                     res["roofline"]["traffic_source"] = ("NOT measured in this run: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from the committed "
                                                          "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
             except Exception:
@@ -717,7 +764,7 @@ def main():
                     one, sR = synth.sphere_row(4, int(os.environ.get("M2S_BENCH_C5P_N", "361")), int(os.environ.get("M2S_BENCH_C5P_TEX", "4096"))), 2048   # (env: test hooks)
                 else:
                     sn, stex, sR = WORKLOADS[sname]
-                    one = synth.sphere_grid(4, n=18, tex_size=stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
+                    one = synth.sponza_standin(stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
                 plan = m2d.shard_ranges_native(one, sR, world)
                 srig = Rig(torch, local_rank, one, sR, tri_range=plan[rank], cap=0, out_rows=0, exchange=exchange)
                 sdt, stotal = timed_loop(torch, dist, True, srig, a.steps, a.warmup)
@@ -807,7 +854,7 @@ def main():
                     res["cold_path"] = {"error": str(e)}
             if not a.no_extra_workloads and a.workload == "c3":
                 res["extra_workloads"] = {}
-                for w in ("c2", "mid", "c4"):
+                for w in ("c2", "mid", "c4") + (() if a.no_c5 else ("c5",)):
                     try:
                         res["extra_workloads"][w] = extra_workload(torch, dist, local_rank, w)
                     except Exception as e:  # noqa: BLE001

@@ -181,7 +181,8 @@ static void free_scene(m2s_ctx* c) {
 // What is remembered about this scene at resolution R (created on first use; the table is bounded: a slider dragged
 // through hundreds of densities simply starts over).
 constexpr int kBandSlots = 64;
-constexpr double kSparseFragsPerTriangle = 1.0;   // AUTO: below this many fragments per triangle the sparse kernel runs
+constexpr double kSparseFragsPerTriangle = 1.5;   // AUTO: below this many fragments per triangle the sparse kernel runs (measured
+                                                  // crossover against k_fused2: above 1.8; a workgroup's stream overflows from ~2.5)
 static m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     auto it = c->rinfo.find(R);
     if (it != c->rinfo.end()) return it->second;
@@ -454,6 +455,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const size_t chain_words = std::max<size_t>(n_fused_waves(n_tri), 1);
     const size_t o_meshes = take(n_mp * sizeof(MeshParams));
     const size_t o_mesh_first = take(mesh_first.size() * sizeof(uint32_t));
+    const size_t o_mesh_of8 = take(((np + 7) / 8 + 1) * sizeof(uint2));
     const size_t o_cnt = take(np * sizeof(uint32_t));
     const size_t o_off = take((np + 1) * sizeof(uint32_t));
     const size_t o_partials = take(std::max<size_t>(n_count_blocks(n_tri), 1) * sizeof(uint32_t));
@@ -529,6 +531,8 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     HIPCHK(c, hipMemcpyAsync(c->d_mesh_first, mesh_first.data(), mesh_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     c->scene.meshes = c->d_meshes;
     c->scene.mesh_first = c->d_mesh_first;
+    c->scene.mesh_of8 = (const uint2*)(A + o_mesh_of8);
+    launch_mesh_table(c->scene, (uint2*)(A + o_mesh_of8), c->stream);   // (after mesh_first: same stream)
 
     // ---- work buffers -----------------------------------------------------------------------------
     c->d_cnt = (uint32_t*)(A + o_cnt);
@@ -772,7 +776,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         ri.decided = true;
         const double frags = counted ? (double)c->h_total[0] : predicted;
         ri.multipass = frags >= 11.0 * (double)sc.n_tri;
-        // fewer fragments than triangles: most triangles cover no pixel centre, the sparse form drops them cheaply
+        // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
         // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
         ri.sparse = !ri.multipass && frags < kSparseFragsPerTriangle * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
     }

@@ -366,6 +366,15 @@ __device__ __forceinline__ uint32_t find_mesh(const SceneDev& sc, uint32_t gt) {
     return lo;
 }
 
+// Mesh of the range of local triangles [t0, t_last] (t0 a multiple of 8, wave-uniform) and whether the whole range lies in it:
+// one 8-byte load through the constant address space (the table is written at upload, never during a conversion).
+__device__ __forceinline__ uint32_t mesh_of_range(const SceneDev& sc, uint32_t t0, uint32_t t_last, bool& uniform) {
+    const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)sc.mesh_of8;
+    const uint32_t m = q[2u * (t0 >> 3)], end = q[2u * (t0 >> 3) + 1u];
+    uniform = end > t_last;
+    return m;
+}
+
 __device__ __forceinline__ bool setup_raster_for(const SceneDev& sc, uint32_t t, uint32_t mesh_hint, bool uniform_mesh,
                                                  uint32_t R, Raster& rs) {
     float p[9];

@@ -65,6 +65,10 @@ struct SceneDev {
     TriPlanes tri;
     const MeshParams* meshes;
     const uint32_t* mesh_first;  // n_meshes+1 prefix of GLOBAL triangle indices
+    const uint2* mesh_of8;       // per 8 local triangles: {mesh of local triangle 8k, local index one past that mesh's last
+                                 // triangle}: ONE scalar load tells a wave / workgroup its mesh and whether its range lies
+                                 // inside it (round 3; before: a binary search over mesh_first = log2(meshes) + 1 dependent
+                                 // scalar loads in front of every batch's position loads)
     uint32_t n_meshes;
     uint32_t n_tri;              // triangles resident on this device (the shard)
     uint32_t tri_first;          // global index of local triangle 0
@@ -73,6 +77,7 @@ struct SceneDev {
 // ---- launchers (all asynchronous on `st`) ----------------------------------------------------
 void launch_repack(const float* d_aos, uint32_t stride_floats, uint32_t n_tri_src, uint32_t src_first,
                    uint32_t n, uint32_t dst_first, TriPlanes dst /*non-const view*/, hipStream_t st);
+void launch_mesh_table(const SceneDev& sc, uint2* table, hipStream_t st);   // fills mesh_of8 (ceil(n_tri / 8) entries)
 void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh,
                       hipStream_t st);
 void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m, uint32_t w, uint32_t h, uint32_t* dst,

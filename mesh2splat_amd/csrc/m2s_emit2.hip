@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     const uint32_t t = blockBase + threadIdx.x;
     const bool valid = t < sc.n_tri;
     const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
-    const uint32_t m0 = find_mesh(sc, sc.tri_first + blockBase);
-    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+    bool uniform_mesh;
+    const uint32_t m0 = mesh_of_range(sc, blockBase, lastT, uniform_mesh);   // one scalar load (was: a binary search)
 
     float p[9];
     Geo g;

@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
     const uint32_t t = t0 + lane;
     const bool valid = (uint32_t)lane < tpw && t < sc.n_tri;
     const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
-    const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
-    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+    bool uniform_mesh;
+    const uint32_t m0 = mesh_of_range(sc, t0, lastT, uniform_mesh);   // one scalar load (was: a binary search)
 
     M2S_STAMP(0);
     // ---------------- triangle phase ----------------

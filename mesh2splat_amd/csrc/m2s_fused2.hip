@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     uint32_t m0w = 0;
     if (has_batch) {
         const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
-        const uint32_t m0 = find_mesh(sc, sc.tri_first + t0);
-        const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+        bool uniform_mesh;
+        const uint32_t m0 = mesh_of_range(sc, t0, lastT, uniform_mesh);   // one scalar load (was: a binary search)
         uniform_mesh_w = uniform_mesh; m0w = m0;
         m = m0;
         if (valid) {

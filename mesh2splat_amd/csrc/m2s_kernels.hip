@@ -103,6 +103,19 @@ void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m,
     hipLaunchKernelGGL(k_combo, dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a, n, m, w, h, dst);
 }
 
+// mesh_of8[k] = {mesh of local triangle 8 k, local index one past the last triangle of that mesh (clamped to the shard)}
+__global__ void __launch_bounds__(kBlock) k_mesh_table(SceneDev sc, uint2* __restrict__ table) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k * 8u >= sc.n_tri) return;
+    const uint32_t m = find_mesh(sc, sc.tri_first + k * 8u);
+    const unsigned long long end = (unsigned long long)sc.mesh_first[m + 1] - sc.tri_first;
+    table[k] = make_uint2(m, (uint32_t)(end < sc.n_tri ? end : sc.n_tri));
+}
+void launch_mesh_table(const SceneDev& sc, uint2* table, hipStream_t st) {
+    const uint32_t n = (sc.n_tri + 7u) / 8u;
+    if (n) hipLaunchKernelGGL(k_mesh_table, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, sc, table);
+}
+
 void launch_mip_level(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh,
                       hipStream_t st) {
     uint32_t n = dw * dh;
@@ -118,8 +131,8 @@ __global__ void __launch_bounds__(kBlock) k_count(SceneDev sc, uint32_t R, uint3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = blockIdx.x * kTriPerBlock;
     const uint32_t lastT = min(blockBase + kTriPerBlock, sc.n_tri) - 1;
-    const uint32_t m0 = find_mesh(sc, sc.tri_first + blockBase);
-    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+    bool uniform_mesh;
+    const uint32_t m0 = mesh_of_range(sc, blockBase, lastT, uniform_mesh);   // one scalar load (was: a binary search)
     uint32_t sum = 0;
     for (int it = 0; it < kTriPerBlock / kBlock; ++it) {
         const uint32_t t = blockBase + it * kBlock + threadIdx.x;

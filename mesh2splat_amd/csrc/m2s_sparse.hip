@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
 
     // ======================= tier 1: every candidate, cheap and conservative =======================
     const uint32_t lastT = min(t_wg + kSpCand, sc.n_tri) - 1u;
-    const uint32_t m0 = find_mesh(sc, sc.tri_first + t_wg);
-    const bool uniform_mesh = (m0 + 1 >= sc.n_meshes) || (sc.mesh_first[m0 + 1] > sc.tri_first + lastT);
+    bool uniform_mesh;
+    const uint32_t m0 = mesh_of_range(sc, t_wg, lastT, uniform_mesh);   // one scalar load (was: a binary search)
     unsigned long long passm[kSpPer];
     bool pass[kSpPer];
     {
@@ -306,8 +306,10 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         for (int i = 0; i < 9; ++i) p[i] = pn[i];
         const float4 uvb0 = uvn0;
         const float2 uvb1 = uvn1;
+#ifndef M2S_SPARSE_NO_PREFETCH
         r_next = claim_round();
         request_round(r_next);
+#endif
         Geo g;
         Raster rs;
         rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
@@ -459,6 +461,10 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         if (stamp) SP_T(20, SP_NOW() - q0);   // + entries written
         sp_store(&S.expanded[r], 1u);   // release (set even on error so that nobody waits for it)
         if (!alive) break;
+#ifdef M2S_SPARSE_NO_PREFETCH   // A/B switch: request a round's inputs only when it is about to be computed
+        r_next = claim_round();
+        request_round(r_next);
+#endif
     }
 
     // ======================= fragment phase: strips of the workgroup's stream =======================

@@ -141,6 +141,35 @@ def sphere_grid(n_meshes_side: int = 4, n: int = 18, tex_size: int = 1024, spaci
     return Scene(meshes)
 
 
+def sponza_standin(tex_size: int = 1024, seed: int = SEED, stride: int = 12) -> Scene:
+    """I-4 as BASELINE config 4 needs it: 64 meshes x 3 888 triangles, 64 materials, and — what SURVEY 8(d) demands and the
+    survey's own radius (0.2 s: 8 266 992 Gaussians at R = 1024) does not deliver — FEWER Gaussians than the reference's
+    7 000 000 cap, so that parity is defined (beyond the cap the reference keeps an arrival-order-dependent subset).
+    radius 0.12 s: 6 612 408 Gaussians at R = 1024 (oracle count; the first four meshes, whose cumulative bounding box is
+    still one sphere wide in two axes, contribute 5.7 M of them whatever the radius)."""
+    return sphere_grid(4, n=18, tex_size=tex_size, spacing=1.0, radius_frac=0.12, seed=seed, stride=stride)
+
+
+def c5_scene(n: int = 1021, tex_size: int = 4096, count: int = 4, seed: int = SEED, cache: str | None = None) -> Scene:
+    """I-5 at FULL size (BASELINE config 5): `count` cube-spheres of 12 n^2 triangles in a row (n = 1021: 50 037 168 triangles,
+    7.2 GB of live vertex data), each with its own `tex_size`^2 maps.  sphere_row's layout, but ONE sphere is generated and
+    shifted in fp32 (one sphere takes ~35 s of numpy; positions differ from sphere_row's in the last bit); `cache`: optional .npy path for repeated runs inside one session."""
+    import os
+    if cache and os.path.exists(cache):
+        base = np.load(cache)
+    else:
+        base = cube_sphere_vertices(n, radius=1.0, center=(0.0, 0.0, 0.0), stride=12)
+        if cache:
+            np.save(cache, base)
+    meshes = []
+    for k in range(count):
+        v = base.copy()
+        v[:, 0] += np.float32(2.5 * k)
+        tex = procedural_textures(tex_size, seed + k) if tex_size else {}
+        meshes.append(Mesh(name=f"sphere_{k}", vertices=v, base_color=(1.0, 1.0, 1.0, 1.0), textures=tex))
+    return Scene(meshes)
+
+
 def sphere_row(count: int = 4, n: int = 361, tex_size: int = 4096, seed: int = SEED, stride: int = 12) -> Scene:
     """I-5 proxy (BASELINE config 5 at 1/8 of its triangles by default): `count` cube-spheres of 12 n^2 triangles in a row,
     each with its own maps; the cumulative bbox grows mesh by mesh, so later meshes cover fewer pixels each."""

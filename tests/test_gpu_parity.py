@@ -64,7 +64,7 @@ def test_unit_quad_textured(conv, oracle, R):
     assert_records_match(rec, orec, f"textured quad R={R}")
 
 
-@pytest.mark.parametrize("n,R,tex", [(8, 64, 0), (24, 256, 128), (76, 512, 512)])
+@pytest.mark.parametrize("n,R,tex", [(8, 64, 0), (24, 256, 128), (76, 512, 2048)])      # the last one: BASELINE config 2's stand-in (I-2) at its stated size
 def test_cube_sphere(conv, oracle, n, R, tex):
     scene = synth.cube_sphere(n, tex_size=tex)
     total, rec, ototal, orec = run_both(conv, oracle, scene, R)

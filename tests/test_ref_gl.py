@@ -76,3 +76,15 @@ def test_default_sampler_and_mipmaps_differ_within_known_bounds(oracle):
         assert d.max() <= (0 if l == 0 else 2), (l, d.max())
     lvl1 = np.abs(g["mips"][1].astype(int) - chain[int(offs[1]): int(offs[1]) + 32 * 32].reshape(32, 32, 4).astype(int))
     assert 0.15 < (lvl1 > 0).mean() < 0.35               # the tie cases of the 2x2 average
+
+
+def test_c4_standin_counter_and_coverage_on_llvmpipe(oracle):
+    """BASELINE config 4's stand-in at its stated size (64 meshes, 248 832 triangles, R = 1024): the reference's host code and
+    unmodified shaders on a real GL give the oracle's counter (6 612 408 < the 7 M cap) and the oracle's covered pixels."""
+    scene = synth.sponza_standin(32)
+    g = refgl.run(scene, 1024)
+    if g is None:
+        pytest.skip("no software GL context on this machine")
+    total, _, keys = oracle.convert(scene, 1024, cap=0, want_keys=True, n_threads=8)
+    assert g["counter"] == total == 6_612_408 and g["cap"] == 7_000_000
+    assert np.array_equal(np.sort(refgl.coverage_keys(scene, g["coverage"])), np.sort(keys))

@@ -55,6 +55,10 @@ def live_cases():
     yield "soup_flat", synth.random_soup(200, seed=4), 64, dict(with_normals=False, with_tangents=False)
     yield "quad", synth.unit_quad(), 33, {}
     yield "cap_overflow", synth.random_soup(2500, seed=8, textures=synth.procedural_textures(8, 1)), 32, dict(indexed=False)
+    # BASELINE config 4's stand-in at its stated size (64 meshes / 64 materials, 248 832 triangles, R = 1024; 32^2 maps keep the
+    # .glb small): the reference's per-mesh uniform path (ConversionPass.cpp:50-52,77-116) run 64 times for real, 6 612 408
+    # fragments under the 7 M cap — counter, cap, SSBO size and every record bit-identical to the oracle
+    yield "c4_standin", synth.sponza_standin(32), 1024, dict(indexed=False)
 
 
 @pytest.mark.skipif(not refhost.pipeline_available(), reason="oracle/_ref/ref_pipeline_check not built (needs /root/reference)")
@@ -64,10 +68,12 @@ def test_oracle_matches_reference_pipeline_live(tmp_path, hiplib, oracle, case):
     glb = str(tmp_path / (name + ".glb"))
     gltf_io.write_glb(scene, glb, **kw)
     overflow = name == "cap_overflow"
-    ply = None if overflow else str(tmp_path / "ref.ply")
+    ply = None if overflow or name == "c4_standin" else str(tmp_path / "ref.ply")
     ref = refhost.run_pipeline(glb, R, str(tmp_path), ply_path=ply, fmt=0, std=0.65)
     rec = check_against_oracle(oracle, ref, gltf_io.load_glb(glb), R)
-    if overflow:
+    if name == "c4_standin":
+        assert ref["counter"] == 6_612_408 == len(rec) and ref["max_gaussians"] == 7_000_000
+    elif overflow:
         assert ref["counter"] > ref["max_gaussians"] == len(rec)            # counter keeps counting past the cap (FS:46-51)
     else:
         mine = str(tmp_path / "o.ply")

@@ -16,7 +16,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from mesh2splat_amd import synth                      # noqa: E402
 from mesh2splat_amd.converter import Converter        # noqa: E402
-from mesh2splat_amd.scene import Mesh, Scene          # noqa: E402
 
 
 def log(*a):
@@ -29,21 +28,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1021
 tex = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 R, count = 2048, 4
 
-_cache = f"/tmp/c5_sphere_{n}.npy"      # (repeated runs inside one profiling session: 37 s of host-side generation each otherwise)
-if os.path.exists(_cache):
-    base = np.load(_cache)
-else:
-    base = synth.cube_sphere_vertices(n, radius=1.0, center=(0.0, 0.0, 0.0), stride=12)
-    if os.environ.get("C5_CACHE"):
-        np.save(_cache, base)
-log("one sphere generated", base.shape)
-meshes = []
-for k in range(count):          # synth.sphere_row, without generating the same sphere four times
-    v = base.copy()
-    v[:, 0] += np.float32(2.5 * k)
-    meshes.append(Mesh(name=f"sphere_{k}", vertices=v, base_color=(1.0, 1.0, 1.0, 1.0), textures=synth.procedural_textures(tex, synth.SEED + k)))
-del base
-scene = Scene(meshes)
+scene = synth.c5_scene(n, tex, count, cache=f"/tmp/c5_sphere_{n}.npy" if os.environ.get("C5_CACHE") or os.path.exists(f"/tmp/c5_sphere_{n}.npy") else None)
 T = scene.n_triangles
 log("scene ready:", T, "triangles,", sum(m.vertices.nbytes for m in scene.meshes) / 1e9, "GB of vertices")
 

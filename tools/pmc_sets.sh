@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 100 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_$i -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_$i.log 2>&1 || echo "pass $i failed/timeout: $set"
+  timeout 100 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${TAG}_$i -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap-extra --no-c5 > $R/gpurun_out/${TAG}_$i.log 2>&1 || echo "pass $i failed/timeout: $set"
 done
 python $R/tools/pmc_summary.py $R/gpurun_out/${TAG}_*/f_counter_collection.csv > $R/gpurun_out/${TAG}_summary.json
 python -c "
