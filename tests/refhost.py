@@ -170,14 +170,26 @@ def parse_pipeline_dump(blob: bytes):
     return dict(counter=counter, max_gaussians=cap, ssbo_bytes=ssbo, records=rec)
 
 
-def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, out_path: str = None):
+DROPIN_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_check")
+
+
+def dropin_available() -> bool:
+    return os.path.isfile(DROPIN_BIN) and os.access(DROPIN_BIN, os.X_OK)
+
+
+def run_dropin(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65):
+    """The reference's loader + oracle/ref_dropin/ConversionPassHip.cpp (libm2s_hip.so) + the reference's exportPly; needs a GPU."""
+    return run_pipeline(glb_path, R, tmp_dir, ply_path, fmt, std, out_path=os.path.join(tmp_dir, "ref_dropin.bin"), exe=DROPIN_BIN)
+
+
+def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, out_path: str = None, exe: str = None):
     out = out_path or os.path.join(tmp_dir, "ref_pipeline.bin")
-    cmd = [PIPE_BIN, glb_path, str(int(R)), out]
+    cmd = [exe or PIPE_BIN, glb_path, str(int(R)), out]
     if ply_path:
         cmd += [ply_path, str(int(fmt)), "%.9g" % float(np.float32(std))]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
-        raise RuntimeError(f"ref_pipeline_check failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-400:]}")
+        raise RuntimeError(f"{os.path.basename(cmd[0])} failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-400:]}")
     with open(out, "rb") as f:
         return parse_pipeline_dump(f.read())
 

@@ -96,3 +96,10 @@ def test_gfx950_has_no_image_sampling(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "image/texture API not supported" in r.stderr
+
+
+def test_integration_md_quotes_the_compiled_dropin():
+    """INTEGRATION.md's reference-side replacement is the file oracle/Makefile compiles into oracle/_ref/ref_dropin_check."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = open(os.path.join(root, "oracle", "ref_dropin", "ConversionPassHip.cpp")).read()
+    assert body in open(os.path.join(root, "INTEGRATION.md")).read()
