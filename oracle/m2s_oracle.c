@@ -353,10 +353,24 @@ typedef struct {
     uint64_t first_tri, n_tri;
 } mesh_t;
 
+/* DIAGNOSTIC switch (never set by the parity tests): 1 = compute the level of detail the way Mesa llvmpipe does,
+ * lambda = 0.5 * fast_log2(rho^2) with fast_log2(x) = exponent(x) + (mantissa(x) - 1) — a piecewise-LINEAR log2
+ * (gallivm lp_build_fast_log2), up to 0.043 below the true log2.  tools/ref_gl_decompose.py measured it: with this one
+ * substitution the oracle reproduces llvmpipe's fp32 sampler to 4e-7 on minified textures (tests/test_ref_gl.py); without it
+ * the two differ by up to 2e-2 on noise.  The pinned semantics stay the specification's log2 (GL 4.6 core 8.14.1, eq. 8.8). */
+static int g_lod_mode = 0;
+void orc_debug_set_lod_mode(int mode) { g_lod_mode = mode; }
+
 /* level-of-detail for one texture: GL 4.6 core 8.14.1 eq. 8.7-8.8, derivatives exact (affine) */
 static float lod_lambda(const tex_t* t, float dudx, float dvdx, float dudy, float dvdy) {
     float sx = dudx * (float)t->w, tx = dvdx * (float)t->h;
     float sy = dudy * (float)t->w, ty = dvdy * (float)t->h;
+    if (g_lod_mode == 1) {
+        const float r2 = fmaxf(sx * sx + tx * tx, sy * sy + ty * ty);
+        int e;
+        const float m = frexpf(r2, &e);          /* r2 = m * 2^e, m in [0.5, 1) */
+        return r2 > 0.0f ? 0.5f * ((float)(e - 1) + (2.0f * m - 1.0f)) : -126.0f;
+    }
     float rx = sqrtf(sx * sx + tx * tx), ry = sqrtf(sy * sy + ty * ty);
     float rho = fmaxf(rx, ry);
     return log2f(rho);

@@ -90,6 +90,8 @@ int orc_debug_gs(const float* v0, const float* v1, const float* v2, const float 
                  uint32_t R, float ndc_xy[6], float scale_xyz[3], float rot_wxyz[4]);
 uint64_t orc_debug_raster(const float ndc_xy[6], uint32_t R, uint64_t max_frag, int32_t* xy, float* l12, float grad[4]);
 float orc_debug_lod(uint32_t w, uint32_t h, float dudx, float dvdx, float dudy, float dvdy);
+/* diagnostic only: 0 = pinned (log2 of rho), 1 = Mesa llvmpipe's 0.5 * fast_log2(rho^2); see m2s_oracle.c */
+void orc_debug_set_lod_mode(int mode);
 void orc_debug_sample(const orc_scene* sc, uint32_t mesh, int slot, float u, float v, float lambda, float out[4]);
 void orc_debug_fs(const orc_scene* sc, uint32_t mesh, const float varyings[12], const float lam[3],
                   const float scale_xy[2], const float rot_wxyz[4], float record[ORC_RECORD_FLOATS]);

@@ -72,6 +72,8 @@ def lib():
                                    C.c_void_p]
         L.orc_debug_fs.restype = None
         L.orc_debug_fs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_debug_set_lod_mode.restype = None
+        L.orc_debug_set_lod_mode.argtypes = [C.c_int]
         L.orc_quat_cast.restype = None
         L.orc_quat_cast.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_prepass.restype = C.c_uint64

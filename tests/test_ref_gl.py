@@ -88,3 +88,27 @@ def test_c4_standin_counter_and_coverage_on_llvmpipe(oracle):
     total, _, keys = oracle.convert(scene, 1024, cap=0, want_keys=True, n_threads=8)
     assert g["counter"] == total == 6_612_408 and g["cap"] == 7_000_000
     assert np.array_equal(np.sort(refgl.coverage_keys(scene, g["coverage"])), np.sort(keys))
+
+
+def test_minification_matches_llvmpipe_once_its_lod_approximation_is_applied(oracle):
+    """Full-record agreement on the MINIFICATION path (tools/ref_gl_decompose.py, profiles/r03/ref_gl_decomposition.json).
+    The 2e-2 between the pinned trilinear filter and llvmpipe on noise textures decomposes into (a) llvmpipe's level of detail
+    lambda = 0.5 fast_log2(rho^2) with a piecewise-LINEAR log2 (up to 0.043 below log2 rho), (b) its 8-bit filter weights,
+    (c) glGenerateMipmap's rounding of ties, (d) its plane-equation interpolation of the texture coordinates.  Remove (b) with
+    llvmpipe's fp32 sampler, (c) with textures whose 2x2 averages are exact integers through level 3, (d) with a quad whose
+    coordinates are exact, and apply (a) to the oracle through its DIAGNOSTIC switch: what is left is 3e-7 — the pinned level
+    selection, texel addressing, bilinear weights and level blend ARE what a real GL computes; only its log2 is approximate."""
+    base = synth.procedural_textures(64)
+    tie_free = {k: (v & np.uint8(0xC0)) for k, v in base.items()}          # multiples of 64: levels 1..3 are exact
+    L = oracle.lib()
+    try:
+        L.orc_debug_set_lod_mode(1)
+        for R in (24, 12):                                                 # lambda 1.4 (levels 1+2), 2.4 (levels 2+3)
+            r = _cmp(synth.unit_quad(tie_free), R, oracle, float_sampler=True)
+            assert r["gl_counter"] == r["oracle_counter"] == R * R
+            assert r["color"]["max_abs"] <= 2e-6 and r["pbr"]["max_abs"] <= 2e-6 and r["normal"]["max_abs"] <= 4e-6, r
+        L.orc_debug_set_lod_mode(0)
+        r = _cmp(synth.unit_quad(tie_free), 24, oracle, float_sampler=True)
+        assert 1e-3 < r["color"]["max_abs"] < 2e-2                         # the pinned log2 against llvmpipe's: the LOD term alone
+    finally:
+        L.orc_debug_set_lod_mode(0)
