@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CTL = "cpu"   # where the control-plane tensors of torch.distributed live: "cpu" on the gloo process group (default), "cuda" on nccl
 
 WORKLOADS = {
     # name: (cube-sphere n, texture size, R)
@@ -363,7 +364,7 @@ def timed_loop(torch, dist, multi, rig, steps, warmup, sync_steps=False):
     sync()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=CTL)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, total
@@ -503,6 +504,25 @@ def c5_workload(torch, local_rank, steps=8):
     return res
 
 
+class stdout_to_stderr:
+    """gloo and librccl announce themselves on C stdout; the driver reads ONE JSON line from this process's stdout.  While the
+    process group / the communicator come up, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -522,17 +542,35 @@ def main():
     torch.cuda.set_device(local_rank)
     multi = world > 1 or a.force_dist
     exchange = None
+    phases = {}          # multi-GPU: how long each bring-up step took on this rank, and every error met on the way (-> the JSON line)
+    dist_errors = []
+    global CTL
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own account of a failure goes to stderr
+        # ONE user of RCCL per process: the C-ABI communicator (m2s_dist_*), which carries the data path.  torch.distributed only
+        # bootstraps (the 128-byte id), barriers and reduces the timings, on CPU tensors over gloo — it does not bring up a second
+        # set of RCCL communicators next to ours (M2S_BENCH_PG=nccl restores that; the torch.distributed FALLBACK exchange below
+        # switches to it, because it moves device memory through torch).
+        backend = os.environ.get("M2S_BENCH_PG", "gloo")
+        t_pg = time.perf_counter()
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                CTL = "cuda"
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                CTL = "cpu"
+            dist.barrier()
+        phases["control_plane"] = backend
+        phases["control_plane_init_s"] = time.perf_counter() - t_pg
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
         # rank 0's RCCL id reaches the other ranks through the process group that torchrun set up — together with a flag: if rank 0
         # cannot get one (no librccl), EVERY rank learns it here, before anybody enters a collective of the C-ABI communicator.
         # From here on the data path talks to RCCL through the C ABI (m2s_dist_*), not through torch.distributed.
-        idt = torch.zeros(129, dtype=torch.uint8, device="cuda")
+        idt = torch.zeros(129, dtype=torch.uint8, device=CTL)
         if rank == 0:
             try:
                 if os.environ.get("M2S_BENCH_FORCE_TORCH_EXCHANGE"):      # (test hook for the fallback below)
@@ -542,6 +580,7 @@ def main():
                 idt[0] = 1
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
+                dist_errors.append(f"rank 0: m2s_dist_unique_id: {e!r}")
         dist.broadcast(idt, src=0)
         idh = idt.cpu().numpy()
         exchange, ok = None, 0
@@ -549,18 +588,36 @@ def main():
             def bootstrap(_):
                 return bytes(idh[1:].tobytes())
             bootstrap.provides_id = True
+            t_comm = time.perf_counter()
             try:
-                exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
+                with stdout_to_stderr():
+                    exchange = m2d.RcclExchange(local_rank, rank, world, bootstrap)
                 ok = 1
+                phases["rccl_comm_init_s"] = time.perf_counter() - t_comm
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
+                dist_errors.append(f"rank {rank}: m2s_dist_create: {e!r}")
                 exchange, ok = None, 0
-        okt = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        okt = torch.tensor([ok], dtype=torch.int32, device=CTL)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 0:           # on ANY rank: every rank switches, or the collectives would not match
             if exchange is not None:
                 exchange.close()
+            if CTL != "cuda":              # the fallback moves device memory through torch: it needs the nccl process group
+                dist.barrier()
+                dist.destroy_process_group()
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                CTL = "cuda"
+                phases["control_plane"] = "nccl (re-initialised for the torch.distributed fallback exchange)"
             exchange = m2d.TorchExchange(rank, world)
+        if exchange is not None:           # the first exchange of all: 8 bytes per rank, timed on its own
+            t_x = time.perf_counter()
+            try:
+                exchange.all_gather_counts(rank)
+                phases["first_count_exchange_ms"] = (time.perf_counter() - t_x) * 1e3
+            except Exception as e:  # noqa: BLE001
+                dist_errors.append(f"rank {rank}: first counter exchange: {e!r}")
+                print(f"[rank {rank}] first counter exchange failed: {e!r}", file=sys.stderr, flush=True)
         # librccl announces itself through C stdio ("Librccl path : ..."); push that out now so that the JSON line
         # stays the LAST line of stdout
         import ctypes
@@ -584,7 +641,7 @@ def main():
               out_rows=0 if multi else None, exchange=exchange)
     T_local = rig.conv.num_triangles
     dt, total = timed_loop(torch, dist, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
-    ntot = torch.tensor([total], dtype=torch.int64, device="cuda")
+    ntot = torch.tensor([total], dtype=torch.int64, device=CTL)
     if multi:
         dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
     n_all = int(ntot.item())
@@ -709,6 +766,9 @@ def main():
                                                          "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
             except Exception:
                 pass
+    if rank == 0 and multi:
+        res["multi_gpu_bringup"] = {**phases, "exchange": getattr(exchange, "kind", None), "errors": dist_errors,
+                                    "what": "rank 0's timings of the bring-up steps; errors: every m2s_dist_* failure met so far (text of m2s_dist_last_error)"}
     # The multi-GPU extras below contain collectives that have never run on more than one GPU by the builder.  Should one of
     # them hang, every rank leaves after --extras-timeout seconds and rank 0 still prints the (complete) headline line.
     watchdog = None
@@ -740,7 +800,7 @@ def main():
                 exchange.gather_records_t(rig.out, counts, merged, -1, rig.stream)
             rig.drain_counts()
             torch.cuda.synchronize(); dist.barrier()
-            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=CTL)
             dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
             gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
                       "bytes_received_per_rank": 96 * (offs[-1] - counts[rank]),
@@ -784,12 +844,12 @@ def main():
                         exchange.gather_records_t(srig.out, scounts, merged, -1, srig.stream)
                     srig.drain_counts()
                     torch.cuda.synchronize(); dist.barrier()
-                    gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device="cuda")
+                    gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=CTL)
                     dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
                     entry["gather"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": soffs[-1] / float(gdt.item()),
                                        "what": "convert + all-pairs record exchange into the merged buffer on every rank"}
                     # the merged buffer must be the single-GPU output: checksum of checksums across ranks
-                    chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device="cuda")
+                    chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device=CTL)
                     allchk = [torch.zeros_like(chk) for _ in range(world)]
                     dist.all_gather(allchk, chk)
                     entry["gather"]["merged_identical_on_all_ranks"] = bool(all(int(x.item()) == int(chk.item()) for x in allchk))
@@ -816,13 +876,13 @@ def main():
                                 torch.cuda.synchronize(); dist.barrier()
                                 d0 = time.perf_counter()
                                 dn, doff = exchange.sort_by_depth(srig.conv, view)
-                                ddt = torch.tensor([time.perf_counter() - d0], dtype=torch.float64, device="cuda")
+                                ddt = torch.tensor([time.perf_counter() - d0], dtype=torch.float64, device=CTL)
                                 dist.all_reduce(ddt, op=dist.ReduceOp.MAX)
                                 sl = torch.from_numpy(srig.conv.download_sorted()).cuda() if dn else torch.zeros((0, 24), dtype=torch.float32, device="cuda")
                                 z = (sl[:, 2] + torch.tensor(-6.0, device="cuda")).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF   # key = bits of view-space z
                                 edge = torch.tensor([int(z[0].item()) if dn else -1, int(z[-1].item()) if dn else -1,
                                                      int(sl.view(torch.int32).to(torch.int64).sum().item()), dn,
-                                                     int(bool((z[1:] >= z[:-1]).all().item())) if dn > 1 else 1], dtype=torch.int64, device="cuda")
+                                                     int(bool((z[1:] >= z[:-1]).all().item())) if dn > 1 else 1], dtype=torch.int64, device=CTL)
                                 edges = [torch.zeros_like(edge) for _ in range(world)]
                                 dist.all_gather(edges, edge)
                                 E = [[int(v) for v in e.tolist()] for e in edges]

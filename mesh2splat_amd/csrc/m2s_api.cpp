@@ -69,7 +69,9 @@ struct m2s_ctx {
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
         bool bands_ready = false;  // d_bands[band_slot] holds the XCD band bases of k_fused2 for this R
         int band_slot = 0;
+        uint32_t gen = 0;          // generation of the table this entry belongs to (the table starts over when it is full)
     };
+    uint32_t rinfo_gen = 0;
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
     unsigned long long* d_bands = nullptr;  // kBandSlots x 8 band bases (device)
@@ -91,7 +93,8 @@ struct m2s_ctx {
     struct Slot { hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr; uint64_t limit = 0; void* d_out = nullptr; uint32_t R = 0;
                   bool sync_result = false; uint64_t sync_total = 0; bool prof = false; float ms[M2S_K_N] = {};
                   int own_lane = -1; uint32_t gen = 0;   // context-owned buffer (0 / 1) and its generation at submission; -1: caller's buffer
-                  bool wrote_bands = false; };
+                  bool wrote_bands = false; uint32_t ri_gen = 0;   // the launch leaves band bases behind, for the RInfo entry of that table generation
+                  hipStream_t st = nullptr; bool shared_work = false; };   // stream it ran on; did it use the context's shared work buffers (chain, deferred list)?
     Slot slot[M2S_MAX_IN_FLIGHT];
     uint32_t slot_head = 0, slot_count = 0; // oldest in-flight slot, number in flight
     hipStream_t last_submit_stream = nullptr;   // stream of the newest in-flight submission (work buffers are shared: see submit)
@@ -173,6 +176,7 @@ static void free_scene(m2s_ctx* c) {
     c->d_cnt = c->d_off = c->d_partials = nullptr;
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr;
     c->rinfo.clear();
+    ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
     c->scene = SceneDev{};
     c->has_scene = false;
@@ -186,8 +190,11 @@ constexpr double kSparseFragsPerTriangle = 1.5;   // AUTO: below this many fragm
 static m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     auto it = c->rinfo.find(R);
     if (it != c->rinfo.end()) return it->second;
-    if (c->rinfo.size() >= (size_t)kBandSlots) c->rinfo.clear();
+    // (a full table starts over; submissions still in flight remember the generation they were made under, so that a band
+    //  slot which now belongs to another density is never marked ready on their behalf: m2s_convert_wait)
+    if (c->rinfo.size() >= (size_t)kBandSlots) { c->rinfo.clear(); ++c->rinfo_gen; }
     m2s_ctx::RInfo ri;
+    ri.gen = c->rinfo_gen;
     ri.band_slot = (int)c->rinfo.size();
     return c->rinfo.emplace(R, ri).first->second;
 }
@@ -944,9 +951,14 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     // than the newest one in flight is ordered behind it with an event.  (The second lane is exempt: it has its own
     // chain and is only taken by single-kernel conversions that touch nothing else.)
     auto chain_behind_newest = [&](hipStream_t on) -> hipError_t {
-        if (!c->slot_count || c->last_submit_stream == on) return hipSuccess;
-        const m2s_ctx::Slot& prev = c->slot[(c->slot_head + c->slot_count - 1) % M2S_MAX_IN_FLIGHT];
-        return prev.sync_result ? hipSuccess : hipStreamWaitEvent(on, prev.done, 0);
+        // the newest in-flight submission that used the SHARED work buffers (everything but second-lane submissions, which
+        // have a chain of their own): if it runs on another stream, this one is ordered behind it
+        for (uint32_t q = c->slot_count; q-- > 0;) {
+            const m2s_ctx::Slot& prev = c->slot[(c->slot_head + q) % M2S_MAX_IN_FLIGHT];
+            if (prev.sync_result || !prev.shared_work) continue;
+            return prev.st == on ? hipSuccess : hipStreamWaitEvent(on, prev.done, 0);
+        }
+        return hipSuccess;
     };
     if (fast_mp) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -969,6 +981,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
             sl.limit = limit;
             sl.d_out = d_out;
             sl.gen = c->buf_gen[0];
+            sl.st = st; sl.shared_work = true;
             ++c->slot_count;
             return M2S_OK;
         }
@@ -980,6 +993,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         const m2s_status s = run_pass(c, R, d_records, capacity_records, st, &total, true);
         if (s != M2S_OK) return s;
         sl.sync_result = true;
+        sl.shared_work = false;
         sl.sync_total = total;
         memcpy(sl.ms, c->last_ms, sizeof sl.ms);   // a later submit overwrites last_ms before this slot is waited for
         sl.limit = c->last_stored;   // already clamped
@@ -1024,7 +1038,9 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         }
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
-    if (!second_lane && !(c->lanes == 2 && !d_records)) HIPCHK(c, chain_behind_newest(st));
+    // (every submission that uses the shared chain is ordered behind the newest one that did, whatever stream that ran on — a
+    //  first-lane submission after a conversion into a caller's buffer on the caller's stream included: ADVICE r2)
+    if (!second_lane) HIPCHK(c, chain_behind_newest(st));
     if (sl.own_lane >= 0) {
         if (c->buf_R[sl.own_lane] != R) { c->buf_R[sl.own_lane] = R; ++c->buf_gen[sl.own_lane]; }
         sl.gen = c->buf_gen[sl.own_lane];
@@ -1048,6 +1064,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
     if (!second_lane) c->last_submit_stream = st;
+    sl.st = st; sl.shared_work = !second_lane; sl.ri_gen = ri.gen;
     sl.sync_result = false;
     sl.limit = limit;
     sl.d_out = d_out;
@@ -1079,14 +1096,17 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     const uint32_t any_big = (uint32_t)(c->h_total[3 + 2 * k] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[3 + 2 * k] >> 32);
     memset(c->last_ms, 0, sizeof c->last_ms);
     if (sl.prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], sl.t0, sl.t1));
-    m2s_ctx::RInfo& ri = rinfo_for(c, sl.R);
+    // what is remembered about (scene, R) may have been dropped since the submission (full table, m2s_set_pipeline): only an
+    // entry of the generation the submission was made under is updated, and none is created here
+    auto rit = c->rinfo.find(sl.R);
+    m2s_ctx::RInfo* rip = (rit != c->rinfo.end() && rit->second.gen == sl.ri_gen) ? &rit->second : nullptr;
     if (err || any_big) {   // cannot happen for a scene/R that converted cleanly before; never return partial output silently
-        ri.async_ok = false;
+        if (rip) rip->async_ok = false;
         (void)hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream);
         (void)hipStreamSynchronize(c->stream);
         return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
     }
-    if (sl.wrote_bands) ri.bands_ready = true;   // that launch has completed: its band bases are in place
+    if (sl.wrote_bands && rip) rip->bands_ready = true;   // that launch has completed: its band bases are in place
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);
@@ -1443,6 +1463,7 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
         c->rinfo.clear();
+        ++c->rinfo_gen;
     }
     c->pipeline = pipeline;
     return M2S_OK;

@@ -35,7 +35,9 @@
 #include <thread>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -110,7 +112,14 @@ struct LocalGroup {
     std::vector<Post> gathered;                    // all-gather: what every rank contributes
     struct Send { int dst = 0; const void* ptr = nullptr; size_t bytes = 0; int device = 0; };
     std::vector<std::vector<Send>> sends;          // record exchange: what every rank sends, in its own order
+    std::vector<char> rank_joined;                 // a rank joins once
 };
+// In-process groups live in a process-wide registry and are named by a random token: the 128-byte id carries the token, not a
+// pointer, so an id whose group has been released (or a forged one) is refused instead of dereferenced, and a rank cannot join
+// twice.  A group is released when every rank that joined has left and all `world` ranks had joined; a group some rank never
+// joined (it failed before m2s_dist_create) stays registered — a few hundred bytes — rather than being freed under a late joiner.
+std::mutex g_groups_lock;
+std::map<unsigned long long, LocalGroup*> g_groups;
 constexpr char kLocalMagic[8] = { 'M', '2', 'S', 'L', 'O', 'C', 'A', 'L' };
 constexpr int kLocalBarrierSeconds = 120;
 
@@ -199,20 +208,23 @@ static m2s_status t_all_gather(m2s_dist* d, const unsigned long long* d_send, un
         return M2S_OK;
     }
     LocalGroup* g = d->local;
-    TH(hipStreamSynchronize(st));          // what I contribute is complete
+    // Every rank passes BOTH barriers on every path: a rank that hit an error still arrives (its peers would otherwise stall
+    // for kLocalBarrierSeconds and the group would be left broken), and reports the error afterwards.
+    m2s_status result = M2S_OK;
+    if (hipStreamSynchronize(st) != hipSuccess) { err = "all-gather: stream failed before the exchange"; result = M2S_ERR_HIP; }   // what I contribute is complete
     {
         std::lock_guard<std::mutex> l(g->m);
-        g->gathered[(size_t)d->rank] = LocalGroup::Post{ d_send, d->device, count * sizeof(unsigned long long) };
+        g->gathered[(size_t)d->rank] = LocalGroup::Post{ d_send, d->device, result == M2S_OK ? count * sizeof(unsigned long long) : ~(size_t)0 };
     }
     if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }
-    for (int r = 0; r < d->world; ++r) {
+    for (int r = 0; r < d->world && result == M2S_OK; ++r) {
         const LocalGroup::Post& p = g->gathered[(size_t)r];   // (stable between the two barriers)
-        if (p.bytes != count * sizeof(unsigned long long)) { err = "all-gather sizes differ between ranks"; (void)local_barrier(g); return M2S_ERR_STATE; }
-        TH(hipMemcpyPeerAsync(d_recv + (size_t)r * count, d->device, p.ptr, p.device, p.bytes, st));
+        if (p.bytes != count * sizeof(unsigned long long)) { err = p.bytes == ~(size_t)0 ? "all-gather: a rank failed before the exchange" : "all-gather sizes differ between ranks"; result = M2S_ERR_STATE; break; }
+        if (hipMemcpyPeerAsync(d_recv + (size_t)r * count, d->device, p.ptr, p.device, p.bytes, st) != hipSuccess) { err = "all-gather: hipMemcpyPeerAsync failed"; result = M2S_ERR_HIP; }
     }
-    TH(hipStreamSynchronize(st));
-    if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }   // nobody overwrites its contribution earlier
-    return M2S_OK;
+    if (hipStreamSynchronize(st) != hipSuccess && result == M2S_OK) { err = "all-gather: stream failed"; result = M2S_ERR_HIP; }
+    if (!local_barrier(g) && result == M2S_OK) { err = "a rank of the in-process group did not arrive"; result = M2S_ERR_STATE; }   // nobody overwrites its contribution earlier
+    return result;
 }
 
 // Every message is described on both sides (exact sizes).  sends[i].ptr is read, recvs[i].ptr written; messages between one
@@ -229,18 +241,19 @@ static m2s_status t_exchange(m2s_dist* d, const std::vector<Xfer>& sends, const 
         return M2S_OK;
     }
     LocalGroup* g = d->local;
-    TH(hipStreamSynchronize(st));          // what I send is complete
+    m2s_status result = M2S_OK;
+    if (hipStreamSynchronize(st) != hipSuccess) { err = "record exchange: stream failed before the exchange"; result = M2S_ERR_HIP; }   // what I send is complete
     {
         std::lock_guard<std::mutex> l(g->m);
         auto& mine = g->sends[(size_t)d->rank];
         mine.clear();
-        for (const Xfer& x : sends) if (x.bytes) mine.push_back(LocalGroup::Send{ x.peer, x.ptr, x.bytes, d->device });
+        if (result == M2S_OK)
+            for (const Xfer& x : sends) if (x.bytes) mine.push_back(LocalGroup::Send{ x.peer, x.ptr, x.bytes, d->device });
     }
     if (!local_barrier(g)) { err = "a rank of the in-process group did not arrive"; return M2S_ERR_STATE; }
     std::vector<size_t> next((size_t)d->world, 0);
-    m2s_status result = M2S_OK;
-    for (const Xfer& x : recvs) {
-        if (!x.bytes) continue;
+    for (const Xfer& x : recvs) {   // (both barriers are passed on every path: see t_all_gather)
+        if (!x.bytes || result != M2S_OK) continue;
         const auto& theirs = g->sends[(size_t)x.peer];
         size_t& k = next[(size_t)x.peer];
         while (k < theirs.size() && theirs[k].dst != d->rank) ++k;
@@ -317,9 +330,17 @@ m2s_status m2s_dist_local_id(int world, uint8_t out_id[M2S_DIST_ID_BYTES]) {
         g->gathered.resize((size_t)world);
         g->sends.resize((size_t)world);
     } catch (...) { delete g; g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
+    try { g->rank_joined.assign((size_t)world, 0); } catch (...) { delete g; g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
+    unsigned long long token = 0;
+    {
+        std::lock_guard<std::mutex> l(g_groups_lock);
+        std::random_device rd;
+        do { token = ((unsigned long long)rd() << 32) ^ rd(); } while (!token || g_groups.count(token));
+        try { g_groups[token] = g; } catch (...) { delete g; g_dist_error = "host allocation failed"; return M2S_ERR_OOM; }
+    }
     memset(out_id, 0, M2S_DIST_ID_BYTES);
     memcpy(out_id, kLocalMagic, sizeof kLocalMagic);
-    memcpy(out_id + 8, &g, sizeof g);
+    memcpy(out_id + 8, &token, sizeof token);
     memcpy(out_id + 16, &world, sizeof world);
     return M2S_OK;
 }
@@ -336,12 +357,22 @@ m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int 
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) { d->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(M2S_ERR_NO_DEVICE); }
     if (is_local) {
-        LocalGroup* g = nullptr;
+        unsigned long long token = 0;
         int gw = 0;
-        memcpy(&g, id + 8, sizeof g);
+        memcpy(&token, id + 8, sizeof token);
         memcpy(&gw, id + 16, sizeof gw);
-        if (!g || gw != world) { d->err = "the in-process group was made for another world size"; return bail(M2S_ERR_INVALID); }
-        { std::lock_guard<std::mutex> l(g->m); ++g->joined; }
+        LocalGroup* g = nullptr;
+        {
+            std::lock_guard<std::mutex> reg(g_groups_lock);
+            auto it = g_groups.find(token);
+            if (it == g_groups.end()) { d->err = "unknown in-process group (released already, or not an id of m2s_dist_local_id)"; return bail(M2S_ERR_INVALID); }
+            g = it->second;
+            std::lock_guard<std::mutex> l(g->m);
+            if (gw != world || g->world != world) { d->err = "the in-process group was made for another world size"; return bail(M2S_ERR_INVALID); }
+            if (g->rank_joined[(size_t)rank]) { d->err = "this rank has already joined the in-process group"; return bail(M2S_ERR_INVALID); }
+            g->rank_joined[(size_t)rank] = 1;
+            ++g->joined;
+        }
         d->local = g;
     } else {
         ncclUniqueId_t uid;
@@ -349,7 +380,7 @@ m2s_status m2s_dist_create(int device, const uint8_t id[M2S_DIST_ID_BYTES], int 
         const int r = g_rccl.CommInitRank(&d->comm, world, uid, rank);
         if (r != kNcclSuccess) { d->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); d->comm = nullptr; return bail(M2S_ERR_HIP); }
     }
-    const size_t sort_words = (size_t)(kSortSamples + 1) * (1 + (size_t)world) + 3 * (size_t)world + (size_t)world * world;
+    const size_t sort_words = (size_t)(kSortSamples + 2) * (1 + (size_t)world) + 2 * (size_t)world + ((size_t)world + 1) * (1 + (size_t)world) + 1 + (size_t)world;   // see m2s_dist_sort_by_depth
     if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_mine, kRing * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void**)&d->d_all, (size_t)kRing * world * sizeof(unsigned long long))) != hipSuccess ||
@@ -385,10 +416,14 @@ void m2s_dist_destroy(m2s_dist* d) {
     if (d->d_sort) (void)hipFree(d->d_sort);
     if (d->h_sort) (void)hipHostFree(d->h_sort);
     if (d->stream) (void)hipStreamDestroy(d->stream);
-    if (LocalGroup* g = d->local) {   // the group goes with its last member (every rank of it is expected to have joined)
+    if (LocalGroup* g = d->local) {   // the group goes with its last member, once every rank of it has joined and left
+        std::lock_guard<std::mutex> reg(g_groups_lock);
         bool last;
-        { std::lock_guard<std::mutex> l(g->m); last = ++g->left == g->world; }
-        if (last) delete g;
+        { std::lock_guard<std::mutex> l(g->m); last = ++g->left == g->world && g->joined == g->world; }
+        if (last) {
+            for (auto it = g_groups.begin(); it != g_groups.end(); ++it) if (it->second == g) { g_groups.erase(it); break; }
+            delete g;
+        }
     }
     delete d;
 }
@@ -556,88 +591,149 @@ m2s_status m2s_dist_gather_records(m2s_dist* d, const void* d_mine, const uint64
 // rank's slice of the sorted sequence: *out_n records starting at position *out_offset.
 m2s_status m2s_dist_sort_by_depth(m2s_dist* d, m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n, uint64_t* out_offset) {
     if (!d || !ctx || !world_to_view) return M2S_ERR_INVALID;
-    DCHK(d, hipSetDevice(d->device));
+    // A collective must be entered by EVERY rank or by none (RCCL peers of a rank that returned early would block forever in
+    // ncclAllGather / Send / Recv; in-process peers would stall for kLocalBarrierSeconds and break the group).  So a rank
+    // that fails locally — its own sort, a device call, the receive buffer — does not return: it carries on to the next
+    // collective, contributes a non-zero STATUS word to it, and all ranks leave together right after.  Three
+    // agreement points: the sample all-gather, the send-count all-gather, and a one-word all-gather just before the record
+    // exchange (the only step whose failure — the receive buffer — is discovered after the counts are known).
+    m2s_status mine = M2S_OK;                              // this rank's first failure
+    auto note = [&](m2s_status st, const std::string& msg) { if (mine == M2S_OK) { mine = st; d->err = msg; } };
+    auto hipok = [&](hipError_t e, const char* what) { if (e != hipSuccess) note(M2S_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return e == hipSuccess; };
+    hipok(hipSetDevice(d->device), "hipSetDevice");
     uint64_t n = 0;
-    m2s_status s = m2s_sort_by_depth(ctx, world_to_view, &n);
-    if (s != M2S_OK) { d->err = std::string("local sort: ") + m2s_last_error(ctx); return s; }
+    if (mine == M2S_OK) {
+        const m2s_status ls = m2s_sort_by_depth(ctx, world_to_view, &n);
+        if (ls != M2S_OK) { note(ls, std::string("local sort: ") + m2s_last_error(ctx)); n = 0; }
+    }
     const int W = d->world, me = d->rank;
     if (out_n) *out_n = n;
     if (out_offset) *out_offset = 0;
-    if (W == 1) return M2S_OK;
+    if (W == 1) return mine;
     const uint32_t R = m2s_last_resolution(ctx);
-    const uint32_t* keys = static_cast<const uint32_t*>(m2s_device_sorted_keys(ctx));
-    const char* sorted = static_cast<const char*>(m2s_device_sorted_records(ctx));
-    const size_t S = kSortSamples, S1 = S + 1, rec = sizeof(m2s_gaussian);
-    unsigned long long *d_samples = d->d_sort, *d_all = d_samples + S1, *d_split = d_all + (size_t)W * S1, *d_bounds = d_split + W,
-                       *d_sendc = d_bounds + W, *d_matrix = d_sendc + W;
-    unsigned long long *h_samples = d->h_sort, *h_all = h_samples + S1, *h_split = h_all + (size_t)W * S1, *h_bounds = h_split + W,
-                       *h_sendc = h_bounds + W, *h_matrix = h_sendc + W;
+    const uint32_t* keys = mine == M2S_OK ? static_cast<const uint32_t*>(m2s_device_sorted_keys(ctx)) : nullptr;
+    const char* sorted = mine == M2S_OK ? static_cast<const char*>(m2s_device_sorted_records(ctx)) : nullptr;
+    const size_t S = kSortSamples, S2 = S + 2 /* samples | how many are valid | status */, rec = sizeof(m2s_gaussian);
+    const size_t W1 = (size_t)W + 1;                        /* send counts | status */
+    unsigned long long *d_samples = d->d_sort, *d_all = d_samples + S2, *d_split = d_all + (size_t)W * S2, *d_bounds = d_split + W,
+                       *d_sendc = d_bounds + W, *d_matrix = d_sendc + W1, *d_flag = d_matrix + (size_t)W * W1, *d_flags = d_flag + 1;
+    unsigned long long *h_samples = d->h_sort, *h_all = h_samples + S2, *h_split = h_all + (size_t)W * S2, *h_bounds = h_split + W,
+                       *h_sendc = h_bounds + W, *h_matrix = h_sendc + W1, *h_flag = h_matrix + (size_t)W * W1, *h_flags = h_flag + 1;
     {   // same order of communicator operations on every rank: counter exchanges published so far go first
         std::unique_lock<std::mutex> l(d->q_lock);
         d->issued_cv.wait(l, [&] { return d->issued == d->published; });
     }
     std::lock_guard<std::mutex> comm_guard(d->comm_lock);
     hipStream_t st = d->stream;
+    // everybody's status words, gathered: all fine -> carry on; otherwise every rank returns here, with the same verdict
+    auto agreed = [&](const unsigned long long* status_of_rank, size_t stride, const char* where) -> bool {
+        int bad = -1;
+        for (int r = 0; r < W; ++r) if (status_of_rank[(size_t)r * stride] != 0 && bad < 0) bad = r;
+        if (bad < 0) return true;
+        if (mine == M2S_OK) { mine = M2S_ERR_STATE; d->err = std::string("distributed sort abandoned ") + where + ": rank " + std::to_string(bad) + " reported a failure"; }
+        return false;
+    };
     try {
-        // 1. samples of my sorted keys, gathered
-        if (n) m2s::launch_pick_samples(keys, n, (uint32_t)S, d_samples, st);
-        else {
+        // 1. samples of my sorted keys (+ my status), gathered
+        if (mine == M2S_OK && n) {
+            m2s::launch_pick_samples(keys, n, (uint32_t)S, d_samples, st);          // writes S samples and the number of valid ones
+            h_flag[0] = 0;
+            hipok(hipMemcpyAsync(d_samples + S + 1, h_flag, 8, hipMemcpyHostToDevice, st), "status upload");
+        } else {
             for (size_t i = 0; i < S; ++i) h_samples[i] = ~0ull;
             h_samples[S] = 0;
-            DCHK(d, hipMemcpyAsync(d_samples, h_samples, S1 * 8, hipMemcpyHostToDevice, st));
+            h_samples[S + 1] = mine == M2S_OK ? 0ull : 1ull;
+            if (hipMemcpyAsync(d_samples, h_samples, S2 * 8, hipMemcpyHostToDevice, st) != hipSuccess) note(M2S_ERR_HIP, "sample upload failed");
         }
-        if ((s = t_all_gather(d, d_samples, d_all, S1, st, d->err)) != M2S_OK) return s;
-        DCHK(d, hipMemcpyAsync(h_all, d_all, (size_t)W * S1 * 8, hipMemcpyDeviceToHost, st));
-        DCHK(d, hipStreamSynchronize(st));
+        {
+            std::string terr;
+            const m2s_status ts = t_all_gather(d, d_samples, d_all, S2, st, terr);
+            if (ts != M2S_OK) { note(ts, terr); return mine; }                       // the transport itself failed: nothing left to agree through
+        }
+        if (!hipok(hipMemcpyAsync(h_all, d_all, (size_t)W * S2 * 8, hipMemcpyDeviceToHost, st), "samples download") ||
+            !hipok(hipStreamSynchronize(st), "samples download")) {
+            for (int r = 0; r < W; ++r) { h_all[(size_t)r * S2 + S] = 0; h_all[(size_t)r * S2 + S + 1] = 0; }   // unknown: my own status travels with the next gather
+        }
+        if (!agreed(h_all + S + 1, S2, "after the local sorts")) return mine;
         // 2. splitters: the same on every rank
         std::vector<unsigned long long> valid;
         for (int r = 0; r < W; ++r) {
-            const size_t take = (size_t)std::min<unsigned long long>(h_all[(size_t)r * S1 + S], S);
-            valid.insert(valid.end(), h_all + (size_t)r * S1, h_all + (size_t)r * S1 + take);
+            const size_t take = (size_t)std::min<unsigned long long>(h_all[(size_t)r * S2 + S], S);
+            valid.insert(valid.end(), h_all + (size_t)r * S2, h_all + (size_t)r * S2 + take);
         }
         std::sort(valid.begin(), valid.end());
         const size_t m = valid.size();
         for (int j = 1; j < W; ++j) h_split[j - 1] = m ? valid[std::min((size_t)j * m / (size_t)W, m - 1)] : ~0ull;
         // 3. where my sorted block is cut: keys < splitter[0] stay with rank 0, [splitter[j-1], splitter[j]) go to rank j
         for (int j = 0; j < W; ++j) h_bounds[j] = 0;
-        if (n) {
-            DCHK(d, hipMemcpyAsync(d_split, h_split, (size_t)(W - 1) * 8, hipMemcpyHostToDevice, st));
-            m2s::launch_lower_bounds(keys, n, d_split, (uint32_t)(W - 1), d_bounds, st);
-            DCHK(d, hipMemcpyAsync(h_bounds, d_bounds, (size_t)(W - 1) * 8, hipMemcpyDeviceToHost, st));
-            DCHK(d, hipStreamSynchronize(st));
+        if (mine == M2S_OK && n) {
+            if (hipok(hipMemcpyAsync(d_split, h_split, (size_t)(W - 1) * 8, hipMemcpyHostToDevice, st), "splitters upload")) {
+                m2s::launch_lower_bounds(keys, n, d_split, (uint32_t)(W - 1), d_bounds, st);
+                hipok(hipMemcpyAsync(h_bounds, d_bounds, (size_t)(W - 1) * 8, hipMemcpyDeviceToHost, st), "bounds download");
+                hipok(hipStreamSynchronize(st), "bounds download");
+            }
         }
         std::vector<uint64_t> edges((size_t)W + 1, 0);
         for (int j = 1; j < W; ++j) edges[(size_t)j] = std::max<uint64_t>(edges[(size_t)j - 1], std::min<uint64_t>(h_bounds[j - 1], n));
         edges[(size_t)W] = n;
-        for (int j = 0; j < W; ++j) h_sendc[j] = edges[(size_t)j + 1] - edges[(size_t)j];
-        // 4. everybody's send counts: row r of the matrix = what rank r sends to each rank
-        DCHK(d, hipMemcpyAsync(d_sendc, h_sendc, (size_t)W * 8, hipMemcpyHostToDevice, st));
-        if ((s = t_all_gather(d, d_sendc, d_matrix, (size_t)W, st, d->err)) != M2S_OK) return s;
-        DCHK(d, hipMemcpyAsync(h_matrix, d_matrix, (size_t)W * W * 8, hipMemcpyDeviceToHost, st));
-        DCHK(d, hipStreamSynchronize(st));
+        for (int j = 0; j < W; ++j) h_sendc[j] = mine == M2S_OK ? edges[(size_t)j + 1] - edges[(size_t)j] : 0;
+        h_sendc[W] = mine == M2S_OK ? 0ull : 1ull;
+        // 4. everybody's send counts (+ status): row r of the matrix = what rank r sends to each rank
+        if (hipMemcpyAsync(d_sendc, h_sendc, W1 * 8, hipMemcpyHostToDevice, st) != hipSuccess) note(M2S_ERR_HIP, "send counts upload failed");
+        {
+            std::string terr;
+            const m2s_status ts = t_all_gather(d, d_sendc, d_matrix, W1, st, terr);
+            if (ts != M2S_OK) { note(ts, terr); return mine; }
+        }
+        if (!hipok(hipMemcpyAsync(h_matrix, d_matrix, (size_t)W * W1 * 8, hipMemcpyDeviceToHost, st), "matrix download") ||
+            !hipok(hipStreamSynchronize(st), "matrix download"))
+            for (size_t i = 0; i < (size_t)W * W1; ++i) h_matrix[i] = 0;
+        const bool ok4 = agreed(h_matrix + W, W1, "after the split");
         std::vector<uint64_t> roff((size_t)W + 1, 0);
         uint64_t offset = 0;
-        for (int r = 0; r < W; ++r) roff[(size_t)r + 1] = roff[(size_t)r] + h_matrix[(size_t)r * W + me];
+        for (int r = 0; r < W; ++r) roff[(size_t)r + 1] = roff[(size_t)r] + h_matrix[(size_t)r * W1 + me];
         for (int q = 0; q < me; ++q)
-            for (int r = 0; r < W; ++r) offset += h_matrix[(size_t)r * W + q];
+            for (int r = 0; r < W; ++r) offset += h_matrix[(size_t)r * W1 + q];
         const uint64_t total_recv = roff[(size_t)W];
-        // 5. the exchange, into the context's record pool (my sorted block stays where it is: a separate buffer)
+        if (!ok4) return mine;
+        // 5. the receive buffer (the context's record pool; my sorted block stays where it is: a separate buffer) — the one
+        //    step that can fail after the counts are known: agree once more, on one word, before anybody sends
         void* pool = nullptr;
-        if ((s = m2s_reserve_records(ctx, total_recv, &pool)) != M2S_OK) { d->err = std::string("receive buffer: ") + m2s_last_error(ctx); return s; }
+        if (mine == M2S_OK) {
+            const m2s_status rs = m2s_reserve_records(ctx, total_recv, &pool);
+            if (rs != M2S_OK) note(rs, std::string("receive buffer: ") + m2s_last_error(ctx));
+        }
+        h_flag[0] = mine == M2S_OK ? 0ull : 1ull;
+        if (hipMemcpyAsync(d_flag, h_flag, 8, hipMemcpyHostToDevice, st) != hipSuccess) note(M2S_ERR_HIP, "status upload failed");
+        {
+            std::string terr;
+            const m2s_status ts = t_all_gather(d, d_flag, d_flags, 1, st, terr);
+            if (ts != M2S_OK) { note(ts, terr); return mine; }
+        }
+        if (!hipok(hipMemcpyAsync(h_flags, d_flags, (size_t)W * 8, hipMemcpyDeviceToHost, st), "status download") ||
+            !hipok(hipStreamSynchronize(st), "status download"))
+            for (int r = 0; r < W; ++r) h_flags[r] = 1;   // cannot read the verdict: do not send (peers that can read it see my next status... there is none: report)
+        if (!agreed(h_flags, 1, "before the record exchange")) return mine;
         char* dst = static_cast<char*>(pool);
-        if (h_sendc[me]) DCHK(d, hipMemcpyAsync(dst + roff[(size_t)me] * rec, sorted + edges[(size_t)me] * rec, h_sendc[me] * rec, hipMemcpyDeviceToDevice, st));
+        if (h_sendc[me]) hipok(hipMemcpyAsync(dst + roff[(size_t)me] * rec, sorted + edges[(size_t)me] * rec, h_sendc[me] * rec, hipMemcpyDeviceToDevice, st), "own block");
         std::vector<Xfer> sends, recvs;
         for (int step = 1; step < W; ++step) {
             const int to = (me + step) % W, from = (me - step + W) % W;
             sends.push_back(Xfer{ to, const_cast<char*>(sorted) + edges[(size_t)to] * rec, (size_t)(h_sendc[to] * rec) });
-            recvs.push_back(Xfer{ from, dst + roff[(size_t)from] * rec, (size_t)(h_matrix[(size_t)from * W + me] * rec) });
+            recvs.push_back(Xfer{ from, dst + roff[(size_t)from] * rec, (size_t)(h_matrix[(size_t)from * W1 + me] * rec) });
         }
-        if ((s = t_exchange(d, sends, recvs, st, d->err)) != M2S_OK) return s;
-        DCHK(d, hipStreamSynchronize(st));
-        // 6. what arrived, sorted (stable): my slice of the global order
-        if ((s = m2s_set_records(ctx, pool, total_recv, R)) != M2S_OK) { d->err = m2s_last_error(ctx); return s; }
+        {
+            std::string terr;
+            const m2s_status ts = t_exchange(d, sends, recvs, st, terr);
+            if (ts != M2S_OK) { note(ts, terr); return mine; }
+        }
+        if (!hipok(hipStreamSynchronize(st), "record exchange")) return mine;
+        if (mine != M2S_OK) return mine;
+        // 6. what arrived, sorted (stable): my slice of the global order.  Local from here on: no collective follows.
+        m2s_status fs;
+        if ((fs = m2s_set_records(ctx, pool, total_recv, R)) != M2S_OK) { d->err = m2s_last_error(ctx); return fs; }
         uint64_t n2 = 0;
-        if ((s = m2s_sort_by_depth(ctx, world_to_view, &n2)) != M2S_OK) { d->err = std::string("final sort: ") + m2s_last_error(ctx); return s; }
+        if ((fs = m2s_sort_by_depth(ctx, world_to_view, &n2)) != M2S_OK) { d->err = std::string("final sort: ") + m2s_last_error(ctx); return fs; }
         if (out_n) *out_n = total_recv;
         if (out_offset) *out_offset = offset;
         return M2S_OK;

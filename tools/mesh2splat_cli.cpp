@@ -25,6 +25,7 @@
 // One GPU, --batch: load(k+1) | upload + convert(k) | export(k-1) overlap (a loader thread, an exporter thread, two
 // contexts used alternately so that file k's records stay intact while file k+1 converts).
 #include <dirent.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -125,6 +126,7 @@ struct Shared {
     // are forked children of one process on one node); RCCL is only brought up when records have to move (--gather)
     std::atomic<int> arrived;
     std::atomic<unsigned long long> counts[64];
+    std::atomic<int> stage[64];   // --gather: how far each rank has got (see rendezvous below)
 };
 
 int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int rank, int world) {
@@ -133,6 +135,19 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     const uint32_t R = o.R();
     const int device = (int)o.device + (o.one_device ? 0 : rank);
     auto fail = [&](const char* what, const char* msg) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, what, msg); sh->failed.store(1); return 1; };
+    // --gather: RCCL calls are collectives — a rank that fails before one must not leave the others blocked inside it
+    // (ncclCommInitRank, the counter all-gather, the record exchange).  Before each of them every rank reports, through the
+    // shared mapping, that it got there in one piece; a rank that sees `failed` leaves instead of entering.
+    auto rendezvous = [&](int stage) -> bool {
+        sh->stage[rank].store(stage);
+        for (;;) {
+            if (sh->failed.load()) return false;
+            int behind = 0;
+            for (int r = 0; r < world; ++r) behind += sh->stage[r].load() < stage;
+            if (!behind) return true;
+            usleep(100);
+        }
+    };
     const auto t0 = Clock::now();
     std::vector<uint64_t> first((size_t)world), count((size_t)world);
     if (m2s_dist_shard_ranges(meshes, n_meshes, R, world, first.data(), count.data()) != M2S_OK) return fail("shard_ranges", m2s_dist_last_error(nullptr));
@@ -146,6 +161,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
         } else {
             while (!sh->id_ready.load()) { if (sh->failed.load()) return 1; usleep(200); }
         }
+        if (!rendezvous(1)) return 1;                 // every rank has a context and the id: nobody is left alone in ncclCommInitRank
         if (m2s_dist_create(device, sh->id, rank, world, &d) != M2S_OK) return fail("dist_create", m2s_dist_last_error(nullptr));
     }
     const auto t1 = Clock::now();
@@ -160,6 +176,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     if (m2s_convert(ctx, R, &total) != M2S_OK) return fail("convert", m2s_last_error(ctx));
     std::vector<uint64_t> counts((size_t)world), keep((size_t)world), offs((size_t)world + 1);
     if (d) {
+        if (!rendezvous(2)) return 1;                 // every rank has uploaded and converted
         if (m2s_dist_all_gather_counts(d, total, counts.data(), nullptr) != M2S_OK) return fail("all_gather_counts", m2s_dist_last_error(d));
     } else {
         sh->counts[rank].store(total);
@@ -187,6 +204,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
             if (m2s_create(device, &sink) != M2S_OK) return fail("create", m2s_last_error(nullptr));
             if (m2s_reserve_records(sink, offs[(size_t)world], &merged) != M2S_OK) return fail("reserve", m2s_last_error(sink));
         }
+        if (!rendezvous(3)) return 1;                 // rank 0 has its receive buffer
         if (m2s_dist_gather_records(d, m2s_device_records(ctx), keep.data(), merged, 0, nullptr) != M2S_OK) return fail("gather_records", m2s_dist_last_error(d));
         if (m2s_dist_wait(d, nullptr) != M2S_OK) return fail("gather_records", m2s_dist_last_error(d));   // sends / receives have completed
         if (rank == 0) {
@@ -219,8 +237,27 @@ int fork_ranks(int world, F body) {
         if (p == 0) { const int rc = body(r); std::fflush(stdout); std::fflush(stderr); _exit(rc); }
         pids.push_back(p);
     }
+    // a rank that dies (a signal, an abort inside a library) cannot tell the others: when one exits abnormally or non-zero the
+    // parent gives the rest two seconds to notice `failed` by themselves and then ends them, so that nobody waits for ever
     int rc = 0;
-    for (pid_t p : pids) { int st = 0; if (waitpid(p, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1; }
+    size_t left = pids.size();
+    std::vector<char> done(pids.size(), 0);
+    int grace_polls = -1;
+    while (left) {
+        bool progressed = false;
+        for (size_t i = 0; i < pids.size(); ++i) {
+            if (done[i]) continue;
+            int st = 0;
+            const pid_t w = waitpid(pids[i], &st, WNOHANG);
+            if (w == 0) continue;
+            done[i] = 1; --left; progressed = true;
+            if (w < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { rc = 1; if (grace_polls < 0) grace_polls = 2000; }
+        }
+        if (!left) break;
+        if (grace_polls == 0) { for (size_t i = 0; i < pids.size(); ++i) if (!done[i]) kill(pids[i], SIGKILL); grace_polls = -2; }
+        else if (grace_polls > 0) --grace_polls;
+        if (!progressed) usleep(1000);
+    }
     return rc;
 }
 
@@ -233,6 +270,7 @@ int convert_sharded(const Options& o) {
     if (sh == MAP_FAILED) { std::perror("mmap"); return 1; }
     new (sh) Shared();
     sh->id_ready.store(0); sh->failed.store(0); sh->arrived.store(0);
+    for (auto& st : sh->stage) st.store(0);
     std::remove(o.out.c_str());
     const int world = (int)o.gpus;
     int rc = 0;
