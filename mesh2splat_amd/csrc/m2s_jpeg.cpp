@@ -18,6 +18,13 @@
 // are reproduced because the decoded bytes must equal the reference loader's; the code that evaluates them below is
 // written from the formulas (matrix form of the transform, one planar up-sampler, a per-pixel colour function), not
 // transcribed from stb_image.
+// ENTROPY STAGE (round 3: rewritten; round 2's version restated stb_image's decode functions).  Written from ITU-T T.81:
+// a bit sequence over the byte-stuffed segment with a 64-bit accumulator (B.1.1.5, F.2.2.5), canonical Huffman tables decoded
+// by a left-aligned bound search behind a 256-entry first-byte table (Annex C, F.2.2.3), the sequential block procedure
+// (F.2.2.1-F.2.2.2), the progressive DC / AC first / AC refinement procedures (G.1.2.1-G.1.2.3, Figure G.7) and one generic
+// loop over the scan's units with restart intervals (E.2.4).  On VALID files the result is the standard's, hence the
+// reference loader's, bit for bit (tests/test_ref_host.py, tools/diff_decoders.py); on corrupt data this decoder stops at
+// a coefficient index beyond 63 where stb_image clamps it.
 // Supported: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2) Huffman JPEG, 8 bits per sample,
 // 1 or 3 components, sampling factors 1..4, restart intervals, Adobe APP14 / component-id RGB detection.
 // Not supported (explicit error): arithmetic coding, lossless, 12-bit, 4-component (CMYK / YCCK) files.
@@ -30,45 +37,217 @@
 namespace m2s_host {
 namespace {
 
-const uint8_t kZigzag[64 + 15] = { 0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
-                                   6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
-                                   39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
-                                   63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };  // tail: corrupt-stream guard
+// zig-zag sequence of T.81 Figure A.6: position in the 8x8 block (row-major) of the k-th coefficient of the sequence
+const uint8_t kZigzag[64] = { 0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                              6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                              39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
 
-struct Huff {
-    // canonical table: codes of length l are [first[l], first[l] + count[l]) ; values in code order
-    int count[17] = {};
-    int first_code[18] = {};
-    int first_index[17] = {};
-    uint8_t values[256] = {};
+// ---- the entropy-coded segment as a bit sequence (T.81 B.1.1.5 byte stuffing, F.2.2.5 NEXTBIT) ----------------------------
+// A 64-bit accumulator holds the bits not yet consumed, most significant first.  0xFF 0x00 is the data byte 0xFF; 0xFF followed
+// by anything else (after optional 0xFF fill bytes) is a marker: it ends the segment, is remembered, and from then on — as past
+// the end of the file — the sequence continues with zero bits, so that a decoder asking for more than the segment holds gets
+// zeros instead of an error (what the reference's loader does too; valid files never get there).
+class SegmentBits {
+public:
+    SegmentBits(const uint8_t*& cursor, const uint8_t* end) : cur_(cursor), end_(end) {}
+    void restart() { acc_ = 0; have_ = 0; marker_ = 0; }       // byte-aligned restart: pending (padding) bits are dropped
+    int marker() const { return marker_; }                      // 0: still inside the segment
+    void clear_marker() { marker_ = 0; }
+    void fill() {
+        while (have_ <= 56) {
+            unsigned byte = 0;
+            if (!marker_ && cur_ < end_) {
+                byte = *cur_++;
+                if (byte == 0xFF) {
+                    unsigned next = cur_ < end_ ? *cur_++ : 0u;
+                    while (next == 0xFF) next = cur_ < end_ ? *cur_++ : 0u;
+                    if (next != 0) { marker_ = (int)next; byte = 0; }
+                }
+            }
+            acc_ |= (uint64_t)byte << (56 - have_);
+            have_ += 8;
+        }
+    }
+    unsigned peek16() { if (have_ < 16) fill(); return (unsigned)(acc_ >> 48); }
+    void drop(int n) { acc_ <<= n; have_ -= n; }
+    unsigned bits(int n) {                                      // RECEIVE(n), 0 <= n <= 16
+        if (n == 0) return 0;
+        if (have_ < n) fill();
+        const unsigned v = (unsigned)(acc_ >> (64 - n));
+        drop(n);
+        return v;
+    }
+    unsigned bit() { return bits(1); }
+    int receive_extend(int ssss) {                              // F.2.2.1: RECEIVE then EXTEND (Figure F.12)
+        if (ssss == 0) return 0;
+        const int v = (int)bits(ssss);
+        return v < (1 << (ssss - 1)) ? v - (1 << ssss) + 1 : v;
+    }
+private:
+    const uint8_t*& cur_;
+    const uint8_t* end_;
+    uint64_t acc_ = 0;
+    int have_ = 0;
+    int marker_ = 0;
+};
+
+// ---- Huffman table (T.81 Annex C: code lengths -> codes; F.2.2.3 DECODE) ------------------------------------------------
+// Canonical codes: the codes of length l are first[l], first[l] + 1, ... in the order of HUFFVAL, and first[l + 1] =
+// (first[l] + count[l]) * 2.  Left-aligned to 16 bits, "the codes of length <= l" are exactly the values below
+// bound[l] = (first[l] + count[l]) << (16 - l), which grows with l: DECODE is "the smallest l with peek16 < bound[l]".  The 256
+// possible leading bytes are resolved through a table (codes of <= 8 bits: length and symbol at once).
+struct HuffTable {
+    uint16_t quick[256] = {};      // (length << 8) | symbol for a leading byte that starts with a code of <= 8 bits, else 0
+    uint32_t bound[18] = {};       // exclusive upper bound of the left-aligned codes of length <= l
+    int base[17] = {};             // index into symbols of code 0 of length l (may be negative: only the sum with a code is used)
+    uint8_t symbols[256] = {};
     bool present = false;
-    bool build(const uint8_t* counts, const uint8_t* vals, int n_vals) {
-        int code = 0, idx = 0;
+    bool define(const uint8_t counts[16], const uint8_t* vals, int n_vals) {
+        std::memset(quick, 0, sizeof quick);
+        uint32_t code = 0;
+        int index = 0;
         for (int l = 1; l <= 16; ++l) {
-            count[l] = counts[l - 1];
-            first_code[l] = code;
-            first_index[l] = idx;
-            code += count[l];
-            idx += count[l];
-            if (code > (1 << l)) return false;
+            const int n = counts[l - 1];
+            if (code + (uint32_t)n > (1u << l) || index + n > n_vals) return false;   // more codes than a prefix code of this length can have
+            base[l] = index - (int)code;
+            if (l <= 8)
+                for (int i = 0; i < n; ++i) {
+                    const unsigned lo = (code + (unsigned)i) << (8 - l);
+                    for (unsigned f = 0; f < (1u << (8 - l)); ++f) quick[lo + f] = (uint16_t)((l << 8) | vals[index + i]);
+                }
+            code += (uint32_t)n;
+            index += n;
+            bound[l] = code << (16 - l);
             code <<= 1;
         }
-        if (idx != n_vals || idx > 256) return false;
-        std::memcpy(values, vals, (size_t)n_vals);
+        bound[17] = 0xFFFFFFFFu;
+        if (index != n_vals || index > 256) return false;
+        std::memcpy(symbols, vals, (size_t)n_vals);
         present = true;
         return true;
+    }
+    int decode(SegmentBits& in) const {                         // -1: no code matches (corrupt data)
+        const unsigned v = in.peek16();
+        if (const unsigned q = quick[v >> 8]) { in.drop((int)(q >> 8)); return (int)(q & 255u); }
+        for (int l = 9; l <= 16; ++l)
+            if (v < bound[l]) {
+                in.drop(l);
+                return symbols[base[l] + (int)(v >> (16 - l))];
+            }
+        return -1;
     }
 };
 
 struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
-    int dc_pred = 0;
+    int pred = 0;                // PRED of F.2.2.1: the previous DC value of this component
     int x = 0, y = 0;            // size in samples
-    int w2 = 0, h2 = 0;          // size padded to whole MCUs
-    int bw = 0, bh = 0;          // size in blocks, padded to whole MCUs
-    std::vector<uint8_t> data;   // decoded samples, w2 x h2
+    int pw = 0, ph = 0;          // plane size: padded to whole MCUs
+    int bw = 0, bh = 0;          // plane size in blocks
+    std::vector<uint8_t> data;   // decoded samples, pw x ph
     std::vector<short> coeff;    // progressive: 64 coefficients per block
 };
+
+// parameters of the scan being decoded (T.81 B.2.3: Ss, Se, Ah, Al) and its running state
+struct Scan {
+    int n = 0, order[4] = {};
+    int Ss = 0, Se = 63, Ah = 0, Al = 0;
+    unsigned eobrun = 0;         // G.1.2.2: blocks still covered by the last end-of-band run
+    int until_restart = 0;       // MCUs left in the current restart interval
+};
+
+// ---- block decoding procedures ----------------------------------------------------------------------------------------------
+// Sequential DCT (F.2.2): DC difference, then (run, size) pairs until the block is full or EOB.  Coefficients are dequantised as
+// they are stored (the inverse DCT follows at once).
+inline const char* decode_sequential_block(SegmentBits& in, const HuffTable& dc, const HuffTable& ac, const uint16_t dq[64], int& pred, short blk[64]) {
+    std::memset(blk, 0, 64 * sizeof(short));
+    const int t = dc.decode(in);
+    if (t < 0 || t > 15) return "bad JPEG Huffman code";
+    pred = (int)((unsigned)pred + (unsigned)in.receive_extend(t));          // (wraps instead of overflowing on corrupt streams)
+    blk[0] = (short)((unsigned)pred * dq[0]);
+    for (int k = 1; k < 64; ++k) {
+        const int rs = ac.decode(in);
+        if (rs < 0) return "bad JPEG Huffman code";
+        const int ssss = rs & 15, rrrr = rs >> 4;
+        if (ssss == 0) {
+            if (rrrr != 15) break;                                           // EOB
+            k += 15;                                                         // ZRL: sixteen zeros
+            continue;
+        }
+        k += rrrr;
+        if (k > 63) return "corrupt JPEG: coefficient index beyond the block";
+        blk[kZigzag[k]] = (short)(in.receive_extend(ssss) * dq[kZigzag[k]]);
+    }
+    return nullptr;
+}
+// Progressive, DC (G.1.2.1): first scan = the sequential DC procedure with the point transform Al; a refinement scan adds one bit.
+inline const char* decode_dc_progressive(SegmentBits& in, const HuffTable& dc, const Scan& sc, int& pred, short blk[64]) {
+    if (sc.Ah == 0) {
+        std::memset(blk, 0, 64 * sizeof(short));
+        const int t = dc.decode(in);
+        if (t < 0 || t > 15) return "bad JPEG Huffman code";
+        pred = (int)((unsigned)pred + (unsigned)in.receive_extend(t));
+        blk[0] = (short)((unsigned)pred << sc.Al);
+    } else if (in.bit()) {
+        blk[0] = (short)(blk[0] + (1 << sc.Al));
+    }
+    return nullptr;
+}
+// Progressive, AC, first scan of a band (G.1.2.2): as sequential AC within [Ss, Se], plus EOBn = end of band for 2^n + bits blocks.
+inline const char* decode_ac_first(SegmentBits& in, const HuffTable& ac, Scan& sc, short blk[64]) {
+    if (sc.eobrun) { --sc.eobrun; return nullptr; }
+    for (int k = sc.Ss; k <= sc.Se; ++k) {
+        const int rs = ac.decode(in);
+        if (rs < 0) return "bad JPEG Huffman code";
+        const int ssss = rs & 15, rrrr = rs >> 4;
+        if (ssss == 0) {
+            if (rrrr == 15) { k += 15; continue; }
+            sc.eobrun = (1u << rrrr) + in.bits(rrrr) - 1u;                  // this block is the first of the run
+            break;
+        }
+        k += rrrr;
+        if (k > 63) return "corrupt JPEG: coefficient index beyond the block";
+        blk[kZigzag[k]] = (short)(in.receive_extend(ssss) * (1 << sc.Al));
+    }
+    return nullptr;
+}
+// Progressive, AC, refinement (G.1.2.3, Figure G.7).  Coefficients with a non-zero history receive one correction bit each as
+// they are passed; a (run, 1) code places a new +-2^Al coefficient after `run` ZERO-history coefficients; EOBn ends the band for
+// this and the following blocks, whose non-zero coefficients still get their correction bits.
+inline const char* decode_ac_refine(SegmentBits& in, const HuffTable& ac, Scan& sc, short blk[64]) {
+    const short plus = (short)(1 << sc.Al), minus = (short)-plus;
+    auto correct = [&](short& c) {                                           // one correction bit for a non-zero coefficient
+        if (in.bit() && (c & plus) == 0) c = (short)(c > 0 ? c + plus : c + minus);
+    };
+    int k = sc.Ss;
+    if (sc.eobrun == 0) {
+        while (k <= sc.Se) {
+            const int rs = ac.decode(in);
+            if (rs < 0) return "bad JPEG Huffman code";
+            const int ssss = rs & 15;
+            int zeros = rs >> 4;
+            short fresh = 0;
+            if (ssss == 0) {
+                if (zeros != 15) { sc.eobrun = (1u << zeros) + in.bits(zeros); break; }   // EOBn: the rest of this block is handled below
+            } else {
+                if (ssss != 1) return "bad JPEG Huffman code";
+                fresh = in.bit() ? plus : minus;
+            }
+            for (; k <= sc.Se; ++k) {
+                short& c = blk[kZigzag[k]];
+                if (c != 0) { correct(c); continue; }
+                if (zeros == 0) { c = fresh; ++k; break; }                   // (ZRL: fresh == 0, the sixteenth zero is passed)
+                --zeros;
+            }
+        }
+    }
+    if (sc.eobrun) {
+        for (; k <= sc.Se; ++k)
+            if (short& c = blk[kZigzag[k]]; c != 0) correct(c);
+        --sc.eobrun;
+    }
+    return nullptr;
+}
 
 struct Decoder {
     const uint8_t* p;
@@ -81,172 +260,17 @@ struct Decoder {
     Component comp[4];
     uint16_t dequant[4][64] = {};
     bool have_q[4] = {};
-    Huff dc[4], ac[4];
+    HuffTable dc[4], ac[4];
     int restart_interval = 0;
-    bool jfif = false;
-    int app14_transform = -1;
+    bool has_jfif = false;       // an APP0 "JFIF" segment was seen
+    int adobe_transform = -1;    // colour transform flag of an APP14 "Adobe" segment, -1: none
     int rgb_ids = 0;
-    // scan
-    int scan_n = 0, order[4] = {};
-    int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;
-    // bit reader
-    uint32_t code_buffer = 0;
-    int code_bits = 0;
-    uint8_t marker = 0xFF;       // marker met inside the entropy-coded data (0xFF = none)
-    bool nomore = false;
-    int todo = 0;
+    Scan scan;
+    int pending_marker = 0;      // marker that ended the last entropy-coded segment (0: none)
 
     bool fail(const char* m) { *err = m; return false; }
     int get8() { return p < end ? *p++ : 0; }
     int get16() { const int a = get8(); return (a << 8) | get8(); }
-
-    void grow() {
-        do {
-            unsigned b = nomore ? 0u : (unsigned)get8();
-            if (b == 0xFF) {
-                int c = get8();
-                while (c == 0xFF) c = get8();   // fill bytes
-                if (c != 0) { marker = (uint8_t)c; nomore = true; b = 0; }
-            }
-            code_buffer |= b << (24 - code_bits);
-            code_bits += 8;
-        } while (code_bits <= 24);
-    }
-    int get_bits(int n) {
-        if (n == 0) return 0;
-        if (code_bits < n) grow();
-        const int v = (int)(code_buffer >> (32 - n));
-        code_buffer <<= n;
-        code_bits -= n;
-        return v;
-    }
-    int get_bit() { return get_bits(1); }
-    int extend_receive(int n) {   // T.81 F.2.2.1 RECEIVE + EXTEND
-        if (n == 0) return 0;
-        const int v = get_bits(n);
-        return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v;
-    }
-    int decode_huff(const Huff& h) {
-        if (code_bits < 16) grow();
-        int code = 0;
-        for (int l = 1; l <= 16; ++l) {
-            code = (code << 1) | (int)(code_buffer >> 31);
-            code_buffer <<= 1;
-            --code_bits;
-            if (h.count[l] && code >= h.first_code[l] && code < h.first_code[l] + h.count[l])
-                return h.values[h.first_index[l] + code - h.first_code[l]];
-        }
-        return -1;
-    }
-    void reset_scan_state() {
-        code_bits = 0; code_buffer = 0; nomore = false; marker = 0xFF;
-        for (int i = 0; i < 4; ++i) comp[i].dc_pred = 0;
-        todo = restart_interval ? restart_interval : 0x7FFFFFFF;
-        eob_run = 0;
-    }
-
-    // ---- block decoders (T.81 F.2.2, G.1.2) ------------------------------------------------------------------
-    bool block_baseline(short data[64], Component& c) {
-        const Huff &hdc = dc[c.td], &hac = ac[c.ta];
-        const uint16_t* dq = dequant[c.tq];
-        std::memset(data, 0, 64 * sizeof(short));
-        const int t = decode_huff(hdc);
-        if (t < 0 || t > 15) return fail("bad JPEG Huffman code");
-        const int diff = t ? extend_receive(t) : 0;
-        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);   // (wraps instead of overflowing on corrupt streams)
-        data[0] = (short)((unsigned)c.dc_pred * dq[0]);
-        int k = 1;
-        do {
-            const int rs = decode_huff(hac);
-            if (rs < 0) return fail("bad JPEG Huffman code");
-            const int s = rs & 15, r = rs >> 4;
-            if (s == 0) {
-                if (rs != 0xF0) break;   // end of block
-                k += 16;
-            } else {
-                k += r;
-                const int zig = kZigzag[k++];
-                data[zig] = (short)(extend_receive(s) * dq[zig]);
-            }
-        } while (k < 64);
-        return true;
-    }
-    bool block_prog_dc(short data[64], Component& c) {
-        if (spec_end != 0) return fail("corrupt progressive JPEG");
-        if (succ_high == 0) {
-            std::memset(data, 0, 64 * sizeof(short));
-            const int t = decode_huff(dc[c.td]);
-            if (t < 0 || t > 15) return fail("bad JPEG Huffman code");
-            const int diff = t ? extend_receive(t) : 0;
-            c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);
-            data[0] = (short)((unsigned)c.dc_pred << succ_low);
-        } else if (get_bit()) {
-            data[0] = (short)(data[0] + (1 << succ_low));
-        }
-        return true;
-    }
-    bool block_prog_ac(short data[64], const Huff& hac) {
-        if (spec_start == 0) return fail("corrupt progressive JPEG");
-        if (succ_high == 0) {
-            const int shift = succ_low;
-            if (eob_run) { --eob_run; return true; }
-            int k = spec_start;
-            do {
-                const int rs = decode_huff(hac);
-                if (rs < 0) return fail("bad JPEG Huffman code");
-                const int s = rs & 15, r = rs >> 4;
-                if (s == 0) {
-                    if (r < 15) {
-                        eob_run = 1 << r;
-                        if (r) eob_run += get_bits(r);
-                        --eob_run;
-                        break;
-                    }
-                    k += 16;
-                } else {
-                    k += r;
-                    const int zig = kZigzag[k++];
-                    data[zig] = (short)(extend_receive(s) * (1 << shift));
-                }
-            } while (k <= spec_end);
-        } else {   // refinement scan
-            const short bit = (short)(1 << succ_low);
-            if (eob_run) {
-                --eob_run;
-                for (int k = spec_start; k <= spec_end; ++k) {
-                    short* q = &data[kZigzag[k]];
-                    if (*q != 0 && get_bit() && (*q & bit) == 0) *q = (short)(*q > 0 ? *q + bit : *q - bit);
-                }
-            } else {
-                int k = spec_start;
-                do {
-                    const int rs = decode_huff(hac);
-                    if (rs < 0) return fail("bad JPEG Huffman code");
-                    int s = rs & 15, r = rs >> 4;
-                    if (s == 0) {
-                        if (r < 15) {
-                            eob_run = (1 << r) - 1;
-                            if (r) eob_run += get_bits(r);
-                            r = 64;   // run to the end of the band
-                        }
-                    } else {
-                        if (s != 1) return fail("bad JPEG Huffman code");
-                        s = get_bit() ? bit : -bit;
-                    }
-                    while (k <= spec_end) {
-                        short* q = &data[kZigzag[k++]];
-                        if (*q != 0) {
-                            if (get_bit() && (*q & bit) == 0) *q = (short)(*q > 0 ? *q + bit : *q - bit);
-                        } else {
-                            if (r == 0) { *q = (short)s; break; }
-                            --r;
-                        }
-                    }
-                } while (k <= spec_end);
-            }
-        }
-        return true;
-    }
 
     // ---- inverse DCT (see the header comment) ------------------------------------------------------------------
     // The 8-point transform as two 4x4 integer matrices (even and odd inputs): every entry is a sum of the 12-bit LLM
@@ -331,7 +355,7 @@ struct Decoder {
                 if (n > 256) return fail("bad DHT");
                 uint8_t vals[256];
                 for (int i = 0; i < n; ++i) vals[i] = (uint8_t)get8();
-                if (!(tc ? ac[th] : dc[th]).build(counts, vals, n)) return fail("bad DHT code lengths");
+                if (!(tc ? ac[th] : dc[th]).define(counts, vals, n)) return fail("bad DHT code lengths");
                 L -= 17 + n;
             }
             return L == 0 ? true : fail("bad DHT length");
@@ -347,7 +371,7 @@ struct Decoder {
                 bool ok = true;
                 for (int i = 0; i < 5; ++i) if (get8() != tag[i]) ok = false;
                 L -= 5;
-                if (ok) jfif = true;
+                if (ok) has_jfif = true;
             } else if (m == 0xEE && L >= 12) {
                 static const char tag[6] = { 'A', 'd', 'o', 'b', 'e', 0 };
                 bool ok = true;
@@ -355,7 +379,7 @@ struct Decoder {
                 L -= 6;
                 if (ok) {
                     get8(); get16(); get16();      // version, flags0, flags1
-                    app14_transform = get8();
+                    adobe_transform = get8();
                     L -= 6;
                 }
             }
@@ -365,8 +389,8 @@ struct Decoder {
         }
         return fail("unsupported JPEG marker");
     }
-    int next_marker() {
-        if (marker != 0xFF) { const int m = marker; marker = 0xFF; return m; }
+    int next_marker() {   // 0xFF: no marker here
+        if (pending_marker) { const int m = pending_marker; pending_marker = 0; return m; }
         int x = get8();
         if (x != 0xFF) return 0xFF;
         while (x == 0xFF) x = get8();
@@ -412,129 +436,115 @@ struct Decoder {
             Component& c = comp[i];
             c.x = (img_x * c.h + h_max - 1) / h_max;
             c.y = (img_y * c.v + v_max - 1) / v_max;
-            c.w2 = mcu_x * c.h * 8;
-            c.h2 = mcu_y * c.v * 8;
-            c.bw = c.w2 / 8; c.bh = c.h2 / 8;
-            c.data.assign((size_t)c.w2 * c.h2, 0);
-            if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
+            c.pw = mcu_x * c.h * 8;
+            c.ph = mcu_y * c.v * 8;
+            c.bw = c.pw / 8; c.bh = c.ph / 8;
+            c.data.assign((size_t)c.pw * c.ph, 0);
+            if (progressive) c.coeff.assign((size_t)c.pw * c.ph, 0);
         }
         return true;
     }
     bool scan_header() {
         const int L = get16();
-        scan_n = get8();
-        if (scan_n < 1 || scan_n > 4 || scan_n > n_comp) return fail("bad SOS component count");
-        if (L != 6 + 2 * scan_n) return fail("bad SOS length");
-        for (int i = 0; i < scan_n; ++i) {
+        scan.n = get8();
+        if (scan.n < 1 || scan.n > 4 || scan.n > n_comp) return fail("bad SOS component count");
+        if (L != 6 + 2 * scan.n) return fail("bad SOS length");
+        for (int i = 0; i < scan.n; ++i) {
             const int id = get8(), q = get8();
             int which = 0;
             while (which < n_comp && comp[which].id != id) ++which;
             if (which == n_comp) return fail("SOS names an unknown component");
             comp[which].td = q >> 4; comp[which].ta = q & 15;
             if (comp[which].td > 3 || comp[which].ta > 3) return fail("bad SOS table index");
-            order[i] = which;
+            scan.order[i] = which;
         }
-        spec_start = get8();
-        spec_end = get8();
+        scan.Ss = get8();
+        scan.Se = get8();
         const int a = get8();
-        succ_high = a >> 4; succ_low = a & 15;
+        scan.Ah = a >> 4; scan.Al = a & 15;
         if (progressive) {
-            if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13) return fail("bad SOS");
+            if (scan.Ss > 63 || scan.Se > 63 || scan.Ss > scan.Se || scan.Ah > 13 || scan.Al > 13) return fail("bad SOS");
         } else {
-            if (spec_start != 0 || succ_high != 0 || succ_low != 0) return fail("bad SOS");
-            spec_end = 63;
+            if (scan.Ss != 0 || scan.Ah != 0 || scan.Al != 0) return fail("bad SOS");
+            scan.Se = 63;
         }
         return true;
     }
-    bool restart_if_due() {   // called after every MCU / block
-        if (--todo <= 0) {
-            if (code_bits < 24) grow();
-            if (!(marker >= 0xD0 && marker <= 0xD7)) return true;   // no RSTn: the scan ends here
-            reset_scan_state();
-        }
+
+    // One entropy-coded segment (with its restart intervals), T.81 E.2.3-E.2.5.  The scan is a sequence of "units": MCUs when it
+    // interleaves several components, single blocks of the component's own grid (no MCU padding) when it has one component.
+    // `unit(i, j)` decodes unit (i, j); after every unit the restart counter runs, and at the end of an interval the segment
+    // must stand at an RSTn marker — if it does not, the scan ends there (what the reference's loader does with such files).
+    template <class Unit>
+    bool for_each_unit(SegmentBits& in, int nx, int ny, Unit unit) {
+        auto begin_interval = [&]() {
+            in.restart();
+            for (Component& c : comp) c.pred = 0;
+            scan.eobrun = 0;
+            scan.until_restart = restart_interval ? restart_interval : 0x7FFFFFFF;
+        };
+        begin_interval();
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                if (const char* e = unit(i, j)) return fail(e);
+                if (--scan.until_restart <= 0) {
+                    in.fill();                                   // (reaches the marker, if the interval really ends here)
+                    if (!(in.marker() >= 0xD0 && in.marker() <= 0xD7)) return true;
+                    begin_interval();
+                }
+            }
         return true;
     }
     bool entropy_scan() {
-        reset_scan_state();
+        SegmentBits in(p, end);
+        bool ok;
         short block[64];
-        if (!progressive) {
-            if (scan_n == 1) {   // non-interleaved: the component's own block grid, without MCU padding
-                Component& c = comp[order[0]];
-                const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
-                for (int j = 0; j < h; ++j)
-                    for (int i = 0; i < w; ++i) {
-                        if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return fail("JPEG table missing");
-                        if (!block_baseline(block, c)) return false;
-                        idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, block);
-                        if (--todo <= 0) {
-                            if (code_bits < 24) grow();
-                            if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
-                            reset_scan_state();
-                        }
+        const char* const kMissing = "JPEG table missing";
+        if (scan.n == 1) {
+            Component& c = comp[scan.order[0]];
+            const int nx = (c.x + 7) >> 3, ny = (c.y + 7) >> 3;
+            if (!progressive)
+                ok = for_each_unit(in, nx, ny, [&](int i, int j) -> const char* {
+                    if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return kMissing;
+                    if (const char* e = decode_sequential_block(in, dc[c.td], ac[c.ta], dequant[c.tq], c.pred, block)) return e;
+                    idct(c.data.data() + (size_t)c.pw * j * 8 + i * 8, c.pw, block);
+                    return nullptr;
+                });
+            else
+                ok = for_each_unit(in, nx, ny, [&](int i, int j) -> const char* {
+                    short* blk = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.bw);
+                    if (scan.Ss == 0) {
+                        if (scan.Se != 0) return "corrupt progressive JPEG";       // a DC scan codes the DC coefficient only (G.1.1.1.1)
+                        if (!dc[c.td].present) return kMissing;
+                        return decode_dc_progressive(in, dc[c.td], scan, c.pred, blk);
                     }
-                return true;
-            }
-            for (int j = 0; j < mcu_y; ++j)
-                for (int i = 0; i < mcu_x; ++i) {
-                    for (int k = 0; k < scan_n; ++k) {
-                        Component& c = comp[order[k]];
-                        if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return fail("JPEG table missing");
-                        for (int y = 0; y < c.v; ++y)
-                            for (int x = 0; x < c.h; ++x) {
-                                const int x2 = (i * c.h + x) * 8, y2 = (j * c.v + y) * 8;
-                                if (!block_baseline(block, c)) return false;
-                                idct(c.data.data() + (size_t)c.w2 * y2 + x2, c.w2, block);
-                            }
-                    }
-                    if (--todo <= 0) {
-                        if (code_bits < 24) grow();
-                        if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
-                        reset_scan_state();
-                    }
-                }
-            return true;
-        }
-        // progressive
-        if (scan_n == 1) {
-            Component& c = comp[order[0]];
-            const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
-            for (int j = 0; j < h; ++j)
-                for (int i = 0; i < w; ++i) {
-                    short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.bw);
-                    if (spec_start == 0) {
-                        if (!dc[c.td].present) return fail("JPEG table missing");
-                        if (!block_prog_dc(data, c)) return false;
-                    } else {
-                        if (!ac[c.ta].present) return fail("JPEG table missing");
-                        if (!block_prog_ac(data, ac[c.ta])) return false;
-                    }
-                    if (--todo <= 0) {
-                        if (code_bits < 24) grow();
-                        if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
-                        reset_scan_state();
-                    }
-                }
-            return true;
-        }
-        for (int j = 0; j < mcu_y; ++j)
-            for (int i = 0; i < mcu_x; ++i) {
-                for (int k = 0; k < scan_n; ++k) {
-                    Component& c = comp[order[k]];
-                    if (!dc[c.td].present) return fail("JPEG table missing");
+                    if (!ac[c.ta].present) return kMissing;
+                    return scan.Ah == 0 ? decode_ac_first(in, ac[c.ta], scan, blk) : decode_ac_refine(in, ac[c.ta], scan, blk);
+                });
+        } else {
+            ok = for_each_unit(in, mcu_x, mcu_y, [&](int i, int j) -> const char* {
+                for (int k = 0; k < scan.n; ++k) {
+                    Component& c = comp[scan.order[k]];
+                    if (progressive) {                                              // interleaved progressive scans are DC scans
+                        if (scan.Ss != 0 || scan.Se != 0) return "corrupt progressive JPEG";
+                        if (!dc[c.td].present) return kMissing;
+                    } else if (!dc[c.td].present || !ac[c.ta].present || !have_q[c.tq]) return kMissing;
                     for (int y = 0; y < c.v; ++y)
                         for (int x = 0; x < c.h; ++x) {
-                            const int x2 = i * c.h + x, y2 = j * c.v + y;
-                            short* data = c.coeff.data() + 64 * ((size_t)x2 + (size_t)y2 * c.bw);
-                            if (!block_prog_dc(data, c)) return false;   // interleaved progressive scans are DC scans
+                            const int bx = i * c.h + x, by = j * c.v + y;
+                            if (progressive) {
+                                if (const char* e = decode_dc_progressive(in, dc[c.td], scan, c.pred, c.coeff.data() + 64 * ((size_t)bx + (size_t)by * c.bw))) return e;
+                            } else {
+                                if (const char* e = decode_sequential_block(in, dc[c.td], ac[c.ta], dequant[c.tq], c.pred, block)) return e;
+                                idct(c.data.data() + (size_t)c.pw * by * 8 + bx * 8, c.pw, block);
+                            }
                         }
                 }
-                if (--todo <= 0) {
-                    if (code_bits < 24) grow();
-                    if (!(marker >= 0xD0 && marker <= 0xD7)) return true;
-                    reset_scan_state();
-                }
-            }
-        return true;
+                return nullptr;
+            });
+        }
+        pending_marker = in.marker();
+        return ok;
     }
     void finish_progressive() {
         for (int n = 0; n < n_comp; ++n) {
@@ -545,7 +555,7 @@ struct Decoder {
                     short* data = c.coeff.data() + 64 * ((size_t)i + (size_t)j * c.bw);
                     const uint16_t* dq = dequant[c.tq];
                     for (int k = 0; k < 64; ++k) data[k] = (short)(data[k] * dq[k]);
-                    idct(c.data.data() + (size_t)c.w2 * j * 8 + i * 8, c.w2, data);
+                    idct(c.data.data() + (size_t)c.pw * j * 8 + i * 8, c.pw, data);
                 }
         }
     }
@@ -565,12 +575,12 @@ struct Decoder {
             if (m == 0xDA) {
                 if (!scan_header()) return false;
                 if (!entropy_scan()) return false;
-                if (marker == 0xFF) {   // skip to the next marker (padding after the entropy-coded segment)
+                if (!pending_marker) {   // the decoder did not run into the marker that ends the segment: look for it
                     while (p < end) {
                         const int x = get8();
-                        if (x == 0xFF) { const int y = get8(); if (y != 0 && y != 0xFF) { marker = (uint8_t)y; break; } if (y == 0xFF) --p; }
+                        if (x == 0xFF) { const int y = get8(); if (y != 0 && y != 0xFF) { pending_marker = y; break; } if (y == 0xFF) --p; }
                     }
-                    if (marker == 0xFF && p >= end) break;   // missing EOI: decode what we have, like stb_image
+                    if (!pending_marker && p >= end) break;   // missing EOI: decode what we have, like the reference's loader
                 }
             } else if (m == 0xDC) {
                 const int L = get16(), nl = get16();
@@ -666,10 +676,10 @@ bool decode_jpeg(const uint8_t* data, size_t len, Image& img, std::string& err) 
     std::vector<uint8_t> scratch[3];
     for (int k = 0; k < d.n_comp; ++k) {
         const Component& c = d.comp[k];
-        plane[k] = Plane{ c.data.data(), c.w2, c.x, c.y, d.h_max / c.h, d.v_max / c.v };
+        plane[k] = Plane{ c.data.data(), c.pw, c.x, c.y, d.h_max / c.h, d.v_max / c.v };
         scratch[k].assign((size_t)W + 3 + 16, 0);
     }
-    const bool is_rgb = d.n_comp == 3 && (d.rgb_ids == 3 || (d.app14_transform == 0 && !d.jfif));
+    const bool is_rgb = d.n_comp == 3 && (d.rgb_ids == 3 || (d.adobe_transform == 0 && !d.has_jfif));
     static const YccToRgb to_rgb;
     for (int j = 0; j < H; ++j) {
         const uint8_t* row[3] = { nullptr, nullptr, nullptr };
