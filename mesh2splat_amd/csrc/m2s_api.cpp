@@ -75,6 +75,9 @@ struct m2s_ctx {
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
     unsigned long long* d_bands = nullptr;  // kBandSlots x 8 band bases (device)
+    uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
+    uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
+    size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
     void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
@@ -175,6 +178,7 @@ static void free_scene(m2s_ctx* c) {
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr;
+    c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0;
     c->rinfo.clear();
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
@@ -459,7 +463,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
         combo_plan.push_back(cp);
     }
     const size_t n_mp = std::max<uint32_t>(n_meshes, 1);
-    const size_t chain_words = std::max<size_t>(n_fused_waves(n_tri), 1);
+    const size_t chain_words = std::max<size_t>(std::max<size_t>(n_fused_waves(n_tri), batch_table_capacity(n_tri)), 1);
     const size_t o_meshes = take(n_mp * sizeof(MeshParams));
     const size_t o_mesh_first = take(mesh_first.size() * sizeof(uint32_t));
     const size_t o_mesh_of8 = take(((np + 7) / 8 + 1) * sizeof(uint2));
@@ -470,6 +474,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const size_t o_biglist = take(np * sizeof(BigItem));
     const size_t o_bigmeta = take(4 * sizeof(uint32_t));
     const size_t o_bands = take((size_t)kBandSlots * 8 * sizeof(unsigned long long));
+    const size_t o_batch = take(std::max<size_t>(batch_table_capacity(n_tri), 1) * sizeof(uint32_t));
     HIPCHK(c, hipMalloc(&c->scene_arena, arena));
     { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
     c->last_upload_ms[3] = ms_since(t_alloc);
@@ -549,6 +554,9 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->d_biglist = (BigItem*)(A + o_biglist);
     c->d_bigmeta = (uint32_t*)(A + o_bigmeta);
     c->d_bands = (unsigned long long*)(A + o_bands);
+    c->d_batch_first = (uint32_t*)(A + o_batch);
+    c->n_batch_tab = 0;
+    c->chain_words = chain_words;
     HIPCHK(c, hipMemsetAsync(c->d_chain, 0, chain_words * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries; the caller's buffers are released
@@ -587,7 +595,7 @@ static hipError_t next_epoch(m2s_ctx* c, uint32_t* out) {
     const uint32_t e = ++c->epoch;
     *out = e;
     if ((e & 0xFFFFu) != 0) return hipSuccess;
-    const size_t bytes = std::max<size_t>(n_fused_waves(c->scene.n_tri), 1) * sizeof(unsigned long long);
+    const size_t bytes = std::max<size_t>(c->chain_words, 1) * sizeof(unsigned long long);
     hipError_t r = hipDeviceSynchronize();
     if (r == hipSuccess && c->d_chain) r = hipMemset(c->d_chain, 0, bytes);
     if (r == hipSuccess && c->d_chain_b) r = hipMemset(c->d_chain_b, 0, bytes);
@@ -618,6 +626,10 @@ static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, bool may_w
     return b;
 }
 
+static BatchTable batches_for(const m2s_ctx* c) {
+    return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab } : BatchTable{ nullptr, 0u };
+}
+
 static uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     if (c->cap_policy == 0) return 0;
     if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
@@ -641,6 +653,39 @@ static m2s_status count_now(m2s_ctx* c, uint32_t R, hipStream_t st) {
     if (prof)
         for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
     c->frag_per_R2 = (double)c->h_total[0] / ((double)R * (double)R);
+    // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
+    // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
+    // cube-sphere face).  Work = 214 per triangle + 140 per fragment (cycles of the triangle phase per 64 triangles and of a strip
+    // per 64 fragments, tools/team_timing.py); fragments scale with R^2 everywhere alike, so the table serves every density.
+    if (batch_table_capacity(sc.n_tri) && !c->n_batch_tab && !std::getenv("M2S_NO_BATCH_TABLE")) {
+        try {
+            std::vector<uint32_t> cnt(sc.n_tri), first;
+            HIPCHK(c, hipMemcpy(cnt.data(), c->d_cnt, (size_t)sc.n_tri * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            const uint32_t n_target = n_fused_waves(sc.n_tri);
+            const double ct = 214.0, cf = 140.0;
+            double total = 0.0;
+            for (uint32_t t = 0; t < sc.n_tri; ++t) total += ct + cf * (double)cnt[t];
+            const double quota = total / (double)n_target;
+            first.reserve(batch_table_capacity(sc.n_tri));
+            first.push_back(0);
+            double acc = 0.0;
+            uint32_t in_batch = 0;
+            for (uint32_t g = 0; g < sc.n_tri; g += 8) {          // batches start at multiples of 8 (mesh_of8)
+                const uint32_t ge = std::min(g + 8u, sc.n_tri);
+                double gc = 0.0;
+                for (uint32_t t = g; t < ge; ++t) gc += ct + cf * (double)cnt[t];
+                // close the batch before this group if it is full, or if the work so far has reached the batch's share
+                if (in_batch && (in_batch + (ge - g) > 64u || acc + 0.5 * gc >= quota * (double)first.size())) { first.push_back(g); in_batch = 0; }
+                acc += gc;
+                in_batch += ge - g;
+            }
+            first.push_back(sc.n_tri);
+            if (first.size() <= batch_table_capacity(sc.n_tri)) {
+                HIPCHK(c, hipMemcpy(c->d_batch_first, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                c->n_batch_tab = (uint32_t)first.size() - 1u;
+            }
+        } catch (...) { /* no table: uniform batches */ }
+    }
     return M2S_OK;
 }
 
@@ -825,7 +870,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                       c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), batches_for(c), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -1016,7 +1061,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
             // between two context-owned buffers; m2s_device_records / m2s_download follow the conversion last waited for.
             if (!c->stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
             if (!c->d_chain_b) {
-                const size_t words = std::max<size_t>(n_fused_waves(c->scene.n_tri), 1);
+                const size_t words = std::max<size_t>(c->chain_words, 1);
                 HIPCHK(c, hipMalloc((void**)&c->d_chain_b, words * sizeof(unsigned long long)));
                 HIPCHK(c, hipMemsetAsync(c->d_chain_b, 0, words * sizeof(unsigned long long), c->stream_b));
             }
@@ -1057,7 +1102,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     if (sparse) launch_sparse(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                               c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
     else if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
+                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c), st);
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));

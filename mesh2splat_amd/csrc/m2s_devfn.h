@@ -564,32 +564,40 @@ __device__ __forceinline__ void tex_state(TD t, float uf, float vf, float lambda
     else st.hi = st.lo;
 }
 
-template <int NCH>  // number of leading channels wanted (RGBA byte order)
-__device__ __forceinline__ void tap_fetch(const uint32_t* __restrict__ texels, const TexTap& t, float out[NCH]) {
+// The eight texels of one map's trilinear footprint (two levels x 2 x 2), requested together; filtered later.
+struct TexFetch { uint32_t lo[4], hi[4]; };
+__device__ __forceinline__ void tex_issue(const uint32_t* __restrict__ texels, const TexState& st, TexFetch& tf) {
     const GlobalBytes gb = as_global(texels);
-    const uint32_t t00 = ld_texel(gb, t.o00), t10 = ld_texel(gb, t.o10), t01 = ld_texel(gb, t.o01), t11 = ld_texel(gb, t.o11);
+    tf.lo[0] = ld_texel(gb, st.lo.o00); tf.lo[1] = ld_texel(gb, st.lo.o10); tf.lo[2] = ld_texel(gb, st.lo.o01); tf.lo[3] = ld_texel(gb, st.lo.o11);
+    tf.hi[0] = ld_texel(gb, st.hi.o00); tf.hi[1] = ld_texel(gb, st.hi.o10); tf.hi[2] = ld_texel(gb, st.hi.o01); tf.hi[3] = ld_texel(gb, st.hi.o11);
+}
+template <int NCH>  // number of leading channels wanted (RGBA byte order)
+__device__ __forceinline__ void tap_filter(const uint32_t t[4], const TexTap& tp, float out[NCH]) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
-        const float c00 = (float)((t00 >> (8 * ch)) & 255u), c10 = (float)((t10 >> (8 * ch)) & 255u);
-        const float c01 = (float)((t01 >> (8 * ch)) & 255u), c11 = (float)((t11 >> (8 * ch)) & 255u);
-        out[ch] = fma_(t.w11, c11, fma_(t.w01, c01, fma_(t.w10, c10, t.w00 * c00)));
+        const float c00 = (float)((t[0] >> (8 * ch)) & 255u), c10 = (float)((t[1] >> (8 * ch)) & 255u);
+        const float c01 = (float)((t[2] >> (8 * ch)) & 255u), c11 = (float)((t[3] >> (8 * ch)) & 255u);
+        out[ch] = fma_(tp.w11, c11, fma_(tp.w01, c01, fma_(tp.w10, c10, tp.w00 * c00)));
     }
 }
-
+// (1 - f) lo + f hi, always in the two-level form: a lane that blends nothing has f = 0 and st.hi == st.lo, and
+// fma(0, hi, 1 * lo) is lo exactly — the bits of the one-level form, without a branch between the loads and their use
+// (round 3: the second level used to be fetched inside `if (any lane blends)`, after the first level had been consumed: two
+// dependent memory round trips per map, see combo_issue)
+template <int NCH>
+__device__ __forceinline__ void tex_finish(const TexFetch& tf, const TexState& st, float out[NCH]) {
+    float lo[NCH], hi[NCH];
+    tap_filter<NCH>(tf.lo, st.lo, lo);
+    tap_filter<NCH>(tf.hi, st.hi, hi);
+    const float f = st.f, nf = 1.0f - st.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
+}
 template <int NCH>
 __device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, const TexState& st, float out[NCH]) {
-    float lo[NCH];
-    tap_fetch<NCH>(texels, st.lo, lo);
-    if (__ballot(st.f != 0.0f) != 0ull) {
-        float hi[NCH];
-        tap_fetch<NCH>(texels, st.hi, hi);
-        const float f = st.f, nf = 1.0f - st.f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) out[ch] = lo[ch] * kUnorm8;
-    }
+    TexFetch tf;
+    tex_issue(texels, st, tf);
+    tex_finish<NCH>(tf, st, out);
 }
 
 // ---- combo path -----------------------------------------------------------------------------------
@@ -643,42 +651,61 @@ __device__ __forceinline__ float frac_repeat(float u) {
     return fminf(f, 1.0f);
 }
 
+// the requests of one fragment's texel footprint (both mip levels) and what the filter needs afterwards
+struct ComboFetch {
+    ComboTap tlo, thi;
+    ComboPair a0, a1, b0, b1;
+    float f;
+};
 template <class MP, class TD, class TS>
-__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, const TS& ts, float out[9]) {
+__device__ __forceinline__ void combo_issue(MP mp, TD t, float uf, float vf, const TS& ts, ComboFetch& cf) {
     // level selection was done per triangle (tri_shade_setup)
     const uint32_t w = t->w, h = t->h;
     const float f = ts.lod0;
     const uint32_t off0 = __float_as_uint(ts.lod1), off1 = __float_as_uint(ts.lod2);
     const uint32_t l0 = (ts.mesh >> 24) & 15u, l1 = ts.mesh >> 28;
     const uint32_t* __restrict__ base = mp->combo.texels;
-    ComboTap tlo, thi;
+    ComboTap& tlo = cf.tlo;
+    ComboTap& thi = cf.thi;
+    cf.f = f;
     combo_tap(off0, max(1u, w >> l0), max(1u, h >> l0), uf, vf, tlo);
-    const bool two = __ballot(f != 0.0f) != 0ull;   // wave-uniform: does any lane blend two levels?
-    // ALL row reads of both levels are requested before the first one is consumed: one memory round trip
-    // instead of two (measured: the texel phase was 73 % of a strip with the levels fetched back to back)
+    combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
+    // ALL row reads of both levels are requested before the first one is consumed: one memory round trip instead of two.
+    // Round 3: that was the intent since round 1, but NOT what ran.  The second level used to sit inside `if (any lane of the wave
+    // blends two levels)`; the compiler hoisted the byte -> float conversions of the FIRST level — common to both branches —
+    // above that branch, and with them an s_waitcnt vmcnt(0): the second level's reads were issued only after the first level
+    // had arrived (k_fused2 ISA: 36 v_cvt_f32_ubyte and a full wait between the two groups of loads) = two dependent round
+    // trips in the longest latency chain of the kernel.  There is no branch any more: both levels are always read and
+    // filtered; a lane that blends nothing has f = 0, its second level gets weight 0 and contributes exactly +0 (same bits
+    // as the one-level form: lo + 0), at the price of ~100 vector instructions in waves that only magnify.
     // 32-bit byte offsets from the (scalar) base: saddr + voffset addressing, no 64-bit address arithmetic per lane
     // (m2s_upload_scene only builds a combo texture whose size fits)
     const GlobalBytes gb = as_global(base);
-    const ComboPair a0 = ld_combo(gb, tlo.o0);
-    const ComboPair a1 = ld_combo(gb, tlo.o1);
-    if (two) {
-        combo_tap(off1, max(1u, w >> l1), max(1u, h >> l1), uf, vf, thi);
-        const ComboPair b0 = ld_combo(gb, thi.o0);
-        const ComboPair b1 = ld_combo(gb, thi.o1);
-        // fold the level blend (1-f, f) and the UNORM8 scale into the eight bilinear weights: 8 FMAs per
-        // channel and nothing else (VALUE arithmetic: same quantity as (1-f)*tau_lo + f*tau_hi, other rounding)
-        const float klo = (1.0f - f) * kUnorm8, khi = f * kUnorm8;
-        tlo.w00 *= klo; tlo.w10 *= klo; tlo.w01 *= klo; tlo.w11 *= klo;
-        thi.w00 *= khi; thi.w10 *= khi; thi.w01 *= khi; thi.w11 *= khi;
-        float lo[9], hi[9];
-        combo_filter(a0, a1, tlo, lo);
-        combo_filter(b0, b1, thi, hi);
+    cf.a0 = ld_combo(gb, tlo.o0);
+    cf.a1 = ld_combo(gb, tlo.o1);
+    cf.b0 = ld_combo(gb, thi.o0);
+    cf.b1 = ld_combo(gb, thi.o1);
+}
+__device__ __forceinline__ void combo_finish(ComboFetch& cf, float out[9]) {
+    ComboTap& tlo = cf.tlo;
+    ComboTap& thi = cf.thi;
+    const float f = cf.f;
+    // fold the level blend (1-f, f) and the UNORM8 scale into the eight bilinear weights: 8 FMAs per
+    // channel and nothing else (VALUE arithmetic: same quantity as (1-f)*tau_lo + f*tau_hi, other rounding)
+    const float klo = (1.0f - f) * kUnorm8, khi = f * kUnorm8;
+    tlo.w00 *= klo; tlo.w10 *= klo; tlo.w01 *= klo; tlo.w11 *= klo;
+    thi.w00 *= khi; thi.w10 *= khi; thi.w01 *= khi; thi.w11 *= khi;
+    float lo[9], hi[9];
+    combo_filter(cf.a0, cf.a1, tlo, lo);
+    combo_filter(cf.b0, cf.b1, thi, hi);
 #pragma unroll
-        for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] + hi[ch];
-    } else {
-        tlo.w00 *= kUnorm8; tlo.w10 *= kUnorm8; tlo.w01 *= kUnorm8; tlo.w11 *= kUnorm8;
-        combo_filter(a0, a1, tlo, out);
-    }
+    for (int ch = 0; ch < 9; ch++) out[ch] = lo[ch] + hi[ch];
+}
+template <class MP, class TD, class TS>
+__device__ __forceinline__ void combo_sample(MP mp, TD t, float uf, float vf, const TS& ts, float out[9]) {
+    ComboFetch cf;
+    combo_issue(mp, t, uf, vf, ts, cf);
+    combo_finish(cf, out);
 }
 
 
@@ -726,7 +753,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         b0 = ld_plane(tp.B0, t);
         b1 = ld_plane(tp.B1, t);
     }
-#ifndef M2S_LATE_ATTR
+#if !defined(M2S_LATE_ATTR) && !defined(M2S_MID_ATTR)
     const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
     const float a2 = ld_plane(tp.A2, t);
     const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
@@ -763,32 +790,52 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
 #ifdef M2S_SKIP_TEX
     cmb = nullptr; xa = nullptr; xn = nullptr; xm = nullptr;
 #endif
+#if defined(M2S_MID_ATTR) && !defined(M2S_SKIP_ATTR)
+    // A/B switch: the texel reads are requested BEFORE position / normal / tangent (results return in issue order: the filter then
+    // does not wait behind nine attribute loads, which in turn arrive while it runs)
+    ComboFetch cfetch;
+    if (cmb != nullptr) combo_issue(mp, ta, uf, vf, ts, cfetch);
+    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
+    const float a2 = ld_plane(tp.A2, t);
+    const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
+    const float c2 = ld_plane(tp.C2, t);
+    const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
+#endif
     if (cmb != nullptr) {
         // all three maps, same size: one LOD state, interleaved texels, 2 x 24-byte row reads per level
         float acc[9];
+#if defined(M2S_MID_ATTR) && !defined(M2S_SKIP_ATTR)
+        combo_finish(cfetch, acc);
+#else
         combo_sample(mp, ta, uf, vf, ts, acc);
+#endif
         col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2]; col[3] = acc[3];
         nrm[0] = acc[4]; nrm[1] = acc[5]; nrm[2] = acc[6];
         rough = acc[7]; metal = acc[8];
     } else {
-        TexState st;
-        if (xa != nullptr) {
-            tex_state(ta, uf, vf, ts.lod0, st);
-            tex_sample<4>(xa, st, col);
-        }
-        if (xn != nullptr) {
-            if (!(xa != nullptr && tn->w == ta->w && tn->h == ta->h)) tex_state(tn, uf, vf, ts.lod1, st);
-            tex_sample<3>(xn, st, nrm);
-        }
+        // separate maps (sizes differ, or a map is missing): the sampling state of every present map first, then ALL texel
+        // reads (up to 24), then the filters — one memory round trip for the whole texture stage (round 3; was up to six)
+        TexState sa, sn, sm;
+        TexFetch fa, fn, fm;
+        const bool n_like_a = xa != nullptr && xn != nullptr && tn->w == ta->w && tn->h == ta->h;
+        const bool m_like_a = xa != nullptr && xm != nullptr && tm->w == ta->w && tm->h == ta->h;
+        const bool m_like_n = xn != nullptr && xm != nullptr && tm->w == tn->w && tm->h == tn->h;
+        if (xa != nullptr) tex_state(ta, uf, vf, ts.lod0, sa);
+        if (xn != nullptr) { if (n_like_a) sn = sa; else tex_state(tn, uf, vf, ts.lod1, sn); }
         if (xm != nullptr) {
-            const bool sameA = xa != nullptr && tm->w == ta->w && tm->h == ta->h;
-            const bool sameN = xn != nullptr && tm->w == tn->w && tm->h == tn->h;
-            // `st` currently describes the normal map if present (possibly shared with albedo), else albedo
-            const bool reuse = (xn != nullptr) ? (sameN) : sameA;
-            if (!reuse) tex_state(tm, uf, vf, ts.lod2, st);
-            float s[3];
-            tex_sample<3>(xm, st, s);
-            metal = s[2]; rough = s[1];
+            // (the state of the normal map when it has the size of this map, else the albedo map's: as before)
+            if (xn != nullptr ? m_like_n : m_like_a) sm = (xn != nullptr) ? sn : sa;
+            else tex_state(tm, uf, vf, ts.lod2, sm);
+        }
+        if (xa != nullptr) tex_issue(xa, sa, fa);
+        if (xn != nullptr) tex_issue(xn, sn, fn);
+        if (xm != nullptr) tex_issue(xm, sm, fm);
+        if (xa != nullptr) tex_finish<4>(fa, sa, col);
+        if (xn != nullptr) tex_finish<3>(fn, sn, nrm);
+        if (xm != nullptr) {
+            float sv[3];
+            tex_finish<3>(fm, sm, sv);
+            metal = sv[2]; rough = sv[1];
         }
     }
     if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();   // texels arrived and filtered

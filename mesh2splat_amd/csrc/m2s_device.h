@@ -111,11 +111,17 @@ struct BandInfo {
     unsigned long long* out;          // [8] or nullptr: where a launch WITHOUT bands records the bases for out_workgroups_per_band
     uint32_t out_workgroups_per_band;
 };
+// Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
+// = triangles [first[b], first[b + 1]), at most 64, starts at multiples of 8.  first == nullptr: uniform batches of fused_tpw.
+struct BatchTable {
+    const uint32_t* first;   // device, n + 1 entries
+    uint32_t n;
+};
 // band width for a scene of n_tri triangles (0: the scene is too small for 64-triangle batches, no bands)
 uint32_t fused2_band_width(uint32_t n_tri);
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, hipStream_t st);
+                   const BandInfo& bands, const BatchTable& batches, hipStream_t st);
 // sparse form of the single-pass kernel (m2s_sparse.hip); `bands` as for launch_fused2 (k_fused2's band width: rescaled inside)
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
@@ -173,5 +179,7 @@ inline uint32_t fused_tpw(uint32_t n_tri) {
     return r8 < 8u ? 8u : r8 > 64u ? 64u : r8;
 }
 inline uint32_t n_fused_waves(uint32_t n_tri) { const uint32_t w = fused_tpw(n_tri); return (n_tri + w - 1) / w; }
+// entries (batches + 1) a BatchTable for n_tri triangles may need; 0: the scene takes uniform 64-triangle batches
+inline uint32_t batch_table_capacity(uint32_t n_tri) { return fused_tpw(n_tri) < 64u ? n_fused_waves(n_tri) + n_tri / 64u + 16u : 0u; }
 
 }  // namespace m2s

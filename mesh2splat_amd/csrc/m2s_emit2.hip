@@ -42,7 +42,7 @@ constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_sca
 #define M2S_EMIT2_DUAL 0
 #endif
 #ifndef M2S_EMIT2_WAVES
-#define M2S_EMIT2_WAVES (M2S_EMIT2_DUAL ? 2 : 3)
+#define M2S_EMIT2_WAVES (M2S_EMIT2_DUAL ? 2 : 4)   // round 3: 122 VGPRs since both mip levels are read without a branch: four waves per SIMD, no scratch
 #endif
 
 // What k_emit2 needs to know about a triangle: the fragment stage's constants plus the third edge function and the

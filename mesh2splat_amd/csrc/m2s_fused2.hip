@@ -61,6 +61,7 @@ __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
+    uint32_t t0[kTeam];                    // first triangle of each wave's batch (batches need not be equally long: BatchTable)
 #ifdef M2S_FUSED2_LDS_UV
     float2 uv[kTeam][64 * 3];              // per triangle: (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0): texture coordinates without a global round trip
 #endif
@@ -117,11 +118,14 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
                                                       BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
                                                       uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
-                                                      BandInfo bands) {
+                                                      BandInfo bands, BatchTable bt) {
     __shared__ F2Lds S;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_batches = (sc.n_tri + tpw - 1u) / tpw;
+    // Batches are `tpw` consecutive triangles each — or, for a scene small enough to be converted by ONE generation of
+    // workgroups, the entries of a table whose batches carry equal estimated WORK (bt.first[b] .. bt.first[b + 1], at most 64
+    // triangles, starts at multiples of 8): with one generation the kernel lasts as long as its slowest workgroup.
+    const uint32_t n_batches = bt.first ? bt.n : (sc.n_tri + tpw - 1u) / tpw;
     // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (the host knows, from an exact
     // count taken once per scene and R, where the output of each eighth of the triangle list starts) XCD x converts
     // the x-th eighth: neighbouring triangles — neighbouring texels — meet in ONE L2 instead of eight, and the look-back
@@ -157,8 +161,15 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     __syncthreads();
 
     // ======================= triangle phase: one batch per wave (as in k_fused) =======================
-    const uint32_t t0 = b * tpw, t = t0 + lane;
-    const bool valid = has_batch && (uint32_t)lane < tpw && t < sc.n_tri;
+    uint32_t t0 = b * tpw, nt = tpw;
+    if (bt.first && has_batch) {
+        const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)bt.first;
+        t0 = q[b];
+        nt = q[b + 1] - t0;
+    }
+    const uint32_t t = t0 + lane;
+    const bool valid = has_batch && (uint32_t)lane < nt && t < sc.n_tri;
+    if (lane == 0) S.t0[wave] = t0;        // (read by other waves only after this wave's `expanded` flag)
     float p[9];
     Geo g;
     Raster rs;
@@ -172,7 +183,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     bool uniform_mesh_w = false;   // the wave's batch lies inside one mesh (m0w): mesh uniforms through scalar loads
     uint32_t m0w = 0;
     if (has_batch) {
-        const uint32_t lastT = min(t0 + tpw, sc.n_tri) - 1;
+        const uint32_t lastT = min(t0 + nt, sc.n_tri) - 1;
         bool uniform_mesh;
         const uint32_t m0 = mesh_of_range(sc, t0, lastT, uniform_mesh);   // one scalar load (was: a binary search)
         uniform_mesh_w = uniform_mesh; m0w = m0;
@@ -423,7 +434,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
         if (have) {
             const TriShade& ts = *reinterpret_cast<const TriShade*>(&S.tri[ow][tl * 5]);
-            const uint32_t tt = (b0 + ow) * tpw + tl;
+            const uint32_t tt = S.t0[ow] + tl;
             skip = S.tskip[ow][tl];
             // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
 #ifdef M2S_FUSED2_LDS_UV
@@ -490,9 +501,9 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, hipStream_t st) {
+                   const BandInfo& bands, const BatchTable& bt, hipStream_t st) {
     const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
-    const uint32_t n_batches = n_fused_waves(sc.n_tri);
+    const uint32_t n_batches = bt.first ? bt.n : n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     BandInfo b = bands;
@@ -500,7 +511,7 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
     if (b.workgroups_per_band) { nb = 8u * b.workgroups_per_band; b.out = nullptr; }
     else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta, tpw, b);
+                       epoch & 0xFFFFu, biglist, bigmeta, tpw, b, bt);
 }
 
 uint32_t fused2_band_width(uint32_t n_tri) {

@@ -46,7 +46,10 @@ constexpr int kSpPer = kSpSub / kSpWaves;     // sub-batches per wave in tier 1
 constexpr uint32_t kSpCand = (uint32_t)kSpSub * 64u;   // candidate triangles per workgroup (= slots: every candidate may survive)
 constexpr int kSpRounds = kSpSub;
 constexpr uint32_t kSpEntries = M2S_SPARSE_ENTRIES;
-constexpr int kSpStage = 32;                  // records staged per wave and round (half a strip)
+#ifndef M2S_SPARSE_STAGE
+#define M2S_SPARSE_STAGE 32
+#endif
+constexpr int kSpStage = M2S_SPARSE_STAGE;    // records staged per wave and round (32: half a strip)
 constexpr uint32_t kSpWait = 1u << 24;        // LDS polls before giving up
 static_assert(kSpSub % kSpWaves == 0 && kSpSub <= 16, "sub-batches: a multiple of the wave count, slot index must fit 10 bits");
 
@@ -211,6 +214,11 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     const uint32_t lastT = min(t_wg + kSpCand, sc.n_tri) - 1u;
     bool uniform_mesh;
     const uint32_t m0 = mesh_of_range(sc, t_wg, lastT, uniform_mesh);   // one scalar load (was: a binary search)
+#ifdef M2S_SPARSE_NOCULL   // experiment: the pooled-rounds structure WITHOUT tier 1 (every candidate "survives")
+    uint32_t NS = min(kSpCand, sc.n_tri - t_wg);
+    for (uint32_t i = threadIdx.x; i < kSpCand; i += kSpThreads) S.surv[i] = (uint16_t)i;
+    __syncthreads();
+#else
     unsigned long long passm[kSpPer];
     bool pass[kSpPer];
     {
@@ -254,6 +262,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
             if (pass[k]) S.surv[my_off[k] + lanes_below(passm[k])] = (uint16_t)((wave + (uint32_t)k * kSpWaves) * 64u + (uint32_t)lane);
     }
     __syncthreads();
+#endif
     NS = __builtin_amdgcn_readfirstlane(NS);
     SP_T(1, SP_NOW() - tk0);
     const uint32_t nr = (NS + 63u) / 64u;
