@@ -1,0 +1,15 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r3pf}
+cd $R
+for v in "" pf "" pf; do
+  L="X=1"; [ -n "$v" ] && L="M2S_LIB_PATH=$R/mesh2splat_amd/_build/$v/libm2s_hip.so"
+  echo "== [$v]"
+  env $L timeout 300 python tools/pipe_ab.py 289:2048:1024,76:2048:512 team 2>/dev/null
+  env $L timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-viewer-extra --no-extra-workloads --no-overlap-extra 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$v] c3 bench', round(d['ms_per_step'],4), round(d['roofline']['frac'],4), 'cold', d['cold_path']['cold_inputs']['kernel_ms'])"
+done 2>&1 | tee $O/${TAG}.log
+for v in "" emit3 "" emit3; do
+  L="X=1"; [ -n "$v" ] && L="M2S_LIB_PATH=$R/mesh2splat_amd/_build/$v/libm2s_hip.so"
+  for w in c4 mid; do env $L timeout 200 python bench.py --workload $w --steps 40 --warmup 4 --no-cpu-baseline --no-viewer-extra --no-cold --no-extra-workloads --no-overlap-extra 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$v] $w', round(d['ms_per_step'],4), {k:round(x,4) for k,x in d['kernel_ms_dedicated'].items() if isinstance(x,float) and x>0})"; done
+done 2>&1 | tee -a $O/${TAG}.log
