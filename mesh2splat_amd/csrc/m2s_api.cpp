@@ -67,14 +67,16 @@ struct m2s_ctx {
         bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
-        bool bands_ready = false;  // d_bands[band_slot] holds the XCD band bases of k_fused2 for this R
+        bool bands_ready = false;  // d_bands[band_slot] holds the XCD band table (cuts + bases) for this R ...
+        uint32_t bands_unit = 0;   // ... in workgroups of this many triangles (256: cut from a k_fused2 launch, 512: k_sparse)
         int band_slot = 0;
         uint32_t gen = 0;          // generation of the table this entry belongs to (the table starts over when it is full)
     };
     uint32_t rinfo_gen = 0;
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
-    unsigned long long* d_bands = nullptr;  // kBandSlots x 8 band bases (device)
+    unsigned long long* d_bands = nullptr;  // kBandSlots x kBandTableWords: XCD band tables (device)
+    unsigned long long* d_wg_base = nullptr;   // where every workgroup's output started in the newest launch without bands
     uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
@@ -96,7 +98,7 @@ struct m2s_ctx {
     struct Slot { hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr; uint64_t limit = 0; void* d_out = nullptr; uint32_t R = 0;
                   bool sync_result = false; uint64_t sync_total = 0; bool prof = false; float ms[M2S_K_N] = {};
                   int own_lane = -1; uint32_t gen = 0;   // context-owned buffer (0 / 1) and its generation at submission; -1: caller's buffer
-                  bool wrote_bands = false; uint32_t ri_gen = 0;   // the launch leaves band bases behind, for the RInfo entry of that table generation
+                  bool wrote_bands = false; uint32_t bands_unit = 0; uint32_t ri_gen = 0;   // the launch leaves band bases behind, for the RInfo entry of that table generation
                   hipStream_t st = nullptr; bool shared_work = false; };   // stream it ran on; did it use the context's shared work buffers (chain, deferred list)?
     Slot slot[M2S_MAX_IN_FLIGHT];
     uint32_t slot_head = 0, slot_count = 0; // oldest in-flight slot, number in flight
@@ -177,7 +179,7 @@ static void free_scene(m2s_ctx* c) {
     // everything below lived inside the arena
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
-    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr;
+    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->d_wg_base = nullptr;
     c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0;
     c->rinfo.clear();
     ++c->rinfo_gen;
@@ -473,7 +475,8 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const size_t o_chain = take(chain_words * sizeof(unsigned long long));
     const size_t o_biglist = take(np * sizeof(BigItem));
     const size_t o_bigmeta = take(4 * sizeof(uint32_t));
-    const size_t o_bands = take((size_t)kBandSlots * 8 * sizeof(unsigned long long));
+    const size_t o_bands = take((size_t)kBandSlots * kBandTableWords * sizeof(unsigned long long));
+    const size_t o_wg_base = take(((size_t)n_fused_waves(n_tri) / 4 + 2) * sizeof(unsigned long long));
     const size_t o_batch = take(std::max<size_t>(batch_table_capacity(n_tri), 1) * sizeof(uint32_t));
     HIPCHK(c, hipMalloc(&c->scene_arena, arena));
     { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
@@ -554,6 +557,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->d_biglist = (BigItem*)(A + o_biglist);
     c->d_bigmeta = (uint32_t*)(A + o_bigmeta);
     c->d_bands = (unsigned long long*)(A + o_bands);
+    c->d_wg_base = (unsigned long long*)(A + o_wg_base);
     c->d_batch_first = (uint32_t*)(A + o_batch);
     c->n_batch_tab = 0;
     c->chain_words = chain_words;
@@ -613,17 +617,31 @@ static bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
            sparse_supported(c->scene.n_tri);
 }
 
-// XCD bands of k_fused2 for this launch: read them if an earlier launch at this R left them behind, otherwise ask this
-// launch to leave them (second lane: never asked to write — two lanes could race on the slot)
-static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, bool may_write, bool* writes) {
+static bool env_on(const char* name) { const char* v = std::getenv(name); return v && *v && *v != '0'; }   // (debug switches)
+// XCD bands for this launch of k_fused2 (unit 256) or k_sparse (unit 512 triangles per workgroup): the table an earlier launch
+// of the same kernel at this R left behind — or, if there is none, ask this launch to record where every workgroup's output
+// starts, from which the table is cut right behind it (second lane: never asked to — two lanes would race on d_wg_base)
+static uint32_t band_workgroups(const m2s_ctx* c, uint32_t unit) {
+    const uint32_t team = fused2_band_workgroups(c->scene.n_tri);
+    return !team ? 0u : unit == 256u ? team : sparse_workgroups(c->scene.n_tri);
+}
+static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes) {
     BandInfo b{};
     if (writes) *writes = false;
-    const uint32_t bpb = fused2_band_width(c->scene.n_tri);
-    if (!bpb || !c->d_bands || std::getenv("M2S_NO_BANDS")) return b;
-    unsigned long long* slot = c->d_bands + (size_t)ri.band_slot * 8;
-    if (ri.bands_ready) { b.base = slot; b.workgroups_per_band = bpb; }
-    else if (may_write) { b.out = slot; b.out_workgroups_per_band = bpb; if (writes) *writes = true; }
+    const uint32_t n_wg = band_workgroups(c, unit);
+    if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || env_on("M2S_NO_BANDS")) return b;
+    if (ri.bands_ready && ri.bands_unit == unit) {
+        b.table = c->d_bands + (size_t)ri.band_slot * kBandTableWords;
+        b.max_width = band_max_width(n_wg);
+    }
+    else if (may_write) { b.out = c->d_wg_base; if (writes) *writes = true; }
     return b;
+}
+// behind a launch that recorded its workgroups' bases: cut the bands of the next launches at this R
+static void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st) {
+    const uint32_t n_wg = band_workgroups(c, unit);
+    launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg),
+                      c->d_bands + (size_t)ri.band_slot * kBandTableWords, st);
 }
 
 static BatchTable batches_for(const m2s_ctx* c) {
@@ -867,20 +885,22 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             uint32_t epoch;
             HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
+            const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                      c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), st);
+                                      c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, true, &wrote_bands), batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
+            if ((team || sparse) && wrote_bands) pick_bands(c, ri, unit, &c->h_total[0], st);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-            if ((team || sparse) && !err && wrote_bands) ri.bands_ready = true;
+            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
             if (err && std::getenv("M2S_DEBUG"))
                 fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
             if (!(err && (team || sparse))) break;
@@ -1099,13 +1119,15 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     const bool sparse = use_sparse(c, ri);
     const bool team = !sparse && use_team(c, ri);
     c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+    sl.bands_unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
     if (sparse) launch_sparse(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                              c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
+                              c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
     else if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c), st);
+                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c), st);
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
+    if ((team || sparse) && sl.wrote_bands) pick_bands(c, ri, sl.bands_unit, &res[0], st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
     if (!second_lane) c->last_submit_stream = st;
@@ -1151,7 +1173,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
         (void)hipStreamSynchronize(c->stream);
         return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
     }
-    if (sl.wrote_bands && rip) rip->bands_ready = true;   // that launch has completed: its band bases are in place
+    if (sl.wrote_bands && rip) { rip->bands_ready = true; rip->bands_unit = sl.bands_unit; }   // that launch has completed: its band table is in place
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);

@@ -101,24 +101,36 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
 // device-side .ply row encoder, formats 1 and 2 (m2s_export.hip)
 void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float scale_multiplier, uint8_t* out, hipStream_t st);
 
-// XCD bands of k_fused2 (see m2s_fused2.hip): workgroups_per_band == 0 switches banding off.  The band bases live in
-// DEVICE memory: a launch without bands leaves them behind as a by-product (every workgroup that would start a band
-// writes the base it resolved to `out`), the next launch of the same scene at the same R reads them — no counting
-// kernel, no host round trip (round 1 took them from k_count's partial sums through eight small copies).
+// XCD bands of k_fused2 / k_sparse (see m2s_fused2.hip): max_width == 0 switches banding off.  XCD x converts the x-th of
+// eight runs of consecutive workgroups.  The band table lives in DEVICE memory: a launch without bands records where every
+// workgroup's output starts (`out`), k_pick_bands cuts eight runs of equal estimated work from that right behind it, and the
+// next launches of the same scene at the same R read the table — no counting kernel, no host round trip.  (Until round 3 the
+// bands were eight runs of equal LENGTH: on config 3 the busiest XCD then had 11 % more work than the average.)
+// words of a band table (device memory, unsigned long long each)
+constexpr uint32_t kBandBase = 0;    // [x], x < 8: record index at which band x's output starts
+constexpr uint32_t kBandWg = 8;      // [x], x <= 8: first workgroup (= chain word / 4) of band x; x = 8: one past the last
+constexpr int kBandTableWords = 24;   // (17 used)
 struct BandInfo {
-    const unsigned long long* base;   // [8] record index at which each band's output starts (device memory); read when workgroups_per_band != 0
-    uint32_t workgroups_per_band;     // multiple of 4
-    unsigned long long* out;          // [8] or nullptr: where a launch WITHOUT bands records the bases for out_workgroups_per_band
-    uint32_t out_workgroups_per_band;
+    const unsigned long long* table;  // banded launch (max_width != 0): the table above
+    uint32_t max_width;               // banded launch: no band has more workgroups than this (the grid is 8 x max_width)
+    unsigned long long* out;          // launch WITHOUT bands, or nullptr: out[workgroup] = record index at which its output starts
 };
+// The bands of the NEXT launches at this R, from what a launch without bands left in `wg_base`: eight runs of consecutive
+// workgroups of equal estimated WORK (not equal length — fragment density varies along the triangle list, and a launch lasts
+// as long as its slowest XCD).  tri_per_wg: 256 (k_fused2) or 512 (k_sparse);
+// *total = the fragment count of that launch.
+void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
+                       const unsigned long long* total, uint32_t max_width, unsigned long long* table, hipStream_t st);
+// most workgroups the picker may give a band of a scene of n_wg (8 x this many are launched): balanced bands are uneven
+inline uint32_t band_max_width(uint32_t n_wg) { const uint32_t w = (n_wg + 7u) / 8u; return w + w / 4u + 1u; }
 // Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
 // = triangles [first[b], first[b + 1]), at most 64, starts at multiples of 8.  first == nullptr: uniform batches of fused_tpw.
 struct BatchTable {
     const uint32_t* first;   // device, n + 1 entries
     uint32_t n;
 };
-// band width for a scene of n_tri triangles (0: the scene is too small for 64-triangle batches, no bands)
-uint32_t fused2_band_width(uint32_t n_tri);
+// workgroups of k_fused2 for a scene of n_tri triangles that can be converted in bands (0: too small for 64-triangle batches)
+uint32_t fused2_band_workgroups(uint32_t n_tri);
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const BandInfo& bands, const BatchTable& batches, hipStream_t st);
@@ -127,6 +139,8 @@ void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const BandInfo& bands, hipStream_t st);
 bool sparse_supported(uint32_t n_tri);
+uint32_t sparse_workgroups(uint32_t n_tri);   // workgroups of kSpCand = 512 triangles
+constexpr uint32_t kSparseTrianglesPerWorkgroup = 512;
 void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                   unsigned long long* total, uint32_t* status /* [0]=any big [1]=error */, uint32_t epoch, BigItem* biglist,
                   uint32_t* bigmeta /* [0]=count [1]=max fragments [2]=sum of fragments */, hipStream_t st);

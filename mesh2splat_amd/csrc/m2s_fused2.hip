@@ -48,7 +48,8 @@ constexpr uint32_t kXcdRun2 = M2S_XCD_RUN2;
 
 #ifdef M2S_TIMING
 // debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
-//   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup
+//   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup,
+//   [6] start and [7] end of wave 0 (s_memrealtime: 100 MHz, common to all XCDs), [8] XCD (blockIdx & 7)
 constexpr int kF2TimingSlots = 16, kF2TimingBlocks = 8192;
 __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 #define F2_T(slot, v) do { if (wave == 0 && lane == 0 && lb < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + lb] = (v); } while (0)
@@ -126,16 +127,20 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     // workgroups, the entries of a table whose batches carry equal estimated WORK (bt.first[b] .. bt.first[b + 1], at most 64
     // triangles, starts at multiples of 8): with one generation the kernel lasts as long as its slowest workgroup.
     const uint32_t n_batches = bt.first ? bt.n : (sc.n_tri + tpw - 1u) / tpw;
-    // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (the host knows, from an exact
-    // count taken once per scene and R, where the output of each eighth of the triangle list starts) XCD x converts
-    // the x-th eighth: neighbouring triangles — neighbouring texels — meet in ONE L2 instead of eight, and the look-back
-    // chain restarts at every band (a workgroup still only waits for workgroups dispatched before it: h - 8, h - 16, ...).
+    // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (a table in device memory, cut by
+    // k_pick_bands from what an earlier launch at this R recorded: where each of eight runs of consecutive workgroups starts
+    // and where its output starts) XCD x converts the x-th run: neighbouring triangles — neighbouring texels — meet in ONE
+    // L2 instead of eight, and the look-back chain restarts at every band (a workgroup still only waits for workgroups
+    // dispatched before it: h - 8, h - 16, ...).  The runs carry equal estimated work, not equal numbers of workgroups.
     // Without bands: plain round-robin (or runs of kXcdRun2, which the chain does not like: see DESIGN.md).
     const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
-    const uint32_t bpb = bands.workgroups_per_band;
-    if (bpb && round >= bpb) return;
-    const uint32_t lb = bpb ? xcd * bpb + round : ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
-    const bool band_first = bpb && round == 0;        // this workgroup's base is the band's base: known
+    const bool banded = bands.max_width != 0u;
+    uint32_t lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
+    if (banded) {   // (scalar loads: the band's first workgroup and the next band's)
+        lb = (uint32_t)bands.table[kBandWg + xcd] + round;
+        if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
+    }
+    const bool band_first = banded && round == 0;     // this workgroup's base is the band's base: known
     const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
     if (b0 >= n_batches) return;
     const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
@@ -143,6 +148,9 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     const bool has_batch = wave < nb_here;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     [[maybe_unused]] const unsigned long long tk0 = F2_NOW();     // phase timers: live only in -DM2S_TIMING builds
+#ifdef M2S_TIMING
+    const unsigned long long tk_real0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz, the same on every XCD: s_memtime is per XCD)
+#endif
     [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0;
 
     // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
@@ -156,7 +164,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     if (wave == 0 && lane == 0) {
         S.claimed = 0; S.irregular = 0; S.error = 0;
         S.base_state = (b0 == 0 || band_first) ? 2u : 0u;
-        S.base = band_first ? bands.base[xcd] : 0ull;   // scalar load from device memory
+        S.base = band_first ? bands.table[xcd] : 0ull;   // scalar load from device memory
     }
     __syncthreads();
 
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     if (has_batch && lane == 0) {
         // the first batch of the grid / of a band knows its inclusive prefix; everybody else publishes the aggregate
         const bool knows = b == 0 || (band_first && wave == 0);
-        const unsigned long long before = band_first ? bands.base[xcd] : 0ull;
+        const unsigned long long before = band_first ? bands.table[xcd] : 0ull;
         chain_store(&chain[b], (knows ? kFlagPrefix : kFlagAgg) | etag | (((knows ? before : 0ull) + total_w) & kValMask));
     }
     if (lane == 0) {
@@ -491,12 +499,14 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         if (have_base && lane == 0) {
             chain_store(&chain[b0 + nb_here - 1], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (b0 + nb_here == n_batches) *total_out = base + out_total;
-            // by-product of a launch without bands: where each band of the NEXT launch at this R starts
-            if (bands.out && lb % bands.out_workgroups_per_band == 0u) bands.out[lb / bands.out_workgroups_per_band] = base;
+            // by-product of a launch without bands: where every workgroup's output starts (k_pick_bands cuts the bands of the
+            // NEXT launches at this R from it)
+            if (bands.out) bands.out[lb] = base;
         }
     }
     if (lds_load(&S.error) && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     F2_T(0, F2_NOW() - tk0); F2_T(1, tk_cnt); F2_T(2, tk_ent); F2_T(3, tk_base); F2_T(4, n_strips); F2_T(5, (unsigned long long)stream_total);
+    F2_T(6, tk_real0); F2_T(7, __builtin_amdgcn_s_memrealtime()); F2_T(8, (unsigned long long)(blockIdx.x & 7u));
 }
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
@@ -507,18 +517,56 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     BandInfo b = bands;
-    if (tpw != 64u || kTeam != 4) { b.workgroups_per_band = 0; b.out = nullptr; }
-    if (b.workgroups_per_band) { nb = 8u * b.workgroups_per_band; b.out = nullptr; }
+    if (tpw != 64u || kTeam != 4 || bt.first) { b.max_width = 0; b.out = nullptr; }
+    if (b.max_width) { nb = 8u * b.max_width; b.out = nullptr; }
     else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta, tpw, b, bt);
 }
 
-uint32_t fused2_band_width(uint32_t n_tri) {
+// workgroups of k_fused2 for a scene that can be converted in bands (64-triangle batches, no batch table); 0: no bands
+uint32_t fused2_band_workgroups(uint32_t n_tri) {
     if (fused_tpw(n_tri) != 64u || kTeam != 4) return 0;
-    const uint32_t wgs = (n_fused_waves(n_tri) + 3u) / 4u;
-    const uint32_t bpb = (wgs + 7u) / 8u;
-    return (bpb + 3u) & ~3u;
+    return (n_fused_waves(n_tri) + 3u) / 4u;
+}
+
+// One wave; lanes 0..8 each find one cut.  cost(w) = the estimated work before workgroup w (the batch table's weights: 214 per
+// triangle, 140 per fragment) is monotone in w: cut k is the first workgroup with cost >= k / 8 of the whole.
+__global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __restrict__ wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
+                                                   const unsigned long long* __restrict__ total, uint32_t max_width,
+                                                   unsigned long long* __restrict__ table) {
+    __shared__ uint32_t cut[9];
+    const uint32_t k = threadIdx.x;
+    const unsigned long long tot = *total;
+    auto cost = [&](uint32_t w) -> unsigned long long {
+        const unsigned long long tri = min((unsigned long long)w * tri_per_wg, (unsigned long long)n_tri);
+        return 214ull * tri + 140ull * (w < n_wg ? wg_base[w] : tot);
+    };
+    if (k <= 8u) {
+        const unsigned long long target = cost(n_wg) / 8ull * k;
+        uint32_t lo = 0, hi = n_wg;          // first w in [0, n_wg] with cost(w) >= target
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (cost(mid) >= target) hi = mid; else lo = mid + 1u;
+        }
+        cut[k] = k == 0u ? 0u : k == 8u ? n_wg : lo;
+    }
+    __syncthreads();
+    if (k == 0u) {
+        // no band wider than max_width (that is what the launch provides), cuts in order
+        for (uint32_t j = 1; j < 8u; ++j) {
+            const uint32_t rest = (8u - j) * max_width;                     // what the bands after cut j can hold
+            const uint32_t lo = max(cut[j - 1], n_wg > rest ? n_wg - rest : 0u), hi = min(cut[j - 1] + max_width, n_wg);
+            cut[j] = min(max(cut[j], lo), hi);
+        }
+        for (uint32_t j = 0; j < 8u; ++j) table[kBandBase + j] = cut[j] < n_wg ? wg_base[cut[j]] : tot;
+        for (uint32_t j = 0; j <= 8u; ++j) table[kBandWg + j] = cut[j];
+    }
+}
+
+void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
+                       const unsigned long long* total, uint32_t max_width, unsigned long long* table, hipStream_t st) {
+    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, table);
 }
 
 #ifdef M2S_TIMING

@@ -189,13 +189,15 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_wg = (sc.n_tri + kSpCand - 1u) / kSpCand;
-    // XCD bands exactly as in k_fused2 (a band = an eighth of the workgroups = the same triangles as k_fused2's band: the host
-    // passes half of k_fused2's band width, and a sparse workgroup covers twice the triangles)
+    // XCD bands exactly as in k_fused2 (here in workgroups of kSpCand triangles: the table was cut from a k_sparse launch)
     const uint32_t hb = blockIdx.x, xcd = hb & 7u, rnd = hb >> 3;
-    const uint32_t bpb = bands.workgroups_per_band;
-    if (bpb && rnd >= bpb) return;
-    const uint32_t lb = bpb ? xcd * bpb + rnd : hb;
-    const bool band_first = bpb && rnd == 0;
+    const bool banded = bands.max_width != 0u;
+    uint32_t lb = hb;
+    if (banded) {
+        lb = (uint32_t)bands.table[kBandWg + xcd] + rnd;
+        if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
+    }
+    const bool band_first = banded && rnd == 0;
     if (lb >= n_wg) return;
     const uint32_t t_wg = lb * kSpCand;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     if (threadIdx.x == 0) {
         S.claimed_round = 0; S.claimed_strip = 0; S.irregular = 0; S.error = 0; S.done_waves = 0;
         S.base_state = (lb == 0 || band_first) ? 2u : 0u;
-        S.base = band_first ? bands.base[xcd] : 0ull;
+        S.base = band_first ? bands.table[xcd] : 0ull;
         S.pre_w[0] = 0; S.pre_c[0] = 0;
     }
 
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     SP_T(1, SP_NOW() - tk0);
     const uint32_t nr = (NS + 63u) / 64u;
     const bool knows = lb == 0 || band_first;            // this workgroup's base is known without a look-back
-    const unsigned long long before = band_first ? bands.base[xcd] : 0ull;
+    const unsigned long long before = band_first ? bands.table[xcd] : 0ull;
     if (nr == 0 && wave == 0 && lane == 0)               // nothing survived: the aggregate is zero
         chain_store(&chain[lb], (knows ? kFlagPrefix : kFlagAgg) | etag | (before & kValMask));
 
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         if (have_base && lane == 0) {
             chain_store(&chain[lb], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (lb + 1u == n_wg) *total_out = base + out_total;
-            if (bands.out && lb % bands.out_workgroups_per_band == 0u) bands.out[lb / bands.out_workgroups_per_band] = base;
+            if (bands.out) bands.out[lb] = base;     // (k_pick_bands cuts the bands of the next launches at this R from these)
         }
     }
     // status[1] != 0 is what the host acts on; the value says why (1 / 3 / 4 / 5: a wait gave up, 2: entries do not fit) and where
@@ -618,24 +620,20 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         __hip_atomic_store(&status[1], S.error | (lb << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// band_width: k_fused2's band width for this scene (fused2_band_width), or 0
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out, unsigned long long* total,
                    uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, const BandInfo& bands, hipStream_t st) {
     if (!sc.n_tri) return;
-    const uint32_t n_wg = (sc.n_tri + kSpCand - 1u) / kSpCand;
+    const uint32_t n_wg = sparse_workgroups(sc.n_tri);
     uint32_t nb = (n_wg + 7u) & ~7u;
     BandInfo b = bands;
-    // a band covers the same triangles as in k_fused2: its workgroups there x 256 triangles = ours x kSpCand
-    if ((b.workgroups_per_band * 256u) % kSpCand || (b.out_workgroups_per_band * 256u) % kSpCand) { b.workgroups_per_band = 0; b.out = nullptr; b.out_workgroups_per_band = 0; }
-    b.workgroups_per_band = b.workgroups_per_band * 256u / kSpCand;
-    b.out_workgroups_per_band = b.out_workgroups_per_band * 256u / kSpCand;
-    if (b.workgroups_per_band) { nb = 8u * b.workgroups_per_band; b.out = nullptr; }
-    if (!b.out_workgroups_per_band) b.out = nullptr;
+    if (b.max_width) { nb = 8u * b.max_width; b.out = nullptr; }
     hipLaunchKernelGGL(k_sparse, dim3(nb), dim3(kSpThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta, b);
 }
 
 bool sparse_supported(uint32_t n_tri) { return fused_tpw(n_tri) == 64u; }
+static_assert(kSpCand == kSparseTrianglesPerWorkgroup, "m2s_device.h");
+uint32_t sparse_workgroups(uint32_t n_tri) { return (n_tri + kSpCand - 1u) / kSpCand; }
 
 #ifdef M2S_TIMING
 extern "C" int m2s_debug_read_timing_sparse(unsigned long long* dst, size_t n) {

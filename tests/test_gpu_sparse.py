@@ -126,3 +126,35 @@ def test_auto_picks_sparse_and_async_submissions(hiplib, oracle):
     assert c.convert(1024) == oracle.convert(scene, 1024, cap=0, count_only=True, n_threads=8)[0]      # 14 fragments per triangle
     assert c.last_pipeline != "sparse"
     c.close()
+
+
+@pytest.mark.parametrize("pipeline", ["team", "sparse"])
+def test_bands_of_equal_work_on_uneven_density(hiplib, oracle, pipeline):
+    """The second conversion at an R runs in XCD bands cut (k_pick_bands) from what the first one recorded: eight runs of
+    workgroups of equal estimated work.  Here the fragments sit in the first third of the triangle list (the cuts are far from
+    equal lengths and the width limit of a band applies) — and, turned around, in the last third."""
+    # (k_sparse: a workgroup's 512 triangles must stay within its LDS stream of 2560 entries)
+    dense = synth.random_soup(80_000, seed=31, tri_size=0.02 if pipeline == "team" else 0.012).meshes[0].vertices
+    thin = synth.random_soup(170_000, seed=32, tri_size=0.0015).meshes[0].vertices
+    for order in ((dense, thin), (thin, dense)):
+        v = np.concatenate(order, 0)
+        scene = Scene([Mesh(name="uneven", vertices=v, base_color=(1, 1, 1, 1), textures=synth.procedural_textures(64, 9))])
+        c = Converter(0)
+        c.set_pipeline(pipeline)
+        c.upload_scene(scene)
+        c.set_max_gaussians(0)
+        first = c.convert(300)
+        rec1 = c.download().copy()
+        assert c.last_pipeline == pipeline
+        assert c.convert(300) == first                      # in bands
+        rec2 = c.download()
+        assert np.array_equal(rec1.view(np.uint32), rec2.view(np.uint32)), "banded and unbanded launches differ"
+        for _ in range(3):
+            c.submit(300)
+        for _ in range(3):
+            assert c.wait() == first
+        assert np.array_equal(c.download().view(np.uint32), rec1.view(np.uint32))
+        c.close()
+        ototal, orec, _ = oracle.convert(scene, 300, cap=0, n_threads=8)
+        assert first == ototal
+        assert_records_match(rec1, orec, f"uneven density, {pipeline}")

@@ -24,7 +24,7 @@ for pipe in ("team", "sparse"):
     c.set_max_gaussians(0)
     c.set_profiling(True)
     convs[pipe] = c
-for R in (512, 724, 1024, 1448, 1774, 2048, 2500):
+for R in [int(x) for x in os.environ.get("SC_RS", "512,724,1024,1448,1774,2048,2500").split(",")]:
     row = {"R": R}
     for pipe, c in convs.items():
         total = c.convert(R)

@@ -17,9 +17,21 @@ L = _lib.load(); S, B = 16, 8192
 buf = np.zeros(S * B, np.uint64)
 assert L.m2s_debug_read_timing2(buf.ctypes.data_as(C.c_void_p), C.c_size_t(S * B)) == 0
 t = buf.reshape(S, B).astype(np.float64)
-nb = min(B, ((scene.n_triangles + 63) // 64 + 3) // 4)
-t = t[:, :nb]
+nb = int((t[7] > 0).sum())          # (a banded launch ends its bands in smaller workgroups: more than triangles / 256)
+t = t[:, t[7] > 0]
 def st(x): return f"median {np.median(x):9.0f} mean {x.mean():9.0f} p90 {np.percentile(x, 90):9.0f}"
 print("workgroups", nb, "(wave 0 of each)")
 for i, name in enumerate(["total", "wait counts", "wait entries", "wait base", "strips", "entries / workgroup"]):
     print(f"{name:22s}", st(t[i]))
+
+# timeline: how many workgroups are in flight over the kernel's duration, and when each XCD runs out of work
+t0, t1, xcd = t[6], t[7], t[8].astype(int)
+if t1.max() > 0:
+    z = t0.min(); t0 = t0 - z; t1 = t1 - z; span = t1.max()
+    print(f"kernel span {span:.0f} ticks of 10 ns (first start to last end, wave 0 of each workgroup); sum of workgroup times / span = {(t1 - t0).sum() / span:.1f} in flight on average")
+    edges = np.linspace(0, span, 21)
+    occ = [(np.minimum(t1, b) - np.maximum(t0, a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
+    print("in flight per 5 % of the span:", " ".join(f"{o:.0f}" for o in occ))
+    for x in range(8):
+        m = xcd == x
+        if m.any(): print(f"XCD {x}: workgroups {m.sum():5d} first start {t0[m].min():7.0f} last start {t0[m].max():7.0f} last end {t1[m].max():7.0f} entries {t[5][m].sum():9.0f} busy {(t1[m] - t0[m]).sum():11.0f}")
