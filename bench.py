@@ -374,11 +374,24 @@ def stored_of(rig):
     return rig.conv.num_stored
 
 
-def whole_conversion_roofline(total_stored, tri, ms):
-    """96 B per STORED Gaussian + 144 B per triangle over the whole conversion's time."""
+def whole_conversion_roofline(total_stored, tri, ms, traffic_key=None):
+    """96 B per STORED Gaussian + 144 B per triangle over the whole conversion's time.  traffic_key: the entry of
+    profiles/pmc_traffic.json that holds the HBM bytes per launch of this workload's dominant kernel (committed PMC passes)."""
     b = 96.0 * total_stored + 144.0 * tri
     gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {"algorithmic_bytes": b, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    out = {"algorithmic_bytes": b, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    if traffic_key:
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(traffic_key, {})
+            if t.get("algorithmic_bytes") == b:      # the same workload, to the byte
+                k = t["kernel"]
+                out["traffic"] = t[k + "_hbm_bytes_per_launch"]
+                out["traffic_kernel"] = k
+                out["traffic_source"] = "NOT measured in this run: committed rocprofv3 --pmc passes (profiles/pmc_traffic.json)"
+        except Exception:  # noqa: BLE001
+            pass
+    return out
 
 
 def cold_path(torch, local_rank, scene, R, steady_sync_ms):
@@ -464,7 +477,7 @@ def extra_workload(torch, dist, local_rank, name, steps=24, warmup=3):
            "stored": int(stored_of(rig)), "ms_per_step": ms, "value": total / (ms * 1e-3), "value_stored": stored_of(rig) / (ms * 1e-3),
            "pipeline": rig.conv.last_pipeline,
            "kernel_ms": {a: b for a, b in k.items() if b > 0}, "kernels_total_ms": kern,
-           "roofline_whole_conversion": whole_conversion_roofline(stored_of(rig), scene.n_triangles, kern)}
+           "roofline_whole_conversion": whole_conversion_roofline(stored_of(rig), scene.n_triangles, kern, traffic_key=name)}
     rig.close()
     return res
 
@@ -499,7 +512,7 @@ def c5_workload(torch, local_rank, steps=8):
            "stored": int(conv.num_stored), "ms_per_step": ms, "value": total / (ms * 1e-3), "value_stored": conv.num_stored / (ms * 1e-3),
            "pipeline": conv.last_pipeline, "kernels_total_ms": kms, "submission": "one blocking call per step",
            "host_generation_s": gen_s, "upload_s": up_s,
-           "roofline_whole_conversion": whole_conversion_roofline(conv.num_stored, T, kms)}
+           "roofline_whole_conversion": whole_conversion_roofline(conv.num_stored, T, kms, traffic_key="c5")}
     conv.close()
     return res
 

@@ -341,9 +341,10 @@ const char* m2s_io_last_error(void);
  *     kernel (k_emit_big, one workgroup per 1024-fragment chunk); a scene DOMINATED by such triangles falls through
  *     to the multi-pass pipeline;
  *   - otherwise the MULTI-PASS pipeline count -> scan -> offsets -> emit (output-range balanced, any triangle size).
- *   - fewer than ONE fragment per triangle on average (a mesh far finer than the density asked for; BASELINE config 5):
- *     the SPARSE form of the single-pass kernel (k_sparse): a cheap conservative test drops the triangles that cannot cover
- *     a pixel centre before the exact per-triangle phase runs on the survivors; k_fused2 where a workgroup does not fit.
+ *   - a mesh far finer than the density asked for (BASELINE config 5) — fewer than 1.75 fragments per triangle on average
+ *     in a scene of at least 2 M triangles, fewer than 0.5 in a smaller one (measured crossovers): the SPARSE form of the
+ *     single-pass kernel (k_sparse): a cheap conservative test drops the triangles that cannot cover a pixel centre before
+ *     the exact per-triangle phase runs on the survivors; k_fused2 where a workgroup does not fit.
  * MULTIPASS forces the multi-pass pipeline, WAVE / TEAM / SPARSE force the single-pass kernel in one of its forms.  Every
  * setting produces bit-identical output.  Changing the setting forgets the remembered decisions. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,

@@ -191,8 +191,11 @@ static void free_scene(m2s_ctx* c) {
 // What is remembered about this scene at resolution R (created on first use; the table is bounded: a slider dragged
 // through hundreds of densities simply starts over).
 constexpr int kBandSlots = 64;
-constexpr double kSparseFragsPerTriangle = 1.5;   // AUTO: below this many fragments per triangle the sparse kernel runs (measured
-                                                  // crossover against k_fused2: above 1.8; a workgroup's stream overflows from ~2.5)
+// AUTO: below this many fragments per triangle the sparse kernel runs.  Measured against k_fused2 on cube-spheres
+// (tools/sparse_crossover.py, profiles/r03/v3_sparse_crossover_*): with 3 M and 6.2 M triangles k_sparse is ahead up to 1.75
+// fragments per triangle (a workgroup's stream overflows from ~2.5); with 1 M triangles — 2.5 generations of its 512-triangle
+// workgroups — k_fused2 is ahead down to 0.68 at least.
+static double sparse_frags_per_triangle(uint32_t n_tri) { return n_tri >= 2000000u ? 1.75 : 0.5; }
 static m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     auto it = c->rinfo.find(R);
     if (it != c->rinfo.end()) return it->second;
@@ -848,7 +851,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
         ri.multipass = frags >= 11.0 * (double)sc.n_tri;
         // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
         // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
-        ri.sparse = !ri.multipass && frags < kSparseFragsPerTriangle * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
+        ri.sparse = !ri.multipass && frags < sparse_frags_per_triangle(sc.n_tri) * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
     }
 
     // ---- where do the records go, and how many may be stored? ------------------------------------
