@@ -144,3 +144,44 @@ def test_group_with_a_missing_rank_can_be_created_and_destroyed(hiplib):
     ex = m2d.RcclExchange(0, 0, 2, m2d.local_bootstrap(ident))
     assert ex.world == 2 and ex.rank == 0
     ex.close()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_a_rank_that_fails_locally_takes_every_rank_out_of_the_sort_together(hiplib, world, bad_rank):
+    """a collective is entered by every rank or by none.  One rank's context holds no records (its local sort fails
+    with M2S_ERR_STATE); it still contributes to the first all-gather — with a non-zero status word — and EVERY rank returns an
+    error from m2s_dist_sort_by_depth instead of waiting for it.  The group stays usable: the same ranks then sort for real."""
+    scene, R = synth.cube_sphere(20, tex_size=32), 144
+    view = camera.look_at((1.6, 1.1, 2.3), (0.1, 0.0, -0.1))
+    c0, total, _ = _whole(scene, R)
+    want = c0.sort_by_depth(view)
+    c0.close()
+    plan = m2d.shard_ranges_native(scene, R, world)
+
+    def body(rank, ex):
+        c = Converter(0)
+        c.set_triangle_range(*plan[rank])
+        c.upload_scene(scene)
+        c.set_max_gaussians(0)
+        if rank != bad_rank:
+            c.convert(R)                      # the bad rank never converts: nothing to sort
+        with pytest.raises(RuntimeError) as e:
+            ex.sort_by_depth(c, view)
+        first = str(e.value)
+        if rank == bad_rank:
+            c.convert(R)
+        n, off = ex.sort_by_depth(c, view)    # second attempt, every rank has records now
+        got = c.download_sorted()
+        c.close()
+        return first, n, off, got
+
+    results = _run_ranks(world, body)
+    for rank, (first, _, _, _) in enumerate(results):
+        if rank != bad_rank:
+            assert f"rank {bad_rank} reported a failure" in first, first
+    assert sum(n for _, n, _, _ in results) == total
+    run = 0
+    for rank, (_, n, off, got) in enumerate(results):
+        assert off == run
+        assert np.array_equal(got.view(np.uint32), want[run:run + n].view(np.uint32)), f"rank {rank}: slice differs"
+        run += n
