@@ -242,8 +242,10 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto& ev : c->stage_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    unsigned done_flags = hipEventDisableTiming;   // (completion only: its time is never asked for)
+    if (const char* v = std::getenv("M2S_DONE_EVENT_FLAGS")) done_flags = (unsigned)strtoul(v, nullptr, 0);   // debug: A/B of event kinds
     for (auto& sl : c->slot)
-        if ((e = hipEventCreate(&sl.done)) != hipSuccess || (e = hipEventCreate(&sl.t0)) != hipSuccess ||
+        if ((e = hipEventCreateWithFlags(&sl.done, done_flags)) != hipSuccess || (e = hipEventCreate(&sl.t0)) != hipSuccess ||
             (e = hipEventCreate(&sl.t1)) != hipSuccess)
             return bail("hipEventCreate", e);
     *out_ctx = c;
