@@ -645,7 +645,14 @@ static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t u
 // behind a launch that recorded its workgroups' bases: cut the bands of the next launches at this R
 static void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st) {
     const uint32_t n_wg = band_workgroups(c, unit);
-    launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg),
+    // estimated work per triangle / per fragment.  k_fused2: 214 / 140 (cycles of its triangle phase per 64 triangles and of a strip per 64
+    // fragments, tools/team_timing.py; config 3 is insensitive between 100 and 300 per triangle).  k_sparse: most triangles only pay
+    // tier 1: 160 / 140, measured on config 5 at full size (profiles/r03/ab_band_cost_weights_c5.log; the linear model is crude there —
+    // per-XCD spans still differ by 6-9 %, tools/xcd_spans.py — but cutting by MEASURED workgroup lifetimes was no better on config 5
+    // and much worse on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched)
+    uint32_t cost_tri = unit == 256u ? 214u : 160u, cost_frag = 140;
+    if (const char* v = std::getenv("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
+    launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg), cost_tri, cost_frag,
                       c->d_bands + (size_t)ri.band_slot * kBandTableWords, st);
 }
 

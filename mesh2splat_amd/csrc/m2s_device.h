@@ -120,9 +120,9 @@ struct BandInfo {
 // as long as its slowest XCD).  tri_per_wg: 256 (k_fused2) or 512 (k_sparse);
 // *total = the fragment count of that launch.
 void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, unsigned long long* table, hipStream_t st);
+                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, hipStream_t st);
 // most workgroups the picker may give a band of a scene of n_wg (8 x this many are launched): balanced bands are uneven
-inline uint32_t band_max_width(uint32_t n_wg) { const uint32_t w = (n_wg + 7u) / 8u; return w + w / 4u + 1u; }
+inline uint32_t band_max_width(uint32_t n_wg) { const uint32_t w = (n_wg + 7u) / 8u; return w + w / 2u + 1u; }
 // Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
 // = triangles [first[b], first[b + 1]), at most 64, starts at multiples of 8.  first == nullptr: uniform batches of fused_tpw.
 struct BatchTable {

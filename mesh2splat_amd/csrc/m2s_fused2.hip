@@ -534,13 +534,13 @@ uint32_t fused2_band_workgroups(uint32_t n_tri) {
 // triangle, 140 per fragment) is monotone in w: cut k is the first workgroup with cost >= k / 8 of the whole.
 __global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __restrict__ wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
                                                    const unsigned long long* __restrict__ total, uint32_t max_width,
-                                                   unsigned long long* __restrict__ table) {
+                                                   uint32_t cost_tri, uint32_t cost_frag, unsigned long long* __restrict__ table) {
     __shared__ uint32_t cut[9];
     const uint32_t k = threadIdx.x;
     const unsigned long long tot = *total;
     auto cost = [&](uint32_t w) -> unsigned long long {
         const unsigned long long tri = min((unsigned long long)w * tri_per_wg, (unsigned long long)n_tri);
-        return 214ull * tri + 140ull * (w < n_wg ? wg_base[w] : tot);
+        return (unsigned long long)cost_tri * tri + (unsigned long long)cost_frag * (w < n_wg ? wg_base[w] : tot);
     };
     if (k <= 8u) {
         const unsigned long long target = cost(n_wg) / 8ull * k;
@@ -565,8 +565,8 @@ __global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __r
 }
 
 void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, unsigned long long* table, hipStream_t st) {
-    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, table);
+                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, hipStream_t st) {
+    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, cost_tri, cost_frag, table);
 }
 
 #ifdef M2S_TIMING

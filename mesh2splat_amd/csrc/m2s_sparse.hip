@@ -62,6 +62,9 @@ constexpr int kSpTimingSlots = 32, kSpTimingBlocks = 16384;   // [16..21] first 
 __device__ unsigned long long g_sp_timing[kSpTimingSlots * kSpTimingBlocks];
 #define SP_T(slot, v) do { if (wave == 0 && lane == 0 && lb < kSpTimingBlocks) g_sp_timing[(slot) * kSpTimingBlocks + lb] = (v); } while (0)
 #define SP_NOW() __builtin_amdgcn_s_memtime()
+// per XCD: [x] earliest start, [8 + x] latest end of a workgroup (s_memrealtime, 100 MHz, common to all XCDs), [16 + x] sum of
+// wave-0 lifetimes, [24 + x] workgroups; reset by the reader (tools/xcd_spans.py)
+__device__ unsigned long long g_sp_xcd[32];
 #else
 #define SP_T(slot, v) do {} while (0)
 #define SP_NOW() 0ull
@@ -202,6 +205,10 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     const uint32_t t_wg = lb * kSpCand;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     [[maybe_unused]] const unsigned long long tk0 = SP_NOW();      // phase timers: live only in -DM2S_TIMING builds
+#ifdef M2S_TIMING
+    const unsigned long long tk_real0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) atomicMin(&g_sp_xcd[xcd], tk_real0);
+#endif
     [[maybe_unused]] unsigned long long tk_rounds = 0, tk_pre = 0, tk_cnt = 0, tk_strips = 0, tk_exp = 0, tk_base = 0, my_rounds = 0, my_strips = 0;
 
     if (threadIdx.x < (unsigned)kSpRounds) { S.counted[threadIdx.x] = 0; S.expanded[threadIdx.x] = 0; }
@@ -601,6 +608,14 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     tk_strips = SP_NOW() - ts0;
     SP_T(0, SP_NOW() - tk0); SP_T(2, tk_rounds); SP_T(3, tk_pre); SP_T(4, tk_cnt); SP_T(5, tk_strips); SP_T(6, tk_exp); SP_T(7, tk_base);
     SP_T(8, (unsigned long long)nr); SP_T(9, (unsigned long long)stream_total); SP_T(10, (unsigned long long)NS); SP_T(11, my_rounds); SP_T(12, my_strips);
+#ifdef M2S_TIMING
+    if (threadIdx.x == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_sp_xcd[8u + xcd], now);
+        atomicAdd(&g_sp_xcd[16u + xcd], now - tk_real0);
+        atomicAdd(&g_sp_xcd[24u + xcd], 1ull);
+    }
+#endif
     // ======================= epilogue: the workgroup's inclusive prefix / the counter (by the last wave to get here) ======
     uint32_t last = 0;
     if (lane == 0) last = __hip_atomic_fetch_add(&S.done_waves, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)kSpWaves - 1u ? 1u : 0u;
@@ -638,6 +653,13 @@ uint32_t sparse_workgroups(uint32_t n_tri) { return (n_tri + kSpCand - 1u) / kSp
 #ifdef M2S_TIMING
 extern "C" int m2s_debug_read_timing_sparse(unsigned long long* dst, size_t n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sp_timing), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int m2s_debug_read_xcd_spans_sparse(unsigned long long* dst /* [32] */) {
+    const int e = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sp_xcd), 32 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+    unsigned long long init[32];
+    for (int i = 0; i < 32; ++i) init[i] = i < 8 ? ~0ull : 0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_xcd), init, sizeof init, 0, hipMemcpyHostToDevice);
+    return e;
 }
 #endif
 
