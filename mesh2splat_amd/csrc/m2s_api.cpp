@@ -30,6 +30,7 @@ const char* const kStaleMsg = "the records of the conversion last waited for hav
                               "(wait for it, or submit into your own buffers)";
 }  // namespace
 
+constexpr int kBandSlotsMax = 64;   // (scene, R) entries remembered per context: band tables, decisions
 struct m2s_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -69,6 +70,7 @@ struct m2s_ctx {
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
         bool bands_ready = false;  // d_bands[band_slot] holds the XCD band table (cuts + bases) for this R ...
         uint32_t bands_unit = 0;   // ... in workgroups of this many triangles (256: cut from a k_fused2 launch, 512: k_sparse)
+        uint32_t band_width = 0;   // ... whose widest band has this many workgroups (the grid of a banded launch is 8 x this)
         int band_slot = 0;
         uint32_t gen = 0;          // generation of the table this entry belongs to (the table starts over when it is full)
     };
@@ -76,6 +78,7 @@ struct m2s_ctx {
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
     unsigned long long* d_bands = nullptr;  // kBandSlots x kBandTableWords: XCD band tables (device)
+    unsigned long long* h_bands = nullptr;  // kBandSlots x 9 (pinned): the cuts of each table, written by k_pick_bands itself
     unsigned long long* d_wg_base = nullptr;   // where every workgroup's output started in the newest launch without bands
     uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
@@ -190,7 +193,7 @@ static void free_scene(m2s_ctx* c) {
 
 // What is remembered about this scene at resolution R (created on first use; the table is bounded: a slider dragged
 // through hundreds of densities simply starts over).
-constexpr int kBandSlots = 64;
+constexpr int kBandSlots = kBandSlotsMax;
 // AUTO: below this many fragments per triangle the sparse kernel runs.  Measured against k_fused2 on cube-spheres
 // (tools/sparse_crossover.py, profiles/r03/v3_sparse_crossover_*): with 3 M and 6.2 M triangles k_sparse is ahead up to 1.75
 // fragments per triangle (a workgroup's stream overflows from ~2.5); with 1 M triangles — 2.5 generations of its 512-triangle
@@ -238,6 +241,9 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->h_total, (4 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->h_bands, (size_t)kBandSlotsMax * 9 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+    memset(c->h_bands, 0, (size_t)kBandSlotsMax * 9 * sizeof(unsigned long long));
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto& ev : c->stage_ev)
@@ -288,6 +294,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->h_bands) (void)hipHostFree(c->h_bands);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : c->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -635,9 +642,9 @@ static BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t u
     if (writes) *writes = false;
     const uint32_t n_wg = band_workgroups(c, unit);
     if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || env_on("M2S_NO_BANDS")) return b;
-    if (ri.bands_ready && ri.bands_unit == unit) {
+    if (ri.bands_ready && ri.bands_unit == unit && ri.band_width) {
         b.table = c->d_bands + (size_t)ri.band_slot * kBandTableWords;
-        b.max_width = band_max_width(n_wg);
+        b.max_width = ri.band_width;
     }
     else if (may_write) { b.out = c->d_wg_base; if (writes) *writes = true; }
     return b;
@@ -647,13 +654,26 @@ static void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit
     const uint32_t n_wg = band_workgroups(c, unit);
     // estimated work per triangle / per fragment.  k_fused2: 214 / 140 (cycles of its triangle phase per 64 triangles and of a strip per 64
     // fragments, tools/team_timing.py; config 3 is insensitive between 100 and 300 per triangle).  k_sparse: most triangles only pay
-    // tier 1: 160 / 140, measured on config 5 at full size (profiles/r03/ab_band_cost_weights_c5.log; the linear model is crude there —
-    // per-XCD spans still differ by 6-9 %, tools/xcd_spans.py — but cutting by MEASURED workgroup lifetimes was no better on config 5
-    // and much worse on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched)
-    uint32_t cost_tri = unit == 256u ? 214u : 160u, cost_frag = 140;
+    // tier 1: 115 / 140, measured on config 5 at full size (profiles/r03/ab_band_cost_weights_c5.log: 100 / 140 2.86 ms, 115 2.86,
+    // 130 2.90, 145 2.93, 160 2.99, 85 2.96).  (Cutting by MEASURED workgroup lifetimes instead was no better there and much worse
+    // on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched.)
+    uint32_t cost_tri = unit == 256u ? 214u : 115u, cost_frag = 140;
     if (const char* v = std::getenv("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
     launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg), cost_tri, cost_frag,
-                      c->d_bands + (size_t)ri.band_slot * kBandTableWords, st);
+                      c->d_bands + (size_t)ri.band_slot * kBandTableWords, c->h_bands + (size_t)ri.band_slot * 9, st);
+}
+
+// the conversion that cut the bands has completed: how wide is the widest one?  (0: the cuts do not describe this scene — never used)
+static uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit) {
+    const unsigned long long* cut = c->h_bands + (size_t)ri.band_slot * 9;
+    const uint32_t n_wg = band_workgroups(c, unit);
+    if (!n_wg || cut[0] != 0 || cut[8] != n_wg) return 0;
+    uint32_t w = 0;
+    for (int x = 0; x < 8; ++x) {
+        if (cut[x + 1] < cut[x]) return 0;
+        w = std::max<uint32_t>(w, (uint32_t)(cut[x + 1] - cut[x]));
+    }
+    return w;
 }
 
 static BatchTable batches_for(const m2s_ctx* c) {
@@ -912,7 +932,7 @@ static m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_c
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
+            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit); }
             if (err && std::getenv("M2S_DEBUG"))
                 fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
             if (!(err && (team || sparse))) break;
@@ -1185,7 +1205,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
         (void)hipStreamSynchronize(c->stream);
         return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
     }
-    if (sl.wrote_bands && rip) { rip->bands_ready = true; rip->bands_unit = sl.bands_unit; }   // that launch has completed: its band table is in place
+    if (sl.wrote_bands && rip) { rip->bands_ready = true; rip->bands_unit = sl.bands_unit; rip->band_width = band_width_of(c, *rip, sl.bands_unit); }   // that launch has completed: its band table is in place
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);

@@ -1,6 +1,7 @@
 // m2s_device.h — device-side data layout and launcher prototypes (internal; the public
 // boundary is include/m2s.h).  gfx950 only.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -112,7 +113,7 @@ constexpr uint32_t kBandWg = 8;      // [x], x <= 8: first workgroup (= chain wo
 constexpr int kBandTableWords = 24;   // (17 used)
 struct BandInfo {
     const unsigned long long* table;  // banded launch (max_width != 0): the table above
-    uint32_t max_width;               // banded launch: no band has more workgroups than this (the grid is 8 x max_width)
+    uint32_t max_width;               // banded launch: the widest band's workgroups (the grid is 8 x max_width); 0: no bands
     unsigned long long* out;          // launch WITHOUT bands, or nullptr: out[workgroup] = record index at which its output starts
 };
 // The bands of the NEXT launches at this R, from what a launch without bands left in `wg_base`: eight runs of consecutive
@@ -120,9 +121,10 @@ struct BandInfo {
 // as long as its slowest XCD).  tri_per_wg: 256 (k_fused2) or 512 (k_sparse);
 // *total = the fragment count of that launch.
 void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, hipStream_t st);
-// most workgroups the picker may give a band of a scene of n_wg (8 x this many are launched): balanced bands are uneven
-inline uint32_t band_max_width(uint32_t n_wg) { const uint32_t w = (n_wg + 7u) / 8u; return w + w / 2u + 1u; }
+                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table,
+                       unsigned long long* host_cuts /* [9], pinned: the cuts, for the host */, hipStream_t st);
+// widest band the picker may cut (a bound on the grid of a banded launch: 8 x the widest band ACTUALLY cut, which the host learns)
+inline uint32_t band_max_width(uint32_t n_wg) { return (n_wg + 7u) / 8u * 4u + 1u; }
 // Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
 // = triangles [first[b], first[b + 1]), at most 64, starts at multiples of 8.  first == nullptr: uniform batches of fused_tpw.
 struct BatchTable {

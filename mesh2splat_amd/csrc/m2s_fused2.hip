@@ -534,7 +534,8 @@ uint32_t fused2_band_workgroups(uint32_t n_tri) {
 // triangle, 140 per fragment) is monotone in w: cut k is the first workgroup with cost >= k / 8 of the whole.
 __global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __restrict__ wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
                                                    const unsigned long long* __restrict__ total, uint32_t max_width,
-                                                   uint32_t cost_tri, uint32_t cost_frag, unsigned long long* __restrict__ table) {
+                                                   uint32_t cost_tri, uint32_t cost_frag, unsigned long long* __restrict__ table,
+                                                   unsigned long long* __restrict__ host_cuts /* [9], pinned host memory */) {
     __shared__ uint32_t cut[9];
     const uint32_t k = threadIdx.x;
     const unsigned long long tot = *total;
@@ -561,12 +562,14 @@ __global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __r
         }
         for (uint32_t j = 0; j < 8u; ++j) table[kBandBase + j] = cut[j] < n_wg ? wg_base[cut[j]] : tot;
         for (uint32_t j = 0; j <= 8u; ++j) table[kBandWg + j] = cut[j];
+        // the host learns the cuts too (it waits for this conversion before it uses them): a banded launch is as wide as the widest band
+        for (uint32_t j = 0; j <= 8u; ++j) __hip_atomic_store(&host_cuts[j], (unsigned long long)cut[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, hipStream_t st) {
-    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, cost_tri, cost_frag, table);
+                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, unsigned long long* host_cuts, hipStream_t st) {
+    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, cost_tri, cost_frag, table, host_cuts);
 }
 
 #ifdef M2S_TIMING

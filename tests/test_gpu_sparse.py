@@ -132,7 +132,8 @@ def test_auto_picks_sparse_and_async_submissions(hiplib, oracle):
 def test_bands_of_equal_work_on_uneven_density(hiplib, oracle, pipeline):
     """The second conversion at an R runs in XCD bands cut (k_pick_bands) from what the first one recorded: eight runs of
     workgroups of equal estimated work.  Here the fragments sit in the first third of the triangle list (the cuts are far from
-    equal lengths and the width limit of a band applies) — and, turned around, in the last third."""
+    equal lengths: the widest band is ~1.5x the narrowest, and the launch is as wide as the widest) — and, turned around, in the last
+    third."""
     # (k_sparse: a workgroup's 512 triangles must stay within its LDS stream of 2560 entries)
     dense = synth.random_soup(80_000, seed=31, tri_size=0.02 if pipeline == "team" else 0.012).meshes[0].vertices
     thin = synth.random_soup(170_000, seed=32, tri_size=0.0015).meshes[0].vertices
