@@ -22,6 +22,7 @@
 //                 exactly like the single-pass kernel does: record staged half a wave at a time, 16 B/lane non-temporal
 //                 stores.  10.5 KB of LDS per wave.  Output-partitioned, so balanced for ANY triangle size.
 // Output: bit-identical to every other pipeline (same device functions, same operation order).
+#include <cstdlib>
 #include "m2s_fused_common.h"
 #include <algorithm>
 
@@ -215,20 +216,25 @@ static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of fou
 __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ start,
                                                      const unsigned long long* __restrict__ total_p, unsigned long long limit,
-                                                     const float4* __restrict__ setup, float4* __restrict__ out) {
+                                                     const float4* __restrict__ setup, float4* __restrict__ out,
+                                                     uint32_t run /* consecutive workgroups per XCD turn */) {
     __shared__ Emit2Lds lds_all[kBlock / 64];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Emit2Lds& L = lds_all[wave];
     const unsigned long long total = *total_p;
     const unsigned long long nw = total < limit ? total : limit;  // records actually stored
-    // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): every XCD gets one CONTIGUOUS part
-    // of the output — of the mesh surface, of texture space — instead of every 8th workgroup.
+    // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): the XCDs take turns of `run` consecutive
+    // workgroups — runs of the output, of the mesh surface, of texture space meet in ONE L2 —, block-cyclically.  Until round 3
+    // every XCD had one contiguous EIGHTH of the output: fine for one uniform mesh, but a record does not cost the same
+    // everywhere (triangles per slice, magnified or minified maps): on the C4 stand-in the kernel ran 7 % faster with NO mapping
+    // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
+    // inter-workgroup dependency, so any mapping is correct.
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
-    const uint32_t per_xcd = (nblk + 7) / 8;
-    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || lblock >= nblk) return;
+    const uint32_t xcd = blockIdx.x & 7u, turn = (blockIdx.x >> 3) / run, in_run = (blockIdx.x >> 3) % run;
+    const uint32_t lblock = (turn * 8u + xcd) * run + in_run;
+    if (lblock >= nblk) return;
     const uint32_t slice = lblock * (kBlock / 64) + wave;
     const unsigned long long wbase64 = (unsigned long long)slice * kSlice;
     if (wbase64 >= nw) return;
@@ -422,9 +428,11 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
     if (!sc.n_tri || !limit) return;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     uint32_t n_blocks = (uint32_t)((limit + per_wg - 1) / per_wg);
-    n_blocks = (n_blocks + 7u) & ~7u;  // the XCD swizzle needs whole groups of 8
+    uint32_t run = 16;                          // workgroups per XCD turn (profiles/r03/ab_emit2_xcd_turns.log)
+    if (const char* v = std::getenv("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
+    n_blocks = (n_blocks + 8u * run - 1u) / (8u * run) * (8u * run);   // whole rounds of turns; surplus workgroups leave at once
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
-                       (const float4*)setup, out);
+                       (const float4*)setup, out, run);
 }
 
 }  // namespace m2s
