@@ -14,7 +14,7 @@
 // loads); a wave waits for the COUNTS of the waves before it (to know where its entries go) and, per strip, for the
 // EXPANSION of the waves whose entries the strip contains.  No __syncthreads.  Every wait is bounded and raises the
 // error flag instead of hanging; so does a workgroup whose fragments do not fit the LDS stream (kEntries) — the host
-// then repeats the conversion with k_fused (m2s_api.cpp, run_pass) and remembers that for the scene and R.
+// then repeats the conversion with k_fused (m2s_pass.cpp, run_pass) and remembers that for the scene and R.
 #include "m2s_fused_common.h"
 
 #pragma clang fp contract(off)

@@ -1,0 +1,412 @@
+// m2s_pass.cpp — the conversion pass driver (== ConversionPass::execute, src/renderer/renderPasses/ConversionPass.cpp:9-68):
+// pipeline choice, XCD band tables, the single-pass kernels with their fallbacks, the multi-pass pipeline.
+#include "m2s_ctx.h"
+#include "m2s_ply.h"
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+using namespace m2s;
+using namespace m2s_host;
+
+namespace {
+// AUTO: below this many fragments per triangle the sparse kernel runs.  Measured against k_fused2 on cube-spheres
+// (tools/sparse_crossover.py, profiles/r03/v3_sparse_crossover_*): with 3 M and 6.2 M triangles k_sparse is ahead up to 1.75
+// fragments per triangle (a workgroup's stream overflows from ~2.5); with 1 M triangles — 2.5 generations of its 512-triangle
+// workgroups — k_fused2 is ahead down to 0.68 at least.
+static double sparse_frags_per_triangle(uint32_t n_tri) { return n_tri >= 2000000u ? 1.75 : 0.5; }
+static bool env_on(const char* name) { const char* v = std::getenv(name); return v && *v && *v != '0'; }   // (debug switches)
+// XCD bands for this launch of k_fused2 (unit 256) or k_sparse (unit 512 triangles per workgroup): the table an earlier launch
+// of the same kernel at this R left behind — or, if there is none, ask this launch to record where every workgroup's output
+// starts, from which the table is cut right behind it (second lane: never asked to — two lanes would race on d_wg_base)
+static uint32_t band_workgroups(const m2s_ctx* c, uint32_t unit) {
+    const uint32_t team = fused2_band_workgroups(c->scene.n_tri);
+    return !team ? 0u : unit == 256u ? team : sparse_workgroups(c->scene.n_tri);
+}
+}  // namespace
+
+namespace m2s_host {
+// Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless a workgroup's
+// fragments did not fit its LDS stream at this R before.
+bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    return !(c->pipeline == M2S_PIPELINE_WAVE || ri.team_off);
+}
+// ... or its sparse form (m2s_sparse.hip): meshes with fewer fragments than triangles, large enough for 64-triangle batches
+bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    return (c->pipeline == M2S_PIPELINE_SPARSE || (c->pipeline == M2S_PIPELINE_AUTO && ri.sparse)) && !ri.sparse_off &&
+           sparse_supported(c->scene.n_tri);
+}
+BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes) {
+    BandInfo b{};
+    if (writes) *writes = false;
+    const uint32_t n_wg = band_workgroups(c, unit);
+    if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || env_on("M2S_NO_BANDS")) return b;
+    if (ri.bands_ready && ri.bands_unit == unit && ri.band_width) {
+        b.table = c->d_bands + (size_t)ri.band_slot * kBandTableWords;
+        b.max_width = ri.band_width;
+    }
+    else if (may_write) { b.out = c->d_wg_base; if (writes) *writes = true; }
+    return b;
+}
+// behind a launch that recorded its workgroups' bases: cut the bands of the next launches at this R
+void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st) {
+    const uint32_t n_wg = band_workgroups(c, unit);
+    // estimated work per triangle / per fragment.  k_fused2: 214 / 140 (cycles of its triangle phase per 64 triangles and of a strip per 64
+    // fragments, tools/team_timing.py; config 3 is insensitive between 100 and 300 per triangle).  k_sparse: most triangles only pay
+    // tier 1: 115 / 140, measured on config 5 at full size (profiles/r03/ab_band_cost_weights_c5.log: 100 / 140 2.86 ms, 115 2.86,
+    // 130 2.90, 145 2.93, 160 2.99, 85 2.96).  (Cutting by MEASURED workgroup lifetimes instead was no better there and much worse
+    // on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched.)
+    uint32_t cost_tri = unit == 256u ? 214u : 115u, cost_frag = 140;
+    if (const char* v = std::getenv("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
+    launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg), cost_tri, cost_frag,
+                      c->d_bands + (size_t)ri.band_slot * kBandTableWords, c->h_bands + (size_t)ri.band_slot * 9, st);
+}
+
+// the conversion that cut the bands has completed: how wide is the widest one?  (0: the cuts do not describe this scene — never used)
+uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit) {
+    const unsigned long long* cut = c->h_bands + (size_t)ri.band_slot * 9;
+    const uint32_t n_wg = band_workgroups(c, unit);
+    if (!n_wg || cut[0] != 0 || cut[8] != n_wg) return 0;
+    uint32_t w = 0;
+    for (int x = 0; x < 8; ++x) {
+        if (cut[x + 1] < cut[x]) return 0;
+        w = std::max<uint32_t>(w, (uint32_t)(cut[x + 1] - cut[x]));
+    }
+    return w;
+}
+
+BatchTable batches_for(const m2s_ctx* c) {
+    return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab } : BatchTable{ nullptr, 0u };
+}
+
+uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
+    if (c->cap_policy == 0) return 0;
+    if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
+    // ConversionPass.cpp:21-24 (unsigned int arithmetic wraps)
+    const uint32_t mc = std::max<uint32_t>(1u, c->n_meshes_total);
+    const uint32_t mx = R * R * 6u * mc;
+    return std::min(mx, kMaxGaussiansToSort);
+}
+}  // namespace m2s_host
+
+// exact fragment count of the scene at R (k_count + scan + read-back): the one host round trip a NEW SCENE pays
+static m2s_status count_now(m2s_ctx* c, uint32_t R, hipStream_t st) {
+    const SceneDev& sc = c->scene;
+    const bool prof = c->profiling;
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_count(sc, R, c->d_cnt, c->d_partials, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (prof)
+        for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
+    c->frag_per_R2 = (double)c->h_total[0] / ((double)R * (double)R);
+    // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
+    // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
+    // cube-sphere face).  Work = 214 per triangle + 140 per fragment (cycles of the triangle phase per 64 triangles and of a strip
+    // per 64 fragments, tools/team_timing.py); fragments scale with R^2 everywhere alike, so the table serves every density.
+    if (batch_table_capacity(sc.n_tri) && !c->n_batch_tab && !std::getenv("M2S_NO_BATCH_TABLE")) {
+        try {
+            std::vector<uint32_t> cnt(sc.n_tri), first;
+            HIPCHK(c, hipMemcpy(cnt.data(), c->d_cnt, (size_t)sc.n_tri * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            const uint32_t n_target = n_fused_waves(sc.n_tri);
+            const double ct = 214.0, cf = 140.0;
+            double total = 0.0;
+            for (uint32_t t = 0; t < sc.n_tri; ++t) total += ct + cf * (double)cnt[t];
+            const double quota = total / (double)n_target;
+            first.reserve(batch_table_capacity(sc.n_tri));
+            first.push_back(0);
+            double acc = 0.0;
+            uint32_t in_batch = 0;
+            for (uint32_t g = 0; g < sc.n_tri; g += 8) {          // batches start at multiples of 8 (mesh_of8)
+                const uint32_t ge = std::min(g + 8u, sc.n_tri);
+                double gc = 0.0;
+                for (uint32_t t = g; t < ge; ++t) gc += ct + cf * (double)cnt[t];
+                // close the batch before this group if it is full, or if the work so far has reached the batch's share
+                if (in_batch && (in_batch + (ge - g) > 64u || acc + 0.5 * gc >= quota * (double)first.size())) { first.push_back(g); in_batch = 0; }
+                acc += gc;
+                in_batch += ge - g;
+            }
+            first.push_back(sc.n_tri);
+            if (first.size() <= batch_table_capacity(sc.n_tri)) {
+                HIPCHK(c, hipMemcpy(c->d_batch_first, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                c->n_batch_tab = (uint32_t)first.size() - 1u;
+            }
+        } catch (...) { /* no table: uniform batches */ }
+    }
+    return M2S_OK;
+}
+
+// Multi-pass pipeline: handles every triangle size, output-balanced.  Second generation (m2s_emit2.hip): k_count_scan
+// (count + offsets + per-triangle setup records, one kernel) -> k_emit2 (wave-granular).  M2S_MULTIPASS_V1=1 selects the
+// first generation (count -> scan -> offsets -> emit, m2s_kernels.hip) for A/B measurements.
+namespace m2s_host {
+bool multipass_v1() { static const bool v1 = std::getenv("M2S_MULTIPASS_V1") != nullptr; return v1; }
+}
+
+static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
+    const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
+    if (c->start_cap < n_start) {
+        drain_in_flight(c);
+        if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
+        const size_t want = std::max<size_t>(std::max<size_t>(n_start, 2 * c->start_cap), 16384);
+        HIPCHK(c, hipMalloc((void**)&c->d_start, want * sizeof(uint32_t)));
+        c->start_cap = want;
+    }
+    if (!multipass_v1() && !c->d_setup) HIPCHK(c, hipMalloc(&c->d_setup, setup_bytes(c->scene.n_tri)));
+    return M2S_OK;
+}
+
+namespace m2s_host {
+// enqueues the pipeline's kernels and the read-back of the counter into *h_res (pinned); no synchronisation
+m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, bool prof,
+                                    unsigned long long* h_res, hipStream_t st) {
+    const SceneDev& sc = c->scene;
+    if (multipass_v1()) {
+        if (!counted) {
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+            launch_count(sc, R, c->d_cnt, c->d_partials, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+        }
+        const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
+        launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+        launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    } else {
+        uint32_t epoch;
+        HIPCHK(c, next_epoch(c, &epoch));
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
+                          reinterpret_cast<uint32_t*>(&h_res[1]), st);
+        if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
+        launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+    return M2S_OK;
+}
+}
+
+static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, hipStream_t st) {
+    const bool prof = c->profiling;
+    { const m2s_status s = ensure_multipass_buffers(c, limit); if (s != M2S_OK) return s; }
+    c->h_total[0] = 0; c->h_total[1] = 0;
+    { const m2s_status s = enqueue_multipass(c, R, d_out, limit, counted, prof, c->h_total, st); if (s != M2S_OK) return s; }
+    HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
+    if (prof) {
+        if (multipass_v1()) { for (int k = counted ? 2 : 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
+        else {
+            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_COUNT], c->ev[0], c->ev[1]));
+            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
+        }
+    }
+    return M2S_OK;
+}
+
+namespace m2s_host {
+m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total,
+                           bool from_submit) {
+    if (!c->has_scene) return fail(c, M2S_ERR_STATE, "m2s_upload_scene has not been called");
+    if (c->slot_count && !from_submit)
+        return fail(c, M2S_ERR_STATE, "conversions submitted with m2s_convert_submit are still in flight: m2s_convert_wait first");
+    if (R == 0 || R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [1, 4096]");
+    HIPCHK(c, hipSetDevice(c->device));
+    // A synchronous conversion shares the work buffers (chain, counts, offsets, deferred-triangle list) with whatever
+    // was submitted before it, possibly on other streams: let that finish first.
+    if (from_submit) drain_in_flight(c);
+    const SceneDev& sc = c->scene;
+    const uint64_t cap = resolve_cap(c, R);
+    const bool prof = c->profiling;
+    c->last_R = R;
+    c->records_stale = false;
+    memset(c->last_ms, 0, sizeof c->last_ms);
+
+    if (sc.n_tri == 0) {
+        c->last_total = c->last_stored = 0;
+        if (!d_user && !c->d_records) {   // (an empty shard is a conversion like any other: its consumers see zero records, not "no conversion")
+            const m2s_status s = ensure_records(c, 1);
+            if (s != M2S_OK) return s;
+        }
+        c->last_records = d_user ? d_user : c->d_records;
+        if (out_total) *out_total = 0;
+        return M2S_OK;
+    }
+    m2s_ctx::RInfo& ri = rinfo_for(c, R);
+
+    // ---- AUTO: which pipeline for this scene at this R? ---------------------------------------------
+    // The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
+    // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
+    // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
+    // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).
+    // The fragment count of a scene is proportional to R^2 (window coordinates scale with R), so ONE exact count — taken
+    // at the scene's first conversion, 0.02-0.06 ms plus a host round trip — decides for every later R without touching
+    // the device: the threshold is not sharp, and both pipelines produce the same bytes anyway.
+    bool counted = false;  // k_count + k_scan already ran in this call, at this R
+    const bool need_estimate = (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) || (!d_user && !cap);
+    if (need_estimate && c->frag_per_R2 < 0.0) {
+        const m2s_status s = count_now(c, R, st);
+        if (s != M2S_OK) return s;
+        counted = true;
+    }
+    const double predicted = c->frag_per_R2 >= 0.0 ? c->frag_per_R2 * (double)R * (double)R : 0.0;
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) {
+        ri.decided = true;
+        const double frags = counted ? (double)c->h_total[0] : predicted;
+        ri.multipass = frags >= 11.0 * (double)sc.n_tri;
+        // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
+        // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
+        ri.sparse = !ri.multipass && frags < sparse_frags_per_triangle(sc.n_tri) * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
+    }
+
+    // ---- where do the records go, and how many may be stored? ------------------------------------
+    uint64_t limit;
+    float4* d_out;
+    if (d_user) {
+        limit = cap ? std::min(cap, user_cap) : user_cap;
+        d_out = (float4*)d_user;
+    } else {
+        // unlimited policy: room for the predicted count plus slack; a conversion that still overflows is repeated below
+        const uint64_t want = cap ? cap : (counted ? std::max<uint64_t>(c->h_total[0], 1) : (uint64_t)(predicted * 1.02) + 4096);
+        const m2s_status s = ensure_records(c, want);
+        if (s != M2S_OK) return s;
+        limit = cap ? cap : c->records_cap;
+        d_out = (float4*)c->d_records;
+    }
+    if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
+
+    for (int round = 0; round < 2; ++round) {
+    // ---- run ---------------------------------------------------------------------------------------
+    bool done = false;
+    if (c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass) {
+        counted = false;   // the fused kernel does its own counting; a count taken above only sized / decided
+        // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
+        // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
+        // counter and its two status words straight into pinned host memory.
+        uint32_t any_big = 0, err = 0;
+        bool wrote_bands = false;
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const bool sparse = use_sparse(c, ri);
+            const bool team = !sparse && use_team(c, ri);
+            c->h_total[0] = 0;
+            c->h_total[1] = 0;
+            uint32_t epoch;
+            HIPCHK(c, next_epoch(c, &epoch));
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
+            const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
+            if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                                      c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), st);
+            else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
+            else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                              c->d_biglist, c->d_bigmeta, st);
+            if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
+            if ((team || sparse) && wrote_bands) pick_bands(c, ri, unit, &c->h_total[0], st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+            if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
+            any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
+            err = (uint32_t)(c->h_total[1] >> 32);
+            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit); }
+            if (err && std::getenv("M2S_DEBUG"))
+                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
+            if (!(err && (team || sparse))) break;
+            // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
+            // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
+            // launch listed, try again.
+            if (sparse) ri.sparse_off = true; else ri.team_off = true;
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
+        }
+        done = true;
+        // a clean single-kernel conversion: the same scene at the same R can be submitted asynchronously from now on
+        ri.async_ok = !err && !any_big;
+        if (err) {
+            // The bounded look-back spin gave up (never observed; would need a dispatcher that starves earlier
+            // workgroups).  Degrade to the multi-pass pipeline, which has no inter-workgroup dependency.
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
+            ri.multipass = true;
+            done = false;
+        } else
+        if (any_big) {
+            uint32_t meta[4] = { 0, 0, 0, 0 };
+            HIPCHK(c, hipMemcpyAsync(meta, c->d_bigmeta, sizeof meta, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, sizeof meta, st));   // restore the "zero between conversions" invariant
+            const uint64_t total_now = c->h_total[0];
+            if (meta[0] > 256 && (uint64_t)meta[2] * 8 > total_now) {
+                // Scene dominated by mid-size / big triangles (e.g. a coarse mesh at high density): one workgroup per
+                // triangle chunk would be mostly empty.  The output-partitioned multi-pass pipeline packs them densely;
+                // remember the decision so that later conversions of this scene at this R go straight to it.
+                ri.multipass = true;
+                done = false;
+            } else {
+                // second stage: emit exactly the deferred triangles, one workgroup per 1024-fragment chunk
+                if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+                launch_emit_big(sc, R, c->d_biglist, meta[0], meta[1], limit, d_out, st);
+                if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
+            }
+        }
+    }
+    if (!done) {
+        m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
+        if (s != M2S_OK) return s;
+        ri.mp_ready = true;
+        c->last_pipeline = M2S_PIPELINE_MULTIPASS;
+    }
+    // unlimited policy, context-owned buffer: the prediction was too low — make room for the exact count and repeat
+    // (never seen with the 2 % slack; the fragment count scales with R^2 up to clipping at the viewport edge)
+    if (!d_user && !cap && c->h_total[0] > limit && limit < 0xFFFFFFFFull && round == 0) {
+        const m2s_status s = ensure_records(c, c->h_total[0]);
+        if (s != M2S_OK) return s;
+        limit = std::min<uint64_t>(c->records_cap, 0xFFFFFFFFull);
+        d_out = (float4*)c->d_records;
+        counted = false;
+        continue;
+    }
+    break;
+    }
+    const uint64_t total = c->h_total[0];
+    if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
+    c->frag_per_R2 = (double)total / ((double)R * (double)R);
+    c->last_total = total;
+    c->last_stored = std::min(total, limit);
+    c->last_records = d_out;
+    if (!d_user) { if (c->buf_R[0] != R) { c->buf_R[0] = R; ++c->buf_gen[0]; } }
+    if (out_total) *out_total = total;
+    return M2S_OK;
+}
+}  // namespace m2s_host
+
+extern "C" {
+
+m2s_status m2s_convert(m2s_ctx* c, uint32_t R, uint64_t* out_total) {
+    if (!c) return M2S_ERR_INVALID;
+    return run_pass(c, R, nullptr, 0, c->stream, out_total);
+}
+
+m2s_status m2s_convert_into(m2s_ctx* c, uint32_t R, void* d_records, uint64_t capacity_records, void* hip_stream,
+                            uint64_t* out_total) {
+    if (!c) return M2S_ERR_INVALID;
+    if (!d_records && capacity_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL");
+    if (!d_records) return fail(c, M2S_ERR_INVALID, "d_records is NULL (use m2s_convert for the context-owned buffer)");
+    return run_pass(c, R, d_records, capacity_records, (hipStream_t)hip_stream, out_total);
+}
+
+}  // extern "C"

@@ -1,4 +1,4 @@
-// m2s_ply.h — streaming .ply writer shared by m2s_write_ply (m2s_ply.cpp) and m2s_export_ply (m2s_api.cpp).
+// m2s_ply.h — streaming .ply writer shared by m2s_write_ply (m2s_ply.cpp) and m2s_export_ply (m2s_records.cpp).
 #pragma once
 #include "../../include/m2s.h"
 
