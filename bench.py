@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the C2 / mid-size / C4 lines (and the C4 strong-scaling run at N > 1)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="N > 1: seconds after which the multi-GPU extras are abandoned and the headline line is printed")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="tests: every rank on device 0 (several processes share one GPU; needs an RCCL stand-in that allows it: M2S_RCCL_PATH)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()
@@ -545,6 +547,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         a.gpus = world
+    if a.one_device:
+        local_rank = 0
 
     import torch  # first, so that the HIP runtime torch ships is the one the process uses
     import torch.distributed as dist
@@ -564,8 +568,7 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own account of a failure goes to stderr
         # ONE user of RCCL per process: the C-ABI communicator (m2s_dist_*), which carries the data path.  torch.distributed only
         # bootstraps (the 128-byte id), barriers and reduces the timings, on CPU tensors over gloo — it does not bring up a second
-        # set of RCCL communicators next to ours (M2S_BENCH_PG=nccl restores that; the torch.distributed FALLBACK exchange below
-        # switches to it, because it moves device memory through torch).
+        # set of RCCL communicators next to ours (M2S_BENCH_PG=nccl restores that).
         backend = os.environ.get("M2S_BENCH_PG", "gloo")
         t_pg = time.perf_counter()
         with stdout_to_stderr():
@@ -586,8 +589,8 @@ def main():
         idt = torch.zeros(129, dtype=torch.uint8, device=CTL)
         if rank == 0:
             try:
-                if os.environ.get("M2S_BENCH_FORCE_TORCH_EXCHANGE"):      # (test hook for the fallback below)
-                    raise RuntimeError("forced by M2S_BENCH_FORCE_TORCH_EXCHANGE")
+                if os.environ.get("M2S_BENCH_FAIL_COMM"):      # (test hook: the exit path below)
+                    raise RuntimeError("forced by M2S_BENCH_FAIL_COMM")
                 ident0 = m2d.RcclExchange.unique_id()
                 idt[1:].copy_(torch.frombuffer(bytearray(ident0), dtype=torch.uint8))
                 idt[0] = 1
@@ -613,16 +616,20 @@ def main():
                 exchange, ok = None, 0
         okt = torch.tensor([ok], dtype=torch.int32, device=CTL)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        if int(okt.item()) == 0:           # on ANY rank: every rank switches, or the collectives would not match
+        if int(okt.item()) == 0:
+            # NO fallback: the exchange under test is the product's (m2s_dist_* behind the C ABI: RCCL).  A run whose ranks cannot
+            # create that communicator must not report a number measured on something else: every rank leaves, rank 0 says why.
+            errs = [None] * world
+            dist.all_gather_object(errs, dist_errors)
             if exchange is not None:
                 exchange.close()
-            if CTL != "cuda":              # the fallback moves device memory through torch: it needs the nccl process group
-                dist.barrier()
-                dist.destroy_process_group()
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-                CTL = "cuda"
-                phases["control_plane"] = "nccl (re-initialised for the torch.distributed fallback exchange)"
-            exchange = m2d.TorchExchange(rank, world)
+            if rank == 0:
+                print(json.dumps({"error": "the C-ABI communicator (m2s_dist_create) could not be created on every rank; no measurement was taken",
+                                  "n_gpus": world, "exchange_transport": None, "errors": [e for per in errs for e in (per or [])],
+                                  "multi_gpu_bringup": phases}), file=sys.stderr, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
         if exchange is not None:           # the first exchange of all: 8 bytes per rank, timed on its own
             t_x = time.perf_counter()
             try:
@@ -740,13 +747,14 @@ def main():
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "exchange_transport": exchange.transport if multi else "none (single GPU: no exchange)",
             "config": {"workload": (f"I-4 64 meshes x cube-sphere n=18 ({tri_per_mesh} triangles), 64 materials with 3 procedural "
                                     f"{tex}^2 RGBA8 maps each, R={R}") if n == "grid" else
                                    (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
                                     f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
                        "rccl_ranks": (dist.get_world_size() if multi else 1),
-                       "exchange": ("per step: 8-byte counter all-gather, two in flight; transport: " + exchange.kind) if multi else "none (single GPU)",
+                       "exchange": ("per step: 8-byte counter all-gather, two in flight; transport: " + exchange.transport) if multi else "none (single GPU)",
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
                        "submission": "one blocking call per step" if a.sync_steps else
                                      "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
@@ -780,7 +788,7 @@ def main():
             except Exception:
                 pass
     if rank == 0 and multi:
-        res["multi_gpu_bringup"] = {**phases, "exchange": getattr(exchange, "kind", None), "errors": dist_errors,
+        res["multi_gpu_bringup"] = {**phases, "exchange": getattr(exchange, "transport", None), "errors": dist_errors,
                                     "what": "rank 0's timings of the bring-up steps; errors: every m2s_dist_* failure met so far (text of m2s_dist_last_error)"}
     # The multi-GPU extras below contain collectives that have never run on more than one GPU by the builder.  Should one of
     # them hang, every rank leaves after --extras-timeout seconds and rank 0 still prints the (complete) headline line.
@@ -883,7 +891,7 @@ def main():
                         # the same sort WITHOUT merging on one GPU: sample sort across the ranks behind the C ABI (one exact-size record
                         # exchange; every rank ends with its slice of the global order).  Checked against the merged buffer: same
                         # multiset (checksum), sorted inside every slice, slices ordered across ranks.
-                        if hasattr(exchange, "sort_by_depth"):
+                        if True:
                             try:
                                 srig.drain_counts()
                                 torch.cuda.synchronize(); dist.barrier()
@@ -925,6 +933,25 @@ def main():
                     res["cold_path"] = cold_path(torch, local_rank, one, R, sync_ms)
                 except Exception as e:  # noqa: BLE001
                     res["cold_path"] = {"error": str(e)}
+            # The fractions a reader should not have to dig for: every one is algorithmic bytes of ONE conversion over a
+            # WALL-CLOCK time of that conversion as the caller sees it / 8 TB/s —
+            #   frac            the dominant kernel alone, HIP events inside the timed region            (the kernel's roofline)
+            #   frac_step       the driver-timed step: ms_per_step of this line                          (steady state, same scene and R)
+            #   frac_first_call a NEW scene: first m2s_convert after m2s_upload_scene, blocking          (what the reference does on load)
+            #   frac_new_R      the same scene at a density it has never been converted at, blocking     (a move of the density slider)
+            #   frac_cold_inputs  inputs not resident in the 256 MiB Infinity Cache (kernel time, three rotating scene copies)
+            rf, cp = res["roofline"], res.get("cold_path") or {}
+            b = rf["algorithmic_bytes"]
+            rf["frac_step"] = b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if "first_call_ms" in cp:
+                rf["frac_first_call"] = b / (cp["first_call_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                # (the other densities move (R'/R)^2 of the records: scale the bytes of the record part accordingly)
+                rs = cp["new_R_ms"]["densities"]
+                scale = float(np.mean([(r / R) ** 2 for r in rs])) if rs else 1.0
+                rf["frac_new_R"] = (96.0 * stored_local * scale + 144.0 * T_local) / (cp["new_R_ms"]["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rf["frac_cold_inputs"] = cp["cold_inputs"].get("frac_of_hbm_peak")
+            if rf.get("traffic") is not None:
+                res["traffic_note"] = "roofline.traffic is a COMMITTED constant of the same command (see roofline.traffic_source), not a measurement of this run"
             if not a.no_extra_workloads and a.workload == "c3":
                 res["extra_workloads"] = {}
                 for w in ("c2", "mid", "c4") + (() if a.no_c5 else ("c5",)):

@@ -111,6 +111,16 @@ m2s_status m2s_prepare(m2s_ctx* ctx, uint32_t flags);
  * [2] textures (staging, mip and combo kernels, final sync), [3] device / pinned allocations. */
 m2s_status m2s_last_upload_ms(const m2s_ctx* ctx, float out_ms[4]);
 
+/* The resolutionTarget the NEXT m2s_upload_scene prepares the scene for (0, the default: the R this context last converted at,
+ * else 1024).  The reference converts right after SceneManager::loadModel, at RenderContext::resolutionTarget
+ * (guiRendererConcreteMediator.cpp:11-29, RenderContext.hpp:64) — and never twice at the same (scene, R), so its FIRST
+ * conversion is the one a user waits for.  The upload therefore ends with one exact fragment count at this R behind its own
+ * kernels (in [0] of m2s_last_upload_ms; m2s_last_warm_ms alone) and leaves behind what that first conversion needs: the
+ * pipeline decision, the XCD band table, the record pool.  A conversion at any other R needs none of it (fragments scale with
+ * R^2; its first launch runs without bands). */
+m2s_status m2s_set_resolution_hint(m2s_ctx* ctx, uint32_t R);
+float m2s_last_warm_ms(const m2s_ctx* ctx);
+
 /* ---- the pass == ConversionPass::execute ------------------------------------------------------- */
 /* u_maxGaussians policy (converterFS.glsl:46-51): -1 (default) = the reference formula
  * min(R*R*6*max(1,meshes), 7'000'000) in 32-bit unsigned arithmetic (ConversionPass.cpp:21-24);
@@ -196,6 +206,9 @@ m2s_status m2s_dist_local_id(int world, uint8_t out_id[M2S_DIST_ID_BYTES]);
 void m2s_dist_destroy(m2s_dist* d);
 int m2s_dist_rank(const m2s_dist* d);
 int m2s_dist_world(const m2s_dist* d);
+/* What moves the bytes of this communicator: "in-process", "rccl", or "rccl:<path>" when the environment variable M2S_RCCL_PATH
+ * named the library (it takes precedence over an RCCL already in the process and over the system's). */
+const char* m2s_dist_transport(const m2s_dist* d);
 /* d == NULL: message of the last failed m2s_dist_unique_id / _create / _shard_ranges on this thread. */
 const char* m2s_dist_last_error(const m2s_dist* d);
 /* Host only, deterministic (every rank computes the same plan): cuts the flattened triangle list into `world` contiguous

@@ -90,6 +90,10 @@ class Converter:
     def set_triangle_range(self, first: int, count: Optional[int]):
         self._check(self._L.m2s_set_triangle_range(self._h, int(first), (1 << 64) - 1 if count is None else int(count)))
 
+    def set_resolution_hint(self, R: int):
+        """The resolutionTarget the next upload_scene prepares for (0: the last R converted at, else 1024)."""
+        self._check(self._L.m2s_set_resolution_hint(self._h, int(R)))
+
     def upload_scene(self, scene: Scene):
         arr, keep = marshal_scene(scene)
         self._check(self._L.m2s_upload_scene(self._h, arr, scene.n_meshes))
@@ -99,7 +103,8 @@ class Converter:
         """Wall-clock breakdown of the last upload_scene (ms)."""
         ms = (C.c_float * 4)()
         self._check(self._L.m2s_last_upload_ms(self._h, ms))
-        return {"total": float(ms[0]), "geometry": float(ms[1]), "textures": float(ms[2]), "alloc": float(ms[3])}
+        return {"total": float(ms[0]), "geometry": float(ms[1]), "textures": float(ms[2]), "alloc": float(ms[3]),
+                "warm": float(self._L.m2s_last_warm_ms(self._h))}
 
     # -- the pass ---------------------------------------------------------------------------------
     def set_max_gaussians(self, cap: int):
@@ -332,6 +337,7 @@ class ConversionPass(IRenderPass):
         if context.converter is None:
             context.converter = Converter(context.device)
         if context._uploaded_scene is not context.scene:
+            context.converter.set_resolution_hint(context.resolutionTarget)   # the upload prepares for the conversion below
             context.converter.upload_scene(context.scene)
             context._uploaded_scene = context.scene
         context.numberOfGaussians = context.converter.convert(context.resolutionTarget)

@@ -68,7 +68,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
             HIPCHK(c, chain_behind_newest(st));
             unsigned long long* res = &c->h_total[2 + 2 * k];
             res[0] = 0; res[1] = 0;
-            { const m2s_status ms_ = enqueue_multipass(c, R, (float4*)d_out, limit, false, false, res, st); if (ms_ != M2S_OK) return ms_; }
+            { const m2s_status ms_ = enqueue_multipass(c, R, (float4*)d_out, limit, false, res, st); if (ms_ != M2S_OK) return ms_; }
             HIPCHK(c, hipEventRecord(sl.done, st));
             c->last_pipeline = M2S_PIPELINE_MULTIPASS;
             c->last_submit_stream = st;

@@ -35,6 +35,8 @@ void free_scene(m2s_ctx* c) {
     c->rinfo.clear();
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
+    c->warm_R = 0;
+    c->sparse_off_R = c->team_off_R = UINT32_MAX;
     c->scene = SceneDev{};
     c->has_scene = false;
 }
@@ -50,6 +52,8 @@ m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     m2s_ctx::RInfo ri;
     ri.gen = c->rinfo_gen;
     ri.band_slot = (int)c->rinfo.size();
+    ri.sparse_off = R >= c->sparse_off_R;
+    ri.team_off = R >= c->team_off_R;
     return c->rinfo.emplace(R, ri).first->second;
 }
 
@@ -137,7 +141,10 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     for (auto& ev : c->stage_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     unsigned done_flags = hipEventDisableTiming;   // (completion only: its time is never asked for)
-    if (const char* v = std::getenv("M2S_DONE_EVENT_FLAGS")) done_flags = (unsigned)strtoul(v, nullptr, 0);   // debug: A/B of event kinds
+    if (const char* v = debug_env("M2S_DONE_EVENT_FLAGS")) {   // debug: A/B of event kinds; anything but a combination of the known bits is ignored
+        const unsigned f = (unsigned)strtoul(v, nullptr, 0);
+        if ((f & ~(hipEventBlockingSync | hipEventDisableTiming | hipEventReleaseToDevice | hipEventReleaseToSystem)) == 0u) done_flags = f;
+    }
     for (auto& sl : c->slot)
         if ((e = hipEventCreateWithFlags(&sl.done, done_flags)) != hipSuccess || (e = hipEventCreate(&sl.t0)) != hipSuccess ||
             (e = hipEventCreate(&sl.t1)) != hipSuccess)

@@ -63,9 +63,14 @@ struct m2s_ctx {
         int band_slot = 0;
         uint32_t gen = 0;          // generation of the table this entry belongs to (the table starts over when it is full)
     };
+    // smallest R at which a workgroup of k_sparse / k_fused2 did not fit its LDS stream: a property of the SCENE (fragments grow
+    // with R), so a new R above it starts with the next form at once instead of re-discovering the overflow
+    uint32_t sparse_off_R = UINT32_MAX, team_off_R = UINT32_MAX;
     uint32_t rinfo_gen = 0;
     std::map<uint32_t, RInfo> rinfo;
-    double frag_per_R2 = -1.0;              // fragments / R^2 of this scene, learned from its first conversion (any R)
+    double frag_per_R2 = -1.0;              // fragments / R^2 of this scene: from the exact count m2s_upload_scene takes (warm_scene), refreshed by every conversion
+    uint32_t hint_R = 0;                    // m2s_set_resolution_hint: the R the next upload prepares for (0: the last R converted at, else 1024)
+    uint32_t warm_R = 0;                    // the R the resident scene was prepared for
     unsigned long long* d_bands = nullptr;  // kBandSlots x kBandTableWords: XCD band tables (device)
     unsigned long long* h_bands = nullptr;  // kBandSlots x 9 (pinned): the cuts of each table, written by k_pick_bands itself
     unsigned long long* d_wg_base = nullptr;   // where every workgroup's output started in the newest launch without bands
@@ -132,7 +137,7 @@ struct m2s_ctx {
     void* d_stage[2] = { nullptr, nullptr };
     hipEvent_t stage_ev[2] = { nullptr, nullptr };
     void* scene_arena = nullptr;             // one allocation for mesh table, textures, combo textures and work buffers
-    float last_upload_ms[4] = { 0, 0, 0, 0 }; // [0] total, [1] geometry, [2] textures + mips + combo, [3] allocations
+    float last_upload_ms[5] = { 0, 0, 0, 0, 0 }; // [0] total, [1] geometry, [2] textures + mips + combo, [3] allocations, [4] warm_scene
     void* d_rows = nullptr;                  // m2s_export_ply: .ply rows encoded on the device (formats 1 and 2)
     uint64_t rows_cap = 0;                   // bytes
     void* d_loaded = nullptr;                // m2s_upload_records (a loaded .ply)
@@ -180,7 +185,8 @@ uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit
 m2s::BatchTable batches_for(const m2s_ctx* c);
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
 bool multipass_v1();
-m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, bool prof,
+m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident
+m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                              unsigned long long* h_res, hipStream_t st);
 m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total,
                     bool from_submit = false);

@@ -414,7 +414,7 @@ __device__ __forceinline__ uint32_t ld_texel(GlobalBytes base, uint32_t texel) {
 
 
 // Per-triangle constants of the fragment stage: computed once per triangle (fused kernel: in the
-// triangle phase, kept in LDS; multi-pass emit: recomputed per fragment).  64 bytes = four float4.
+// triangle phase, kept in LDS; multi-pass emit: read from the TriSetup record k_count_scan wrote).  80 bytes = five float4.
 struct TriShade {
     int a1, b1, a2, b2;      // edge functions opposite vertex 1 / 2 ...
     long long e1, e2;        // ... and their exact values at the bbox origin pixel (x0,y0)

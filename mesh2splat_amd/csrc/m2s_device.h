@@ -7,6 +7,15 @@
 
 namespace m2s {
 
+// Debug / A-B switches of the library (M2S_NO_BANDS, M2S_BAND_COST, M2S_EMIT2_RUN, ...) are environment variables that are only
+// looked at when M2S_DEBUG is set in the environment (decided once per process): a stray variable cannot change what a
+// production process does, and the conversion path of a production process reads no environment at all.
+inline const char* debug_env(const char* name) {
+    static const bool enabled = std::getenv("M2S_DEBUG") != nullptr;
+    return enabled ? std::getenv(name) : nullptr;
+}
+inline bool debug_on(const char* name) { const char* v = debug_env(name); return v && *v && *v != '0'; }
+
 // ---- launch geometry ----------------------------------------------------------------------
 constexpr int kBlock = 256;              // 4 wave64 per workgroup
 constexpr int kTriPerBlock = 1024;       // triangles per workgroup in the count / offsets kernels
@@ -85,6 +94,8 @@ void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m,
                         hipStream_t st);
 void launch_count(const SceneDev& sc, uint32_t R, uint32_t* cnt, uint32_t* partials, hipStream_t st);
 void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long long* total, hipStream_t st);
+// where the output of every run of `unit` (256 / 512) triangles starts, from launch_count's counts and the scanned partials
+void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, unsigned long long* wg_base, hipStream_t st);
 void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
                     uint32_t n_start, hipStream_t st);
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,

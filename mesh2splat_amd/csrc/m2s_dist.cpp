@@ -65,6 +65,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
+    std::string path;       // M2S_RCCL_PATH if that is what was loaded (m2s_dist_transport reports it)
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -72,10 +73,16 @@ thread_local std::string g_dist_error;
 
 void load_rccl() {
     Rccl& r = g_rccl;
-    // an RCCL that is already in the process (PyTorch's) first, then the system one
+    // an explicitly named library first (M2S_RCCL_PATH: a site's own build — or the test stand-in of tests/stub_rccl, which lets
+    // several PROCESSES share one GPU; loaded RTLD_LOCAL so that its nccl* symbols never interpose on a real RCCL in the same
+    // process), then an RCCL that is already in the process (PyTorch's), then the system one
+    if (const char* e = std::getenv("M2S_RCCL_PATH")) {
+        r.handle = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) { r.error = std::string("M2S_RCCL_PATH: ") + (dlerror() ? dlerror() : "could not be loaded"); return; }
+        r.path = e;
+    }
     const char* names[] = { "librccl.so.1", "librccl.so" };
     for (const char* n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    if (const char* e = std::getenv("M2S_RCCL_PATH")) if (!r.handle) r.handle = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
     const char* paths[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
     for (const char* n : paths) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!r.handle) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
@@ -429,6 +436,15 @@ void m2s_dist_destroy(m2s_dist* d) {
 }
 
 int m2s_dist_rank(const m2s_dist* d) { return d ? d->rank : -1; }
+// what moves the bytes of this communicator: "in-process" (ranks are threads: m2s_dist_local_id), "rccl" (the process's or the
+// system's librccl) or "rccl:<path>" (the library M2S_RCCL_PATH named)
+const char* m2s_dist_transport(const m2s_dist* d) {
+    static thread_local std::string s;
+    if (!d) return "";
+    if (d->local) return "in-process";
+    s = g_rccl.path.empty() ? "rccl" : "rccl:" + g_rccl.path;
+    return s.c_str();
+}
 int m2s_dist_world(const m2s_dist* d) { return d ? d->world : 0; }
 
 // Starts the exchange of this rank's counter for one conversion; returns at once (the value is queued for the exchange

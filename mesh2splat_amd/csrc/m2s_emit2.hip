@@ -429,7 +429,7 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
     const uint32_t per_wg = kSlice * (kBlock / 64);
     uint32_t n_blocks = (uint32_t)((limit + per_wg - 1) / per_wg);
     uint32_t run = 16;                          // workgroups per XCD turn (profiles/r03/ab_emit2_xcd_turns.log)
-    if (const char* v = std::getenv("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
+    if (const char* v = debug_env("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
     n_blocks = (n_blocks + 8u * run - 1u) / (8u * run) * (8u * run);   // whole rounds of turns; surplus workgroups leave at once
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
                        (const float4*)setup, out, run);

@@ -304,8 +304,11 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         }
         tk_cnt = F2_NOW() - tw0;
     }
-    if (alive && (unsigned long long)stream0 + total_c > kEntries) alive = false;   // does not fit the LDS stream
     if (!alive && lane == 0) lds_store(&S.error, 1u);
+    if (alive && (unsigned long long)stream0 + total_c > kEntries) {   // does not fit the LDS stream
+        alive = false;
+        if (lane == 0) lds_store(&S.error, 2u);
+    }
 
     float4* stage = S.stage[wave];
     unsigned long long base = 0;
@@ -504,7 +507,8 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             if (bands.out) bands.out[lb] = base;
         }
     }
-    if (lds_load(&S.error) && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // status[1] != 0 is what the host acts on; 2 = "a workgroup's entries do not fit", 1 = a bounded wait gave up
+    { const uint32_t e = lds_load(&S.error); if (e && lane == 0) __hip_atomic_store(&status[1], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     F2_T(0, F2_NOW() - tk0); F2_T(1, tk_cnt); F2_T(2, tk_ent); F2_T(3, tk_base); F2_T(4, n_strips); F2_T(5, (unsigned long long)stream_total);
     F2_T(6, tk_real0); F2_T(7, __builtin_amdgcn_s_memrealtime()); F2_T(8, (unsigned long long)(blockIdx.x & 7u));
 }

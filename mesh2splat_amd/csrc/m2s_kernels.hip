@@ -212,6 +212,38 @@ void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long
 }
 
 // ============================================================================================
+// K_unit_bases: where the output of every run of `unit` (256 or 512) consecutive triangles starts, from the exact counts and
+// the scanned partial sums — what a launch of the single-pass kernels without bands records as a by-product
+// (BandInfo::out), here from the count m2s_upload_scene takes, so that the FIRST conversion of a scene already runs in bands.
+// ============================================================================================
+__global__ void __launch_bounds__(kBlock) k_unit_bases(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ partials,
+                                                       uint32_t n_tri, uint32_t unit, unsigned long long* __restrict__ wg_base) {
+    __shared__ uint32_t red[kTriPerBlock / kBlock][kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blockBase = blockIdx.x * kTriPerBlock;
+#pragma unroll
+    for (int it = 0; it < kTriPerBlock / kBlock; ++it) {
+        const uint32_t t = blockBase + it * kBlock + threadIdx.x;
+        const uint32_t s = wave_sum(t < n_tri ? cnt[t] : 0u);
+        if (lane == 0) red[it][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = partials[blockIdx.x];
+        const uint32_t per = unit / kBlock;                        // 256-triangle groups per unit (1 or 2)
+        for (int it = 0; it < kTriPerBlock / kBlock; ++it) {
+            if (it % per == 0 && blockBase + it * kBlock < n_tri) wg_base[(blockBase + it * kBlock) / unit] = run;
+            run += red[it][0] + red[it][1] + red[it][2] + red[it][3];
+        }
+    }
+}
+
+void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, unsigned long long* wg_base, hipStream_t st) {
+    if (!n_tri) return;
+    hipLaunchKernelGGL(k_unit_bases, dim3(n_count_blocks(n_tri)), dim3(kBlock), 0, st, cnt, partials, n_tri, unit, wg_base);
+}
+
+// ============================================================================================
 // K_offsets: off[t] = exclusive prefix of cnt; start[m] = triangle that owns output index m*kEmitF
 // ============================================================================================
 __global__ void __launch_bounds__(kBlock) k_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ partials,

@@ -22,7 +22,6 @@ namespace {
 // fragments per triangle (a workgroup's stream overflows from ~2.5); with 1 M triangles — 2.5 generations of its 512-triangle
 // workgroups — k_fused2 is ahead down to 0.68 at least.
 static double sparse_frags_per_triangle(uint32_t n_tri) { return n_tri >= 2000000u ? 1.75 : 0.5; }
-static bool env_on(const char* name) { const char* v = std::getenv(name); return v && *v && *v != '0'; }   // (debug switches)
 // XCD bands for this launch of k_fused2 (unit 256) or k_sparse (unit 512 triangles per workgroup): the table an earlier launch
 // of the same kernel at this R left behind — or, if there is none, ask this launch to record where every workgroup's output
 // starts, from which the table is cut right behind it (second lane: never asked to — two lanes would race on d_wg_base)
@@ -47,7 +46,7 @@ BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bo
     BandInfo b{};
     if (writes) *writes = false;
     const uint32_t n_wg = band_workgroups(c, unit);
-    if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || env_on("M2S_NO_BANDS")) return b;
+    if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || debug_on("M2S_NO_BANDS")) return b;
     if (ri.bands_ready && ri.bands_unit == unit && ri.band_width) {
         b.table = c->d_bands + (size_t)ri.band_slot * kBandTableWords;
         b.max_width = ri.band_width;
@@ -64,7 +63,7 @@ void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const
     // 130 2.90, 145 2.93, 160 2.99, 85 2.96).  (Cutting by MEASURED workgroup lifetimes instead was no better there and much worse
     // on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched.)
     uint32_t cost_tri = unit == 256u ? 214u : 115u, cost_frag = 140;
-    if (const char* v = std::getenv("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
+    if (const char* v = debug_env("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
     launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg), cost_tri, cost_frag,
                       c->d_bands + (size_t)ri.band_slot * kBandTableWords, c->h_bands + (size_t)ri.band_slot * 9, st);
 }
@@ -96,25 +95,47 @@ uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
 }
 }  // namespace m2s_host
 
-// exact fragment count of the scene at R (k_count + scan + read-back): the one host round trip a NEW SCENE pays
-static m2s_status count_now(m2s_ctx* c, uint32_t R, hipStream_t st) {
+// AUTO's decision for this scene at R from its (exact or predicted) fragment count.
+// The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
+// sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
+// faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
+// 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).
+static void decide(const m2s_ctx* c, m2s_ctx::RInfo& ri, double frags) {
+    ri.decided = true;
+    ri.multipass = frags >= 11.0 * (double)c->scene.n_tri;
+    // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
+    // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
+    ri.sparse = !ri.multipass && frags < sparse_frags_per_triangle(c->scene.n_tri) * (double)c->scene.n_tri && !debug_on("M2S_NO_SPARSE");
+}
+
+static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit);
+
+namespace m2s_host {
+// Everything a FIRST conversion of a scene used to find out inside its own call — round 3: an exact count, a host round trip,
+// the record pool's hipMalloc, a launch without bands: 0.45 ms on config 3 against 0.13 ms for a repeated conversion — is
+// found out here, behind the upload's own kernels, at the resolution the caller is about to convert at (m2s_set_resolution_hint;
+// default: the last R this context converted at, else 1024).  The reference converts right after SceneManager::loadModel at the
+// RenderContext's current resolutionTarget (guiRendererConcreteMediator.cpp:11-29), never twice at one (scene, R): its first
+// conversion is the one that counts.  Left behind: the scene's fragments / R^2 (AUTO's decision and the pool size at ANY R
+// without touching the device), and for R itself the decision, the XCD band table cut from the exact counts (k_unit_bases +
+// k_pick_bands), the batch table of one-generation scenes, the multi-pass work buffers, the record pool.
+m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     const SceneDev& sc = c->scene;
-    const bool prof = c->profiling;
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (!sc.n_tri || R == 0 || R > 4096) return M2S_OK;
+    hipStream_t st = c->stream;
     launch_count(sc, R, c->d_cnt, c->d_partials, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
     launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    if (prof)
-        for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1]));
-    c->frag_per_R2 = (double)c->h_total[0] / ((double)R * (double)R);
+    const uint64_t total = c->h_total[0];
+    c->frag_per_R2 = (double)total / ((double)R * (double)R);
+    c->warm_R = R;
     // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
     // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
     // cube-sphere face).  Work = 214 per triangle + 140 per fragment (cycles of the triangle phase per 64 triangles and of a strip
     // per 64 fragments, tools/team_timing.py); fragments scale with R^2 everywhere alike, so the table serves every density.
-    if (batch_table_capacity(sc.n_tri) && !c->n_batch_tab && !std::getenv("M2S_NO_BATCH_TABLE")) {
+    if (batch_table_capacity(sc.n_tri) && !c->n_batch_tab && !debug_on("M2S_NO_BATCH_TABLE")) {
         try {
             std::vector<uint32_t> cnt(sc.n_tri), first;
             HIPCHK(c, hipMemcpy(cnt.data(), c->d_cnt, (size_t)sc.n_tri * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -143,14 +164,37 @@ static m2s_status count_now(m2s_ctx* c, uint32_t R, hipStream_t st) {
             }
         } catch (...) { /* no table: uniform batches */ }
     }
+    m2s_ctx::RInfo& ri = rinfo_for(c, R);
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total);
+    const uint64_t cap = resolve_cap(c, R);
+    const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
+    if (single && (use_sparse(c, ri) || use_team(c, ri)) && !debug_on("M2S_NO_WARM_BANDS")) {
+        // the band table of the first launch at R, from the exact counts (the same table a launch without bands leaves behind)
+        const uint32_t unit = use_sparse(c, ri) ? kSparseTrianglesPerWorkgroup : 256u;
+        bool writes = false;
+        (void)bands_for(c, ri, unit, true, &writes);
+        if (writes) {
+            launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, c->d_wg_base, st);
+            pick_bands(c, ri, unit, c->d_total, st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));
+            ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit);
+        }
+    }
+    // allocations a first conversion would otherwise make inside its own call; best effort (the conversion reports a failure)
+    const uint64_t want = cap ? cap : std::max<uint64_t>(total, 1);
+    if (!single || total >= 8ull * sc.n_tri) (void)ensure_multipass_buffers(c, std::min<uint64_t>(cap ? cap : want, 0xFFFFFFFFull));
+    (void)ensure_records(c, want);
+    c->err.clear();
     return M2S_OK;
 }
+}  // namespace m2s_host
 
 // Multi-pass pipeline: handles every triangle size, output-balanced.  Second generation (m2s_emit2.hip): k_count_scan
 // (count + offsets + per-triangle setup records, one kernel) -> k_emit2 (wave-granular).  M2S_MULTIPASS_V1=1 selects the
 // first generation (count -> scan -> offsets -> emit, m2s_kernels.hip) for A/B measurements.
 namespace m2s_host {
-bool multipass_v1() { static const bool v1 = std::getenv("M2S_MULTIPASS_V1") != nullptr; return v1; }
+bool multipass_v1() { static const bool v1 = debug_env("M2S_MULTIPASS_V1") != nullptr; return v1; }
 }
 
 static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
@@ -168,17 +212,15 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
 
 namespace m2s_host {
 // enqueues the pipeline's kernels and the read-back of the counter into *h_res (pinned); no synchronisation
-m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, bool prof,
+m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                                     unsigned long long* h_res, hipStream_t st) {
     const SceneDev& sc = c->scene;
     if (multipass_v1()) {
-        if (!counted) {
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-            launch_count(sc, R, c->d_cnt, c->d_partials, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-            launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-        }
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count(sc, R, c->d_cnt, c->d_partials, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+        launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
         const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
         launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
         if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -200,15 +242,15 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
 }
 }
 
-static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool counted, hipStream_t st) {
+static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, hipStream_t st) {
     const bool prof = c->profiling;
     { const m2s_status s = ensure_multipass_buffers(c, limit); if (s != M2S_OK) return s; }
     c->h_total[0] = 0; c->h_total[1] = 0;
-    { const m2s_status s = enqueue_multipass(c, R, d_out, limit, counted, prof, c->h_total, st); if (s != M2S_OK) return s; }
+    { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
     HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
     if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
     if (prof) {
-        if (multipass_v1()) { for (int k = counted ? 2 : 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
+        if (multipass_v1()) { for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
         else {
             HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_COUNT], c->ev[0], c->ev[1]));
             HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
@@ -248,29 +290,12 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     m2s_ctx::RInfo& ri = rinfo_for(c, R);
 
     // ---- AUTO: which pipeline for this scene at this R? ---------------------------------------------
-    // The single-pass kernel wins while triangles are small (it does the per-triangle work once and needs no second
-    // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
-    // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
-    // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).
-    // The fragment count of a scene is proportional to R^2 (window coordinates scale with R), so ONE exact count — taken
-    // at the scene's first conversion, 0.02-0.06 ms plus a host round trip — decides for every later R without touching
-    // the device: the threshold is not sharp, and both pipelines produce the same bytes anyway.
-    bool counted = false;  // k_count + k_scan already ran in this call, at this R
-    const bool need_estimate = (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) || (!d_user && !cap);
-    if (need_estimate && c->frag_per_R2 < 0.0) {
-        const m2s_status s = count_now(c, R, st);
-        if (s != M2S_OK) return s;
-        counted = true;
-    }
-    const double predicted = c->frag_per_R2 >= 0.0 ? c->frag_per_R2 * (double)R * (double)R : 0.0;
-    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) {
-        ri.decided = true;
-        const double frags = counted ? (double)c->h_total[0] : predicted;
-        ri.multipass = frags >= 11.0 * (double)sc.n_tri;
-        // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
-        // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
-        ri.sparse = !ri.multipass && frags < sparse_frags_per_triangle(sc.n_tri) * (double)sc.n_tri && !std::getenv("M2S_NO_SPARSE");
-    }
+    // The fragment count of a scene is proportional to R^2 (window coordinates scale with R), so the ONE exact count
+    // m2s_upload_scene took (warm_scene) decides for every R without touching the device: the threshold is not sharp, and
+    // all pipelines produce the same bytes anyway.
+    if (c->frag_per_R2 < 0.0) return fail(c, M2S_ERR_STATE, "the scene has not been analysed (m2s_upload_scene failed?)");
+    const double predicted = c->frag_per_R2 * (double)R * (double)R;
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, predicted);
 
     // ---- where do the records go, and how many may be stored? ------------------------------------
     uint64_t limit;
@@ -280,7 +305,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         d_out = (float4*)d_user;
     } else {
         // unlimited policy: room for the predicted count plus slack; a conversion that still overflows is repeated below
-        const uint64_t want = cap ? cap : (counted ? std::max<uint64_t>(c->h_total[0], 1) : (uint64_t)(predicted * 1.02) + 4096);
+        const uint64_t want = cap ? cap : (uint64_t)(predicted * 1.02) + 4096;
         const m2s_status s = ensure_records(c, want);
         if (s != M2S_OK) return s;
         limit = cap ? cap : c->records_cap;
@@ -292,7 +317,6 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
     if (c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass) {
-        counted = false;   // the fused kernel does its own counting; a count taken above only sized / decided
         // single-pass kernel; triangles too large for its in-workgroup budget are only counted.
         // No memset, no memcpy: the look-back chain is epoch-tagged and the kernel writes the fragment
         // counter and its two status words straight into pinned host memory.
@@ -322,13 +346,15 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
             if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit); }
-            if (err && std::getenv("M2S_DEBUG"))
+            if (err && debug_on("M2S_DEBUG"))
                 fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
             if (!(err && (team || sparse))) break;
             // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
             // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
             // launch listed, try again.
-            if (sparse) ri.sparse_off = true; else ri.team_off = true;
+            // (error value 2 = "entries do not fit": true of every larger R as well)
+            if (sparse) { ri.sparse_off = true; if ((err & 0xFu) == 2u) c->sparse_off_R = std::min(c->sparse_off_R, R); }
+            else { ri.team_off = true; if ((err & 0xFu) == 2u) c->team_off_R = std::min(c->team_off_R, R); }
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
         }
         done = true;
@@ -365,7 +391,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         }
     }
     if (!done) {
-        m2s_status s = run_multipass(c, R, d_out, limit, counted, st);
+        m2s_status s = run_multipass(c, R, d_out, limit, st);
         if (s != M2S_OK) return s;
         ri.mp_ready = true;
         c->last_pipeline = M2S_PIPELINE_MULTIPASS;
@@ -377,7 +403,6 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         if (s != M2S_OK) return s;
         limit = std::min<uint64_t>(c->records_cap, 0xFFFFFFFFull);
         d_out = (float4*)c->d_records;
-        counted = false;
         continue;
     }
     break;

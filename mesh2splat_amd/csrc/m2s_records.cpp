@@ -71,7 +71,7 @@ static m2s_status export_rows(m2s_ctx* c, const char* path, uint32_t format, flo
     m2s_status s = slice ? w.open_slice(path, total_rows, format, scale_multiplier, first_row, n_rows)
                          : w.open(path, total_rows, format, scale_multiplier);
     if (s != M2S_OK) { c->err = std::string("could not write ") + path; return s; }
-    const bool on_device = format != 0 && !std::getenv("M2S_HOST_ENCODE");
+    const bool on_device = format != 0 && !debug_on("M2S_HOST_ENCODE");
     const size_t unit = on_device ? w.row_bytes() : sizeof(m2s_gaussian);     // bytes per row on the bus
     const char* src = static_cast<const char*>(c->last_records);
     if (on_device && n_rows) {

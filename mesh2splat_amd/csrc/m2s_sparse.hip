@@ -175,6 +175,7 @@ __device__ __forceinline__ bool sp_get_base(SpLds& S, const unsigned long long* 
         } else {
             uint32_t spins = 0;
             while (sp_load(&S.base_state) != 2) {
+                if (sp_load(&S.error)) return false;      // (another wave gave up: the launch is discarded, nobody waits)
                 if (++spins > kSpWait) { if (lane == 0) sp_store(&S.error, 5u); return false; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -411,6 +412,9 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
             [[maybe_unused]] const unsigned long long tw0 = SP_NOW();
             uint32_t spins = 0;
             while (sp_load(&S.counted[r - 1]) == 0) {
+                // a wave that gave up (entries do not fit, a wait timed out) has abandoned the round it had claimed ahead:
+                // that round is never counted — do not wait for it (this loop used to spin its full 2^24 polls)
+                if (sp_load(&S.error)) { alive = false; break; }
                 if (++spins > kSpWait) { alive = false; if (lane == 0) sp_store(&S.error, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -420,9 +424,11 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         }
         if (lane == 0) {
             S.pre_w[r + 1] = pw + total_w; S.pre_c[r + 1] = pc + total_c;
-            // deferred triangles anywhere in the workgroup make record index != base + stream position for everything after
-            // them: the flag travels WITH the counts (a strip starts only after every round is counted), not with the later
-            // expansion — a strip of another round's entries must not see it "not yet set"
+            // deferred triangles make record index != base + stream position for everything AFTER them.  The flag is set before
+            // the release store of counted[r] below, so it is visible to every strip whose counted prefix includes this round;
+            // strips that start earlier (the strip loop runs ahead of the counting) hold only entries of earlier rounds, whose
+            // tskip is 0 either way.  It travels with the counts, not with the later expansion: a strip made of ANOTHER
+            // round's entries does not wait for this round's expansion
             if (anybig) __hip_atomic_fetch_or(&S.irregular, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         sp_store(&S.counted[r], 1u);
@@ -531,6 +537,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
                         break;
                     }
                 }
+                if (sp_load(&S.error)) { alive = false; break; }      // (rounds abandoned by a wave that gave up are never counted)
                 if (++spins > kSpWait) { alive = false; if (lane == 0) sp_store(&S.error, 4u); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -630,9 +637,13 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
             if (bands.out) bands.out[lb] = base;     // (k_pick_bands cuts the bands of the next launches at this R from these)
         }
     }
-    // status[1] != 0 is what the host acts on; the value says why (1 / 3 / 4 / 5: a wait gave up, 2: entries do not fit) and where
-    if (last && sp_load(&S.error) && lane == 0)
+    // status[1] != 0 is what the host acts on; the value says why (1 / 3 / 4 / 5: a wait gave up, 2: entries do not fit) and where.
+    // The launch is discarded, but its other workgroups still run: leave a chain word behind (if the round that publishes the
+    // aggregate was abandoned there is none) so that no successor's look-back waits out its spin limit on this workgroup.
+    if (last && sp_load(&S.error) && lane == 0) {
+        chain_store(&chain[lb], kFlagPrefix | etag);
         __hip_atomic_store(&status[1], S.error | (lb << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out, unsigned long long* total,

@@ -278,8 +278,15 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries; the caller's buffers are released
     HIPCHK(c, hipGetLastError());
     c->last_upload_ms[2] = ms_since(t_tex);
-    c->last_upload_ms[0] = ms_since(t_begin);
     c->has_scene = true;
+    // what the first conversion would otherwise have to find out inside its own call (see warm_scene)
+    const auto t_warm = std::chrono::steady_clock::now();
+    if (!debug_on("M2S_NO_WARM")) {
+        const m2s_status ws = warm_scene(c, c->hint_R ? c->hint_R : c->last_R ? c->last_R : 1024u);
+        if (ws != M2S_OK) { c->has_scene = false; return ws; }
+    }
+    c->last_upload_ms[4] = ms_since(t_warm);
+    c->last_upload_ms[0] = ms_since(t_begin);
     return M2S_OK;
 }
 
@@ -298,7 +305,16 @@ m2s_status m2s_prepare(m2s_ctx* c, uint32_t flags) {
 
 m2s_status m2s_last_upload_ms(const m2s_ctx* c, float out_ms[4]) {
     if (!c || !out_ms) return M2S_ERR_INVALID;
-    memcpy(out_ms, c->last_upload_ms, sizeof c->last_upload_ms);
+    memcpy(out_ms, c->last_upload_ms, 4 * sizeof(float));
+    return M2S_OK;
+}
+
+float m2s_last_warm_ms(const m2s_ctx* c) { return c ? c->last_upload_ms[4] : 0.0f; }
+
+m2s_status m2s_set_resolution_hint(m2s_ctx* c, uint32_t R) {
+    if (!c) return M2S_ERR_INVALID;
+    if (R > 4096) return fail(c, M2S_ERR_INVALID, "R must be in [0, 4096]");
+    c->hint_R = R;
     return M2S_OK;
 }
 

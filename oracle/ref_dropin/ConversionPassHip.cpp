@@ -11,6 +11,7 @@
 // INTEGRATION.md quotes it.
 #include "ConversionPass.hpp"
 
+#include <cstdint>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -19,8 +20,34 @@
 
 namespace {
 m2s_ctx* g_ctx = nullptr;
-const void* g_uploaded_for = nullptr;   // the dataMeshAndGlMesh storage the device-resident scene was built from
-size_t g_uploaded_meshes = 0;
+uint64_t g_uploaded_signature = 0;      // of the model the device-resident scene was built from (0: none)
+
+// What SceneManager::loadModel leaves in RenderContext::dataMeshAndGlMesh, reduced to 64 bits: per mesh its name, face count,
+// cumulative bounding box, base colour, and the VBO SceneManager::setupMeshBuffers generated for it.  (NOT the vector's
+// data() pointer: loadModel does clear() + reserve(n) + push_back, SceneManager.cpp:471-573, which keeps the allocation when
+// the next model has as many meshes or fewer — a second one-mesh model would pass for the first.)
+uint64_t model_signature(const RenderContext& rc) {
+    uint64_t h = 1469598103934665603ull;                           // FNV-1a
+    auto mix = [&h](const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    const uint64_t n = rc.dataMeshAndGlMesh.size();
+    mix(&n, sizeof n);
+    for (const auto& meshAndGl : rc.dataMeshAndGlMesh) {
+        const utils::Mesh& mesh = meshAndGl.first;
+        const uint64_t faces = mesh.faces.size(), vertices = meshAndGl.second.vertexCount;
+        mix(mesh.name.data(), mesh.name.size());
+        mix(&faces, sizeof faces);
+        mix(&vertices, sizeof vertices);
+        mix(&meshAndGl.second.vbo, sizeof meshAndGl.second.vbo);
+        mix(&mesh.bbox.min, 12);
+        mix(&mesh.bbox.max, 12);
+        mix(&mesh.material.baseColorFactor, 16);
+        if (faces) { mix(&mesh.faces.front(), sizeof(utils::Face)); mix(&mesh.faces.back(), sizeof(utils::Face)); }
+    }
+    return h ? h : 1;
+}
 
 void check(m2s_status s) {
     if (s != M2S_OK) throw std::runtime_error(m2s_last_error(g_ctx));
@@ -32,7 +59,8 @@ void ConversionPass::execute(RenderContext& renderContext)
     if (!g_ctx) check(m2s_create(/*device*/ 0, &g_ctx));
 
     // ---- scene -> device, once per loaded model (the reference uploads its VBOs / textures in SceneManager::loadModel) ----
-    if (g_uploaded_for != renderContext.dataMeshAndGlMesh.data() || g_uploaded_meshes != renderContext.dataMeshAndGlMesh.size()) {
+    const uint64_t signature = model_signature(renderContext);
+    if (signature != g_uploaded_signature) {
         std::vector<std::vector<float>> vertices(renderContext.dataMeshAndGlMesh.size());
         std::vector<std::vector<unsigned char>> rgba;           // textures the reference keeps with 3 channels, expanded
         rgba.reserve(3 * renderContext.dataMeshAndGlMesh.size());
@@ -83,9 +111,11 @@ void ConversionPass::execute(RenderContext& renderContext)
             }
             meshes.push_back(m);
         }
+        // the upload ends with what the conversion below needs at THIS resolutionTarget (exact count, pipeline choice, XCD band
+        // table, record pool), so that the first conversion of a model costs what a repeated one does
+        check(m2s_set_resolution_hint(g_ctx, renderContext.resolutionTarget));
         check(m2s_upload_scene(g_ctx, meshes.data(), (uint32_t)meshes.size()));   // host memory is only borrowed during the call
-        g_uploaded_for = renderContext.dataMeshAndGlMesh.data();
-        g_uploaded_meshes = renderContext.dataMeshAndGlMesh.size();
+        g_uploaded_signature = signature;
     }
 
     // ---- the pass: cap = min(6 R^2 meshes, 7 000 000) as ConversionPass.cpp:21-24 (the library's default policy) ----

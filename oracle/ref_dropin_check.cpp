@@ -12,6 +12,9 @@
 // (tests/test_gpu_dropin.py).  Needs a GPU at run time (libm2s_hip.so has no CPU fallback).
 //
 //   ref_dropin_check in.glb R out_records.bin [out.ply format gaussianStd]
+//   M2S_DROPIN_LOAD_FIRST=other.glb : SceneManager::loadModel + execute on other.glb first, then everything above on in.glb with
+//   the SAME SceneManager / RenderContext / pass — a second model with as many meshes re-uses dataMeshAndGlMesh's allocation
+//   (clear + reserve + push_back), which an address-keyed "is the scene resident" test would mistake for the first model
 #include "utils/SceneManager.hpp"
 #include "renderer/renderPasses/ConversionPass.hpp"
 
@@ -43,8 +46,12 @@ int main(int argc, char** argv) {
     int rcode = 0;
     try {
         SceneManager sm(rc);
-        if (!sm.loadModel(argv[1], "")) return 2;
         ConversionPass pass;
+        if (const char* first = getenv("M2S_DROPIN_LOAD_FIRST")) {
+            if (!sm.loadModel(first, "")) return 2;
+            pass.execute(rc);
+        }
+        if (!sm.loadModel(argv[1], "")) return 2;
         pass.execute(rc);                                         // first call: uploads the scene, converts
         const auto t0 = std::chrono::steady_clock::now();
         pass.execute(rc);                                         // the scene is resident: what a slider move costs

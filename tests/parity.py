@@ -76,6 +76,50 @@ def error_report(gpu: np.ndarray, ref: np.ndarray) -> dict:
     return out
 
 
+# What the HIP path ACHIEVES against the oracle on the full-size workloads (max |gpu - ref| per field, measured on the final
+# libraries of rounds 2 and 3; gpurun_out/parity_*.json -> profiles/), with a factor 4 of room: the guard of the full-size tests.
+# The 1e-4 rule above is what north_star allows; a regression that moved 0.1 % of the floats to 1e-3 would pass it on most
+# fields — it does not pass this.  `frac` = required fraction of floats within 1e-4 of THEMSELVES (strictly per component):
+# everything, except components of a unit normal that happen to be ~1e-3 (see the module docstring).
+ACHIEVED = {
+    # field: (max_abs bound relative to max |field value| of the workload, frac_within_1e-4_component)
+    "position": (2.4e-7, 1.0), "color": (1.5e-6, 1.0), "scale": (5e-6, 1.0), "normal": (2e-6, 0.9999), "rotation": (5e-7, 1.0),
+    "pbr": (1.5e-6, 1.0),
+}
+
+
+def assert_achieved(gpu: np.ndarray, ref: np.ndarray, what: str, out_json: str = None, scale_by_magnitude: bool = False) -> dict:
+    """error_report + the guard above; writes the report (with the sha of the library under test) to out_json.
+    scale_by_magnitude: the bounds were measured on config 3 (a unit sphere at the origin); for scenes with larger coordinates
+    they are multiplied by max(1, max |field value|)."""
+    rep = error_report(gpu, ref)
+    rep["_what"] = f"HIP records vs oracle, {what} ({gpu.shape[0]} records); see tests/parity.py:error_report"
+    rep["_frac_bit_identical_all_floats"] = float((gpu.view(np.uint32) == ref.view(np.uint32)).mean())
+    try:
+        import hashlib
+        from mesh2splat_amd import _lib
+        rep["_library_sha256"] = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:
+        pass
+    def dump():
+        if out_json:
+            import json, os
+            os.makedirs(os.path.dirname(out_json), exist_ok=True)
+            with open(out_json, "w") as fh:
+                json.dump(rep, fh, indent=1)
+    dump()
+    for name, sl in FIELD_NAMES:
+        bound, frac = ACHIEVED[name]
+        r = ref[:, sl]
+        mag = max(1.0, float(np.abs(r[np.isfinite(r)]).max())) if (r.size and scale_by_magnitude) else 1.0
+        v = rep[name]
+        v["guard_max_abs"] = bound * mag
+        assert v["max_abs"] <= bound * mag, (what, name, v["max_abs"], bound * mag)
+        assert v["frac_within_1e-4_component"] >= frac, (what, name, v["frac_within_1e-4_component"])
+    dump()
+    return rep
+
+
 def assert_ply_rows_match(mine: np.ndarray, ref: np.ndarray, what: str = ""):
     """Format-1 .ply rows (19 floats: xyz | nxyz | f_dc 3 | metallic roughness | opacity | log-scale 3 | rot 4) written from
     GPU records against the reference's file.  The rows are FUNCTIONS of the records, so the 1e-4 bar on the records becomes:

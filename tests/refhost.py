@@ -177,17 +177,20 @@ def dropin_available() -> bool:
     return os.path.isfile(DROPIN_BIN) and os.access(DROPIN_BIN, os.X_OK)
 
 
-def run_dropin(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65):
-    """The reference's loader + oracle/ref_dropin/ConversionPassHip.cpp (libm2s_hip.so) + the reference's exportPly; needs a GPU."""
-    return run_pipeline(glb_path, R, tmp_dir, ply_path, fmt, std, out_path=os.path.join(tmp_dir, "ref_dropin.bin"), exe=DROPIN_BIN)
+def run_dropin(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, load_first: str = None):
+    """The reference's loader + oracle/ref_dropin/ConversionPassHip.cpp (libm2s_hip.so) + the reference's exportPly; needs a GPU.
+    load_first: another .glb that the same SceneManager / pass load and convert BEFORE glb_path (a model switch)."""
+    return run_pipeline(glb_path, R, tmp_dir, ply_path, fmt, std, out_path=os.path.join(tmp_dir, "ref_dropin.bin"), exe=DROPIN_BIN,
+                        env=None if load_first is None else dict(os.environ, M2S_DROPIN_LOAD_FIRST=load_first))
 
 
-def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, out_path: str = None, exe: str = None):
+def run_pipeline(glb_path: str, R: int, tmp_dir: str, ply_path: str = None, fmt: int = 0, std: float = 0.65, out_path: str = None, exe: str = None,
+                 env: dict = None):
     out = out_path or os.path.join(tmp_dir, "ref_pipeline.bin")
     cmd = [exe or PIPE_BIN, glb_path, str(int(R)), out]
     if ply_path:
         cmd += [ply_path, str(int(fmt)), "%.9g" % float(np.float32(std))]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     if r.returncode != 0:
         raise RuntimeError(f"{os.path.basename(cmd[0])} failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-400:]}")
     with open(out, "rb") as f:

@@ -103,3 +103,17 @@ def test_integration_md_quotes_the_compiled_dropin():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     body = open(os.path.join(root, "oracle", "ref_dropin", "ConversionPassHip.cpp")).read()
     assert body in open(os.path.join(root, "INTEGRATION.md")).read()
+
+
+def test_rccl_stand_in_exports_what_load_rccl_resolves():
+    """tests/stub_rccl (the multi-process tests' RCCL stand-in) must export every symbol csrc/m2s_dist.cpp dlsym()s."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "stub_rccl", "_build", "librccl_stub.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(so))], check=True, stdout=subprocess.DEVNULL)
+    wanted = set(re.findall(r'sym\("(nccl\w+)"\)', open(os.path.join(root, "mesh2splat_amd", "csrc", "m2s_dist.cpp")).read()))
+    assert len(wanted) == 9
+    have = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert all(re.search(rf"\bT {w}\b", have) for w in wanted), wanted

@@ -1,6 +1,8 @@
-"""CPU, world_size 2 (gloo): the N>1 host logic — shard plan, counter exchange, record all-gather.
-Device compute is replaced by the oracle here (tests may use it); on GPUs the same functions run on
-RCCL with the HIP path producing each rank's block."""
+"""CPU, world_size 2 / 3 (gloo): the N > 1 host LOGIC — shard plan (the product's: m2s_dist_shard_ranges and its Python twin),
+counter offsets, global cap, the all-pairs record schedule, the sample sort — on a torch.distributed transcription of the exchange
+(tests/torch_twin.py).  Device compute is replaced by the oracle here (tests may use it).  The product's exchange itself
+(csrc/m2s_dist.cpp over RCCL) needs GPUs: tests/test_gpu_dist_stub.py runs it as separate processes, tests/test_gpu_dist_local.py
+as threads."""
 import os
 import socket
 
@@ -10,6 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import torch_twin as twin          # the torch.distributed transcription of the exchange (test infrastructure)
 from mesh2splat_amd import dist as m2d
 from mesh2splat_amd import synth
 
@@ -32,11 +35,11 @@ def _worker(rank, world, port, R, cap, result_dir):
         ranges = m2d.shard_ranges(m2d.estimate_fragments(scene, R), world)
         first, count = ranges[rank]
         total, rec, _ = oracle.convert(scene, R, cap=0, tri_first=first, tri_count=count)
-        counts = m2d.all_gather_counts(total)
+        counts = twin.all_gather_counts(total)
         assert counts[rank] == total
         keep = m2d.clamp_to_cap(counts, cap)
-        merged = m2d.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep)
-        padded = m2d.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep, mode="padded")
+        merged = twin.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep)
+        padded = twin.all_gather_records(torch.from_numpy(rec[: keep[rank]]), keep, mode="padded")
         assert torch.equal(merged.view(torch.int32), padded.view(torch.int32))     # both exchange schedules agree
         np.save(os.path.join(result_dir, f"merged_{rank}.npy"), merged.numpy())
         np.save(os.path.join(result_dir, f"counts_{rank}.npy"), np.asarray(counts))
@@ -84,7 +87,7 @@ def _sort_worker(rank, world, port, case, result_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         keys, payload = _sort_inputs(case, world)[rank]
-        k, p = m2d.sample_sort(torch.from_numpy(keys), torch.from_numpy(payload), samples_per_rank=16)
+        k, p = twin.sample_sort(torch.from_numpy(keys), torch.from_numpy(payload), samples_per_rank=16)
         np.save(os.path.join(result_dir, f"k_{rank}.npy"), k.numpy())
         np.save(os.path.join(result_dir, f"p_{rank}.npy"), p.numpy())
     finally:
@@ -107,7 +110,7 @@ def _sort_inputs(case, world):
         rec[:, 23] = np.arange(n)
         view = np.eye(4, dtype=np.float32)
         view[3, 2] = -3.0                                     # column-major: translation z
-        keys = m2d.depth_keys(torch.from_numpy(rec), view.reshape(16)).numpy()
+        keys = twin.depth_keys(torch.from_numpy(rec), view.reshape(16)).numpy()
         out.append((keys, rec))
     return out
 
@@ -137,7 +140,7 @@ def test_sample_sort_equals_single_stable_sort(tmp_path, world, case):
 
 
 def _exchange_worker(rank, world, port, R, result_dir):
-    """bench.py's stand-in exchange (mesh2splat_amd.dist.TorchExchange: same schedule as m2s_dist_gather_records — every rank
+    """The transcription's exchange object (torch_twin.TorchExchange: same schedule as m2s_dist_gather_records — every rank
     sends its block to rank + step and receives from rank - step, exact sizes, final offsets) on CPU tensors."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -147,7 +150,7 @@ def _exchange_worker(rank, world, port, R, result_dir):
         scene = synth.sphere_grid(2, n=4, tex_size=16)
         first, count = m2d.shard_ranges_native(scene, R, world)[rank]
         total, rec, _ = oracle.convert(scene, R, cap=0, tri_first=first, tri_count=count)
-        ex = m2d.TorchExchange(rank, world, device="cpu")
+        ex = twin.TorchExchange(rank, world, device="cpu")
         for k in range(3):                                   # pipelined counter exchanges complete in order
             ex.publish_count(total + k)
         got = [ex.collect_counts()[0][rank] for _ in range(3)]

@@ -1,0 +1,183 @@
+"""-m gpu: the multi-PROCESS path of csrc/m2s_dist.cpp — one process per rank, each with its own HIP runtime, context and
+communicator — executed for real on the one GPU of the test box.
+
+RCCL refuses two ranks on one device, so these tests select an RCCL stand-in through M2S_RCCL_PATH (tests/stub_rccl: the nine entry
+points load_rccl resolves, over shared memory, with every wait bounded and every send / receive checked against its peer).  What
+runs is the PRODUCT'S code on the path a multi-GPU node takes: the id travels between processes, m2s_dist_create =
+ncclCommInitRank with a bootstrap rendezvous, the counter all-gathers are issued by the worker thread, the record exchange is the
+grouped exact-size ncclSend / ncclRecv schedule (to every rank and to one root), the distributed sort does its three all-gathers
+and one all-pairs exchange — from the command line (mesh2splat --gpus N --gather), from rank scripts, and from bench.py --gpus N.
+A rank that dies inside a collective must become an error on the others, not a hang."""
+import glob
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import camera
+from mesh2splat_amd import gltf_io, synth
+from mesh2splat_amd.converter import Converter
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+STUB = os.path.join(HERE, "stub_rccl", "_build", "librccl_stub.so")
+CLI = os.path.join(ROOT, "mesh2splat_amd", "_build", "mesh2splat")
+needs_stub = pytest.mark.skipif(not os.path.exists(STUB), reason="tests/stub_rccl/_build/librccl_stub.so not built (python __graft_entry__.py)")
+
+
+def stub_env(tmp_path, timeout=60, **extra):
+    objs = tmp_path / "stub_objs"
+    objs.mkdir(exist_ok=True)
+    env = dict(os.environ, M2S_RCCL_PATH=STUB, M2S_STUB_RCCL_DIR=str(objs), M2S_STUB_RCCL_LOG=str(tmp_path / "rccl_log"),
+               M2S_STUB_RCCL_TIMEOUT=str(timeout), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra)
+    return env
+
+
+def logs(tmp_path, world):
+    out = []
+    for r in range(world):
+        p = tmp_path / f"rccl_log.{r}"
+        out.append(p.read_text() if p.exists() else "")
+    return out
+
+
+def run_ranks(tmp_path, world, scenario, env, limit=240):
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_rank.py"), str(r), str(world), str(tmp_path), scenario],
+                              env=env, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    t0 = time.time()
+    rcs, errs = [], []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=max(1.0, limit - (time.time() - t0)))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError(f"{scenario}, world {world}: a rank was still running after {limit} s (a hang)")
+        rcs.append(p.returncode)
+        errs.append(err)
+    return rcs, errs, time.time() - t0
+
+
+def whole(scene, R):
+    c = Converter(0)
+    c.set_max_gaussians(0)
+    c.upload_scene(scene)
+    total = c.convert(R)
+    return c, total, c.download()
+
+
+@needs_stub
+@pytest.mark.parametrize("world,scenario", [(2, "gather"), (4, "gather"), (8, "gather"), (3, "empty")])
+def test_processes_exchange_counters_and_records(hiplib, tmp_path, world, scenario):
+    scene, R = synth.cube_sphere(20, tex_size=32), 144
+    c0, total, rec = whole(scene, R)
+    c0.close()
+    rcs, errs, _ = run_ranks(tmp_path, world, scenario, stub_env(tmp_path))
+    assert rcs == [0] * world, errs
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert bytes(d["transport"]).decode() == "rccl:" + STUB          # the RCCL transport of m2s_dist.cpp, through the stand-in
+        assert int(d["counts"].sum()) == total and int(d["counts"][r]) == int(d["mine"])
+        if scenario == "empty" and r == 0:
+            assert int(d["mine"]) == 0
+        assert np.array_equal(d["everybody"].view(np.uint32), rec.view(np.uint32)), f"rank {r}: merged buffer differs"
+        if r == world - 1:
+            assert np.array_equal(d["rooted"].view(np.uint32), rec.view(np.uint32)), "root's merged buffer differs"
+    lg = logs(tmp_path, world)
+    for r in range(world):
+        assert f"ncclCommInitRank nranks {world} rank {r}" in lg[r]
+        assert lg[r].count("ncclAllGather") == 5                           # one blocking + four pipelined counter exchanges
+        assert "ncclCommDestroy after 5 all-gathers" in lg[r]
+    assert not glob.glob(str(tmp_path / "stub_objs" / "*")), "the exchange left shared objects behind"
+
+
+@needs_stub
+@pytest.mark.parametrize("world,scenario", [(2, "sort"), (4, "sort"), (8, "sort"), (3, "sort_ties")])
+def test_processes_sort_by_depth(hiplib, tmp_path, world, scenario):
+    sys.path.insert(0, HERE)
+    import dist_rank
+    scene, R, view = dist_rank.scene_and_view(scenario)
+    c0, total, _ = whole(scene, R)
+    want = c0.sort_by_depth(view)
+    c0.close()
+    rcs, errs, _ = run_ranks(tmp_path, world, scenario, stub_env(tmp_path))
+    assert rcs == [0] * world, errs
+    run = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        n, off = int(d["n"]), int(d["off"])
+        assert off == run, f"rank {r}: offset {off}, expected {run}"
+        assert np.array_equal(d["sorted"].view(np.uint32), want[run:run + n].view(np.uint32)), f"rank {r}: slice differs"
+        run += n
+    assert run == total
+
+
+@needs_stub
+@pytest.mark.parametrize("die", ["1:0", "1:-1"])
+def test_a_rank_that_dies_inside_a_collective_is_an_error_on_the_others(hiplib, tmp_path, die):
+    """Rank 1 _exit()s inside its first all-gather ("1:0") / inside its first send-receive group ("1:-1").  The other ranks'
+    m2s_dist_* call returns an error (exit code 1 with the library's message); nobody hangs."""
+    world = 3
+    rcs, errs, dt = run_ranks(tmp_path, world, "gather", stub_env(tmp_path, timeout=3, M2S_STUB_RCCL_DIE=die), limit=90)
+    assert rcs[1] == 9
+    assert rcs[0] == 1 and rcs[2] == 1, (rcs, errs)
+    assert "ERR_HIP" in errs[0] or "ERR_STATE" in errs[0], errs[0]
+    assert dt < 60, f"{dt:.0f} s: somebody waited far longer than the stand-in's 3 s bound"
+
+
+@needs_stub
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_command_line_gathers_over_the_rccl_transport(hiplib, tmp_path, world):
+    """mesh2splat in.glb out.ply --gpus N --gather: N forked processes, the id through their shared mapping, RCCL (stand-in)
+    communicator, counter all-gather, record gather to rank 0, which writes the file: same bytes as the one-process run."""
+    glb = str(tmp_path / "s.glb")
+    gltf_io.write_glb(synth.sphere_grid(2, n=6, tex_size=32), glb, indexed=False)
+    one, many = str(tmp_path / "one.ply"), str(tmp_path / "many.ply")
+    base = [CLI, glb, "--density", "96", "--format", "1", "--cap", "0"]
+    r1 = subprocess.run(base[:2] + [one] + base[2:], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr
+    rn = subprocess.run(base[:2] + [many] + base[2:] + ["--gpus", str(world), "--gather", "--one-device"], capture_output=True, text=True,
+                        timeout=300, env=stub_env(tmp_path))
+    assert rn.returncode == 0, rn.stderr
+    assert "gathered on rank 0 over RCCL" in rn.stdout
+    assert open(one, "rb").read() == open(many, "rb").read()
+    lg = logs(tmp_path, world)
+    assert all(f"ncclCommInitRank nranks {world} rank {r}" in lg[r] for r in range(world))
+    assert lg[0].count("ncclRecv") >= 1 and all("ncclSend" in lg[r] for r in range(1, world) )
+
+
+@needs_stub
+def test_command_line_with_a_rank_that_dies(hiplib, tmp_path):
+    glb = str(tmp_path / "s.glb")
+    gltf_io.write_glb(synth.cube_sphere(12, tex_size=16), glb, indexed=False)
+    t0 = time.time()
+    r = subprocess.run([CLI, glb, str(tmp_path / "o.ply"), "--density", "64", "--gpus", "3", "--gather", "--one-device"], capture_output=True,
+                       text=True, timeout=120, env=stub_env(tmp_path, timeout=3, M2S_STUB_RCCL_DIE="2:0"))
+    assert r.returncode != 0
+    assert time.time() - t0 < 60
+
+
+@needs_stub
+def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank; here both on device 0): the line
+    says which transport moved the bytes — the C ABI's RCCL, here the stand-in — and carries gather / strong-scaling sections;
+    and when the communicator cannot be created the run exits non-zero WITHOUT a line (no silent fall-back)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--workload", "c2", "--steps", "4", "--warmup", "1",
+           "--no-extra-workloads", "--extras-timeout", "200"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=stub_env(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["exchange_transport"] == "rccl:" + STUB
+    assert line["value"] > 0 and line["config"]["rccl_ranks"] == 2
+    assert not line["multi_gpu_bringup"]["errors"]
+    assert "gather" in line and line["gather"].get("ms_per_step", 0) > 0, line.get("gather")
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=stub_env(tmp_path, M2S_BENCH_FAIL_COMM="1"))
+    assert bad.returncode != 0
+    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")], "a measurement line was printed although the communicator failed"
+    assert "could not be created" in bad.stderr

@@ -52,6 +52,23 @@ def test_dropin_on_the_committed_reference_scenes(tmp_path, name, R):
     assert_records_match(hip["records"], gold["records"], name + ": drop-in vs committed reference records")
 
 
+def test_dropin_follows_a_model_switch(tmp_path):
+    """two different ONE-mesh models loaded in a row by the same SceneManager.  loadModel's clear + reserve + push_back
+    keeps dataMeshAndGlMesh's allocation, so pointer and size are those of the first model; the body must still notice the switch
+    (it keys the resident scene on a signature of the loaded model) and convert the SECOND one."""
+    a, b = str(tmp_path / "a.glb"), str(tmp_path / "b.glb")
+    gltf_io.write_glb(synth.cube_sphere(6, tex_size=16), a, indexed=False)
+    gltf_io.write_glb(synth.cube_sphere(9, tex_size=32), b, indexed=False)
+    d_ref, d_hip = str(tmp_path / "ref"), str(tmp_path / "hip")
+    os.makedirs(d_ref); os.makedirs(d_hip)
+    ref_b = refhost.run_pipeline(b, 48, d_ref)
+    ref_a = refhost.run_pipeline(a, 48, d_ref, out_path=os.path.join(d_ref, "a.bin"))
+    hip = refhost.run_dropin(b, 48, d_hip, load_first=a)
+    assert ref_a["counter"] != ref_b["counter"]          # (otherwise the test could not tell the models apart)
+    assert hip["counter"] == ref_b["counter"]
+    assert_records_match(hip["records"], ref_b["records"], "second model after a model switch")
+
+
 def test_dropin_on_the_headline_workload(tmp_path):
     """BASELINE config 3 (1 002 252 triangles, 3 x 2048^2 maps, R = 1024) through reference-loader -> HIP -> reference writer."""
     glb = str(tmp_path / "c3.glb")

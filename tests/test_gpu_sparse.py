@@ -97,12 +97,60 @@ def test_cap_and_triangle_range(hiplib, oracle):
 
 
 def test_falls_back_when_a_workgroup_overflows(hiplib, oracle):
-    """A dense scene forced through k_sparse: a workgroup's 512 triangles yield more entries than its LDS stream holds; the
-    conversion is repeated with k_fused2 (and the decision remembered)."""
+    """A dense scene forced through k_sparse: every triangle is larger than an 8 x 8 pixel box, hence deferred; the conversion
+    falls through to another pipeline (and the decision is remembered)."""
     scene = synth.cube_sphere(128, tex_size=32)
     total, rec, ran = convert_with("sparse", scene, 2048, cap=0)
     ototal = oracle.convert(scene, 2048, cap=0, count_only=True, n_threads=8)[0]
     assert ran in ("team", "wave", "multipass") and total == ototal
+
+
+def tessellated_plane(n: int) -> Scene:
+    """n x n cells of two right triangles in the plane z = 0, uv = xy: at R = 5 n every triangle has a 5 x 5 pixel box and 10 or
+    15 fragments — small enough for k_sparse's 8 x 8 masks, and 512 of them hold ~6400 entries: more than its stream of 2560."""
+    g = np.arange(n, dtype=np.float64) / n
+    x0, y0 = np.meshgrid(g, g, indexing="xy")
+    x0, y0 = x0.ravel(), y0.ravel()
+    x1, y1 = x0 + 1.0 / n, y0 + 1.0 / n
+    P = np.stack([np.stack([x0, y0], -1), np.stack([x1, y0], -1), np.stack([x1, y1], -1),
+                  np.stack([x0, y0], -1), np.stack([x1, y1], -1), np.stack([x0, y1], -1)], 1)       # (cells, 6, 2)
+    v = np.zeros((P.shape[0] * 6, 12), np.float32)
+    v[:, 0:2] = P.reshape(-1, 2)
+    v[:, 5] = 1.0
+    v[:, 6] = 1.0
+    v[:, 9] = 1.0
+    v[:, 10:12] = P.reshape(-1, 2)
+    return Scene([Mesh(name="plane", vertices=v, base_color=(1, 1, 1, 1), textures=synth.procedural_textures(64, 5))])
+
+
+def test_entry_stream_overflow_falls_back_to_team_at_once(hiplib, oracle):
+    """error 2 of k_sparse (a workgroup's entries do not fit its LDS stream) in the SECOND round of every workgroup —
+    while its waves hold rounds they claimed ahead.  The abandoned rounds are never counted; sibling waves and successor
+    workgroups must not wait for them (they used to spin for seconds), the host repeats the conversion with k_fused2, whose
+    stream holds these workgroups' ~3200 entries, and remembers it for this and every larger R."""
+    import time
+    scene = tessellated_plane(300)                      # 180 000 triangles: 64-triangle batches, k_sparse is available
+    R = 1500
+    c = Converter(0)
+    c.set_pipeline("sparse")
+    c.set_resolution_hint(64)                           # (the upload's own preparation stays out of the way)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    t0 = time.perf_counter()
+    total = c.convert(R)
+    dt = time.perf_counter() - t0
+    assert c.last_pipeline == "team", c.last_pipeline
+    assert dt < 0.25, f"the fallback took {dt:.3f} s: somebody waited out a spin limit"
+    rec = c.download().copy()
+    t0 = time.perf_counter()
+    assert c.convert(R + 4) > total and c.last_pipeline == "team"      # remembered for the scene: no second discovery
+    assert time.perf_counter() - t0 < 0.25
+    c.close()
+    ototal, orec, _ = oracle.convert(scene, R, cap=0, n_threads=8)
+    assert total == ototal
+    assert_records_match(rec, orec, "plane")
+    t2, rec2, ran2 = convert_with("team", scene, R, 0)
+    assert ran2 == "team" and t2 == total and np.array_equal(rec.view(np.uint32), rec2.view(np.uint32))
 
 
 def test_auto_picks_sparse_and_async_submissions(hiplib, oracle):

@@ -2,7 +2,7 @@
 """Debug tool (-DM2S_TIMING build): when does each XCD start and finish its band of a k_sparse launch?  Prints, per XCD, the span
 from its first workgroup's start to its last one's end (ticks of 10 ns, s_memrealtime), the sum of wave-0 lifetimes and the
 number of workgroups, for the banded launches of BASELINE config 5 at full size (or a cube-sphere: XS_N, XS_R).
-   M2S_LIB_PATH=mesh2splat_amd/_build/timing/libm2s_hip.so [M2S_BAND_COST=t,f] python tools/xcd_spans.py"""
+   M2S_LIB_PATH=mesh2splat_amd/_build/timing/libm2s_hip.so [M2S_DEBUG=1 M2S_BAND_COST=t,f] python tools/xcd_spans.py"""
 import ctypes as C
 import os
 import sys
