@@ -165,6 +165,12 @@ class Converter:
         self._check(self._L.m2s_export_ply_slice(self._h, os.fsencode(path), int(fmt), float(gaussian_std), int(first_row),
                                                  int(n_rows), int(total_rows)))
 
+    def reserve_records(self, n: int) -> int:
+        """Room for n records in the context-owned pool; its device address (m2s_reserve_records)."""
+        p = C.c_void_p()
+        self._check(self._L.m2s_reserve_records(self._h, int(n), C.byref(p)))
+        return int(p.value or 0)
+
     def set_records(self, device_ptr: int, n: int, R: int):
         """Device-resident records from elsewhere (e.g. the merged buffer of a multi-GPU exchange) become the context's
         current records, zero copy (m2s_set_records)."""

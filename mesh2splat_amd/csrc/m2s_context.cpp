@@ -31,7 +31,7 @@ void free_scene(m2s_ctx* c) {
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
     c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->d_wg_base = nullptr;
-    c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0;
+    c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0; c->d_tickets = nullptr;
     c->rinfo.clear();
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;

@@ -77,6 +77,8 @@ struct m2s_ctx {
     uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
+    uint32_t* d_tickets = nullptr;          // 4 ticket sets (TicketSets, m2s_device.h): two per lane, used alternately
+    uint32_t ticket_turn[2] = { 0, 0 };     // per lane: which of its two sets the next persistent launch draws from
     void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
@@ -183,6 +185,7 @@ m2s::BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t uni
 void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st);
 uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit);
 m2s::BatchTable batches_for(const m2s_ctx* c);
+m2s::TicketSets tickets_for(m2s_ctx* c, int lane);   // the ticket sets of the next launch on that lane's chain (advances the turn)
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
 bool multipass_v1();
 m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident

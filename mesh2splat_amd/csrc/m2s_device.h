@@ -144,9 +144,15 @@ struct BatchTable {
 };
 // workgroups of k_fused2 for a scene of n_tri triangles that can be converted in bands (0: too small for 64-triangle batches)
 uint32_t fused2_band_workgroups(uint32_t n_tri);
+// Ticket counters of the persistent form of the single-pass kernels (k_fused2p, see m2s_fused2.hip): eight counters per set, one
+// 128-byte line each.  A launch draws from `use` (all zero when it starts) and zeroes `clear`, the set the NEXT launch on the same
+// chain uses (launches that share a chain are serialised, so that set is idle); use == nullptr: launch the one-unit-per-workgroup form.
+constexpr uint32_t kTicketStride = 32;                   // dwords between two counters
+constexpr size_t kTicketSetBytes = 8 * kTicketStride * sizeof(uint32_t);
+struct TicketSets { uint32_t* use; uint32_t* clear; };
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, const BatchTable& batches, hipStream_t st);
+                   const BandInfo& bands, const BatchTable& batches, const TicketSets& tickets, hipStream_t st);
 // sparse form of the single-pass kernel (m2s_sparse.hip); `bands` as for launch_fused2 (k_fused2's band width: rescaled inside)
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,

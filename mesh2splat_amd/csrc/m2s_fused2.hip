@@ -16,6 +16,7 @@
 // error flag instead of hanging; so does a workgroup whose fragments do not fit the LDS stream (kEntries) — the host
 // then repeats the conversion with k_fused (m2s_pass.cpp, run_pass) and remembers that for the scene and R.
 #include "m2s_fused_common.h"
+#include <cstdio>
 
 #pragma clang fp contract(off)
 
@@ -49,41 +50,56 @@ constexpr uint32_t kXcdRun2 = M2S_XCD_RUN2;
 #ifdef M2S_TIMING
 // debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
 //   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup,
-//   [6] start and [7] end of wave 0 (s_memrealtime: 100 MHz, common to all XCDs), [8] XCD (blockIdx & 7)
+//   [6] start and [7] end of wave 0 (s_memrealtime: 100 MHz, common to all XCDs), [8] XCD (blockIdx & 7),
+//   [9] k_fused2p: at the unit's barrier, [10] resolving the next ticket, [11] until the counts are published, [12] unit number of the workgroup
 constexpr int kF2TimingSlots = 16, kF2TimingBlocks = 8192;
 __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 #define F2_T(slot, v) do { if (wave == 0 && lane == 0 && lb < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + lb] = (v); } while (0)
+#define F2_TW(w, slot, v) do { if (wave == (w) && lane == 0 && lb < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + lb] = (v); } while (0)
 #define F2_NOW() __builtin_amdgcn_s_memtime()
 #else
+#define F2_TW(w, slot, v) do {} while (0)
 #define F2_T(slot, v) do {} while (0)
 #define F2_NOW() 0ull
 #endif
 
-struct F2Lds {
-    float4 tri[kTeam][64 * 5];             // TriShade of the four batches
-    uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
-    uint32_t t0[kTeam];                    // first triangle of each wave's batch (batches need not be equally long: BatchTable)
-#ifdef M2S_FUSED2_LDS_UV
-    float2 uv[kTeam][64 * 3];              // per triangle: (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0): texture coordinates without a global round trip
-#endif
-    uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
-    float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
+// control words of ONE unit of work (a run of kTeam batches).  k_fused2 converts one unit per workgroup and uses ctl[0];
+// the persistent form k_fused2p alternates between the two sets, so that a wave that has finished its strips of unit i can start
+// the triangle phase of unit i + 1 while its team mates still read unit i's words
+struct F2Ctl {
     unsigned long long base;               // record index of stream position 0
     unsigned long long total_w[kTeam];     // fragments (all kinds) per batch
     uint32_t total_c[kTeam];               // entries per batch
     uint32_t counted[kTeam];               // 1: total_w / total_c of that wave are valid
     uint32_t expanded[kTeam];              // 1: that wave's TriShade, tskip and entries are in place
+    uint32_t t0[kTeam];                    // first triangle of each wave's batch (batches need not be equally long: BatchTable)
     uint32_t claimed;                      // next strip to hand out
     uint32_t base_state;                   // 0 unknown, 1 being resolved, 2 known
     uint32_t irregular;                    // 1: record index != base + stream position somewhere (deferred triangles)
     uint32_t error;
+    uint32_t unit;                         // k_fused2p: the unit (logical workgroup) these words belong to, kNoUnit: none left
+    uint32_t first_of_queue;               // k_fused2p: 1 = first unit of its band (its base is the band's, known)
+    uint32_t ready;                        // k_fused2p: iteration number + 1 once `unit` and the words above are initialised
+    uint32_t pad_;
 };
+struct F2Lds {
+    float4 tri[kTeam][64 * 5];             // TriShade of the four batches
+    uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
+#ifdef M2S_FUSED2_LDS_UV
+    float2 uv[kTeam][64 * 3];              // per triangle: (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0): texture coordinates without a global round trip
+#endif
+    uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
+    float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
+    F2Ctl ctl[2];
+    uint32_t drawn;                        // k_fused2p: units this workgroup has drawn a ticket for
+};
+constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // The workgroup's base: sum of the totals of all batches before its first one.  Whoever needs it first resolves it.
-__device__ __forceinline__ bool f2_get_base(F2Lds& S, const unsigned long long* chain, unsigned long long* chain_w, uint32_t b0, int lane,
+__device__ __forceinline__ bool f2_get_base(F2Ctl& S, const unsigned long long* chain, unsigned long long* chain_w, uint32_t b0, int lane,
                                             uint32_t epoch, uint32_t* status, unsigned long long& base) {
     uint32_t st = lds_load(&S.base_state);
     if (st != 2) {
@@ -113,60 +129,204 @@ __device__ __forceinline__ bool f2_get_base(F2Lds& S, const unsigned long long* 
     return true;
 }
 
-__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
-                                                      unsigned long long limit, float4* __restrict__ out,
-                                                      unsigned long long* __restrict__ total_out,
-                                                      uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
-                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
-                                                      BandInfo bands, BatchTable bt) {
-    __shared__ F2Lds S;
-    const int lane = threadIdx.x & 63;
+// ---- persistent form: tickets ------------------------------------------------------------------------------------------
+// k_fused2p keeps (at most) as many workgroups as the GPU holds at once and lets each of them convert unit after unit.  A unit
+// (= what one workgroup of k_fused2 converts: kTeam batches) is handed out by a TICKET (TicketSets, m2s_device.h): eight queues, one per XCD —
+//   banded launch:    queue x = band x of the table (consecutive units first .. first + n, base of the first one known);
+//   launch w/o bands: queue x = units x, x + 8, x + 16, ... (what the hardware's round-robin dispatch gives k_fused2);
+// a workgroup draws from the queue of its own XCD while that has units, then from the queue with the most units left.  Tickets of
+// one queue are drawn in order by workgroups that are RUNNING, so the look-back chain's one requirement holds without any
+// assumption about dispatch: every unit before mine in my queue has been started and will publish its aggregate.  What the
+// dispatcher's order gave k_fused2 for free it also made rigid: a band could not take work from another, and a launch was as
+// wide as its widest band.
+static_assert(kTicketStride == 32, "one 128-byte line per ticket counter");
+
+struct Unit { uint32_t lb; uint32_t first_of_queue; uint32_t queue; };
+struct Queues {      // the eight queues of a launch (see above), from the band table or from the unit count
+    const BandInfo& bands; uint32_t n_wg; bool banded;
+    __device__ __forceinline__ uint32_t first(uint32_t y) const { return banded ? (uint32_t)bands.table[kBandWg + y] : y; }
+    __device__ __forceinline__ uint32_t count(uint32_t y) const {
+        if (banded) return (uint32_t)bands.table[kBandWg + 1u + y] - (uint32_t)bands.table[kBandWg + y];
+        return y < n_wg ? (n_wg - y + 7u) / 8u : 0u;
+    }
+    __device__ __forceinline__ Unit unit(uint32_t y, uint32_t t) const { return Unit{ first(y) + t * (banded ? 1u : 8u), (banded && t == 0u) ? 1u : 0u, y }; }
+};
+// lane 0 of one wave.  Two steps, so that the round trip of the atomic (~1-2 us under load) is not waited for where it is issued:
+// ticket_issue draws from the home queue; ticket_resolve, called later, turns the answer into a unit — or, if the home queue was
+// empty, draws from the queue with the most units left (its CUs would be the last to finish otherwise).  kNoUnit: all empty.
+__device__ __forceinline__ uint32_t ticket_issue(const TicketSets& tk, uint32_t home) {
+    return __hip_atomic_fetch_add(&tk.use[home * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Unit ticket_resolve(const TicketSets& tk, const Queues& q, uint32_t home, uint32_t t) {
+    if (t < q.count(home)) return q.unit(home, t);
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        uint32_t best = 0, y = 8;
+        for (uint32_t z = 0; z < 8u; ++z) {
+            const uint32_t nz = q.count(z);
+            const uint32_t tz = __hip_atomic_load(&tk.use[z * kTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t left = nz > tz ? nz - tz : 0u;
+            if (left > best) { best = left; y = z; }
+        }
+        if (y == 8u) break;
+        const uint32_t t2 = __hip_atomic_fetch_add(&tk.use[y * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 < q.count(y)) return q.unit(y, t2);
+    }
+    return Unit{ kNoUnit, 0u, 0u };
+}
+
+// One kernel body, two launch forms: kPersist = false is k_fused2 (one unit per workgroup, which unit follows from blockIdx),
+// kPersist = true is k_fused2p (units by ticket, a loop).
+// the launch parameters of both forms
+struct F2Args {
+    SceneDev sc;
+    unsigned long long* chain;
+    unsigned long long limit;
+    float4* out;
+    unsigned long long* total_out;
+    uint32_t* status;          // [0] = any big, [1] = error
+    BigItem* biglist;
+    uint32_t* bigmeta;
+    uint32_t R, epoch, tpw;    // tpw: triangles per wave, 64, 32 or 16 (fused_tpw)
+    BandInfo bands;
+    BatchTable bt;
+    TicketSets tk;
+};
+typedef const __attribute__((address_space(4))) F2Args* F2ArgsConst;
+template <class T> __device__ __forceinline__ T ld_const(const __attribute__((address_space(4))) T* p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+// k_fused2p reads its parameters from the kernel-argument segment AGAIN for every unit, through a pointer the compiler cannot see
+// through (`args_mem`): the unit is then compiled like the body of k_fused2 — parameters arrive, are used, die.  Compiled as an
+// ordinary loop over values that live in registers, everything derived from a parameter (R / 2 as a float, plane addresses, the
+// queues' lengths, ...) is computed once in front of the loop and held through every strip: 194 vector registers instead of 157,
+// i.e. 26 of them spilled to scratch at three waves per SIMD, and the kernel 1.47x SLOWER than k_fused2 (0.176 vs 0.120 ms on
+// config 3, profiles/r04/ab_persistent_first_version_spills.log).
+template <bool kPersist>
+__device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2ArgsConst args_mem) {
+    const BandInfo bands = kPersist ? ld_const(&args_mem->bands) : args_direct.bands;     // (prologue and ticket code: a few scalar loads)
+    const TicketSets tk = kPersist ? ld_const(&args_mem->tk) : args_direct.tk;
+    const BatchTable bt = kPersist ? BatchTable{ nullptr, 0u } : args_direct.bt;
+    const uint32_t tpw = kPersist ? 64u : args_direct.tpw;
+    const uint32_t epoch = kPersist ? args_mem->epoch : args_direct.epoch;
+    const uint32_t n_tri_all = kPersist ? args_mem->sc.n_tri : args_direct.sc.n_tri;
+    const int lane_id = threadIdx.x & 63;
+    int lane = lane_id;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Batches are `tpw` consecutive triangles each — or, for a scene small enough to be converted by ONE generation of
     // workgroups, the entries of a table whose batches carry equal estimated WORK (bt.first[b] .. bt.first[b + 1], at most 64
     // triangles, starts at multiples of 8): with one generation the kernel lasts as long as its slowest workgroup.
-    const uint32_t n_batches = bt.first ? bt.n : (sc.n_tri + tpw - 1u) / tpw;
+    const uint32_t n_batches = bt.first ? bt.n : (n_tri_all + tpw - 1u) / tpw;
+    const uint32_t n_wg = (n_batches + (uint32_t)kTeam - 1u) / (uint32_t)kTeam;
     // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (a table in device memory, cut by
     // k_pick_bands from what an earlier launch at this R recorded: where each of eight runs of consecutive workgroups starts
     // and where its output starts) XCD x converts the x-th run: neighbouring triangles — neighbouring texels — meet in ONE
     // L2 instead of eight, and the look-back chain restarts at every band (a workgroup still only waits for workgroups
     // dispatched before it: h - 8, h - 16, ...).  The runs carry equal estimated work, not equal numbers of workgroups.
     // Without bands: plain round-robin (or runs of kXcdRun2, which the chain does not like: see DESIGN.md).
-    const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
+    const uint32_t hb = blockIdx.x, xcd = hb & 7u;
     const bool banded = bands.max_width != 0u;
-    uint32_t lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
-    if (banded) {   // (scalar loads: the band's first workgroup and the next band's)
-        lb = (uint32_t)bands.table[kBandWg + xcd] + round;
-        if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
-    }
-    const bool band_first = banded && round == 0;     // this workgroup's base is the band's base: known
-    const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
-    if (b0 >= n_batches) return;
-    const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
-    const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
-    const bool has_batch = wave < nb_here;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
+    const Queues queues{ bands, n_wg, banded };
+
+    if (kPersist) {
+        // LDS is not zero on entry: `ready` of both control sets and the draw counter are cleared before anybody looks at them.
+        // (One barrier here, one per unit below: every wave executes the same number.)
+        if (threadIdx.x == 0) {
+            S.ctl[0].ready = 0; S.ctl[1].ready = 0; S.drawn = 0;
+            if (hb == 0) for (uint32_t z = 0; z < 8u; ++z) __hip_atomic_store(&tk.clear[z * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t it = 0;; ++it) {
+    F2ArgsConst am = args_mem;
+    if (kPersist) asm volatile("" : "+s"(am));       // (see above: the parameters are loaded afresh for every unit)
+    if (kPersist) { lane = lane_id; asm volatile("" : "+v"(lane)); }   // (likewise per-lane constants: LDS addresses, tags, lane / 6)
+    const SceneDev sc = kPersist ? ld_const(&am->sc) : args_direct.sc;
+    const uint32_t R = kPersist ? am->R : args_direct.R;
+    unsigned long long* __restrict__ const chain = kPersist ? am->chain : args_direct.chain;
+    const unsigned long long limit = kPersist ? am->limit : args_direct.limit;
+    float4* __restrict__ const out = kPersist ? am->out : args_direct.out;
+    unsigned long long* __restrict__ const total_out = kPersist ? am->total_out : args_direct.total_out;
+    uint32_t* __restrict__ const status = kPersist ? am->status : args_direct.status;
+    BigItem* __restrict__ const biglist = kPersist ? am->biglist : args_direct.biglist;
+    uint32_t* __restrict__ const bigmeta = kPersist ? am->bigmeta : args_direct.bigmeta;
+    F2Ctl& C = S.ctl[kPersist ? (it & 1u) : 0u];
+    uint32_t lb;
+    bool band_first;
     [[maybe_unused]] const unsigned long long tk0 = F2_NOW();     // phase timers: live only in -DM2S_TIMING builds
 #ifdef M2S_TIMING
     const unsigned long long tk_real0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz, the same on every XCD: s_memtime is per XCD)
 #endif
-    [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0;
-
-    // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
-    // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed
-    if (lane == 0) {
-        S.counted[wave] = 0;
-        S.expanded[wave] = 0;
+    [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0, tk_bar = 0, tk_tick = 0, tk_tri = 0;
+    if (!kPersist) {
+        if (it) return;
+        const uint32_t round = hb >> 3;
+        lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
+        if (banded) {   // (scalar loads: the band's first workgroup and the next band's)
+            lb = (uint32_t)bands.table[kBandWg + xcd] + round;
+            if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
+        }
+        band_first = banded && round == 0;     // this workgroup's base is the band's base: known
+        if (lb * (uint32_t)kTeam >= n_batches) return;
+        // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
+        // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed.
+        // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
+        // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
+        if (lane == 0) { C.counted[wave] = 0; C.expanded[wave] = 0; }
+        if (wave == 0 && lane == 0) {
+            C.claimed = 0; C.irregular = 0; C.error = 0;
+            C.base_state = (lb == 0 || band_first) ? 2u : 0u;
+            C.base = band_first ? bands.table[xcd] : 0ull;   // scalar load from device memory
+        }
+        __syncthreads();
+    } else {
+        // The unit of this iteration is drawn by the FIRST wave that gets here — when the workgroup is about to start it, not
+        // earlier: units must START in ticket order, or the look-back of every later unit waits for one that was drawn early by a
+        // workgroup still busy with its previous unit.  (First version: wave 0 drew the next ticket a whole unit ahead, to hide
+        // the atomic's round trip; the waves then spent 13 k cycles per unit at the barrier below, behind their last wave's
+        // look-back: 0.150 ms instead of k_fused2's 0.120, profiles/r04/timeline_persistent_tickets_drawn_one_unit_ahead.log.)
+        // The other set of control words is free: everybody left the unit before the previous one at that unit's barrier.
+        {
+            uint32_t mine = 0;
+            if (lane == 0) {
+                uint32_t expect = it;
+                mine = __hip_atomic_compare_exchange_strong(&S.drawn, &expect, it + 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                if (mine) {
+                    [[maybe_unused]] const unsigned long long ttk0 = F2_NOW();
+                    const Unit u = ticket_resolve(tk, queues, xcd, ticket_issue(tk, xcd));
+                    C.unit = u.lb; C.first_of_queue = u.first_of_queue;
+                    C.claimed = 0; C.irregular = 0; C.error = 0;
+                    C.base_state = (u.lb == 0u || u.first_of_queue) ? 2u : 0u;
+                    C.base = u.first_of_queue ? bands.table[kBandBase + u.queue] : 0ull;
+#pragma unroll
+                    for (int k = 0; k < kTeam; ++k) { C.counted[k] = 0; C.expanded[k] = 0; }
+                    tk_tick = F2_NOW() - ttk0;
+                    __hip_atomic_store(&C.ready, it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        uint32_t spins = 0;
+        bool lost = false;
+        while (lds_load(&C.ready) != it + 1u) {
+            if (++spins > kWaitLimit) { lost = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        lb = lost ? kNoUnit : C.unit;
+        lb = __builtin_amdgcn_readfirstlane(lb);
+        if (lost && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lb == kNoUnit) return;
+        band_first = C.first_of_queue != 0u;
     }
-    // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
-    // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
-    if (wave == 0 && lane == 0) {
-        S.claimed = 0; S.irregular = 0; S.error = 0;
-        S.base_state = (b0 == 0 || band_first) ? 2u : 0u;
-        S.base = band_first ? bands.table[xcd] : 0ull;   // scalar load from device memory
-    }
-    __syncthreads();
+    const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
+    const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
+    const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
+    const bool has_batch = wave < nb_here;
+    // (the band of a unit: its base is table[band]; a stolen first unit still takes its OWN band's base, read back from the words)
+    const unsigned long long band_base = band_first ? C.base : 0ull;
 
     // ======================= triangle phase: one batch per wave (as in k_fused) =======================
     uint32_t t0 = b * tpw, nt = tpw;
@@ -177,13 +337,25 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     }
     const uint32_t t = t0 + lane;
     const bool valid = has_batch && (uint32_t)lane < nt && t < sc.n_tri;
-    if (lane == 0) S.t0[wave] = t0;        // (read by other waves only after this wave's `expanded` flag)
+    if (lane == 0) C.t0[wave] = t0;        // (read by other waves only after this wave's `expanded` flag)
     float p[9];
     Geo g;
     Raster rs;
     rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
 #pragma unroll
     for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
+    if (kPersist) {
+        // Every per-unit variable gets a value on EVERY path, once per unit.  A variable that lanes without a triangle leave
+        // unset is "undefined" to the compiler, and in a loop the cheapest undefined value is the one the register held in
+        // the previous iteration: positions, frame and window coordinates of unit i were carried — live — through all strips
+        // into unit i + 1 (16 register pairs copied at the loop latch; with the per-lane constants hoisted in front of the loop
+        // 194 VGPRs instead of 157).
+#pragma unroll
+        for (int i = 0; i < 9; i++) p[i] = 0.0f;
+        g.xx = g.xy = g.xz = g.nx = g.ny = g.nz = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) g.ou[i] = g.ov[i] = 0.0f;
+    }
     bool ok = false;
     uint32_t m = 0;
     float4 uvb0 = make_float4(0, 0, 0, 0);
@@ -267,25 +439,25 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     const uint32_t inclc = wave_incl_scan(cntc, lane);
     const unsigned long long total_w = __builtin_amdgcn_readlane(incl, 63);
     const uint32_t total_c = __builtin_amdgcn_readlane(inclc, 63);
-    const unsigned long long toff = incl - cnt;   
+    const unsigned long long toff = incl - cnt;
     const uint32_t ctoff = inclc - cntc;
 
     // publish: the chain word of this batch (global batch 0 knows its prefix) and the counts for the team
     if (has_batch && lane == 0) {
         // the first batch of the grid / of a band knows its inclusive prefix; everybody else publishes the aggregate
         const bool knows = b == 0 || (band_first && wave == 0);
-        const unsigned long long before = band_first ? bands.table[xcd] : 0ull;
-        chain_store(&chain[b], (knows ? kFlagPrefix : kFlagAgg) | etag | (((knows ? before : 0ull) + total_w) & kValMask));
+        chain_store(&chain[b], (knows ? kFlagPrefix : kFlagAgg) | etag | (((knows ? band_base : 0ull) + total_w) & kValMask));
     }
     if (lane == 0) {
-        S.total_w[wave] = total_w; S.total_c[wave] = total_c;
+        C.total_w[wave] = total_w; C.total_c[wave] = total_c;
         // deferred triangles make record index != base + stream position for everything after them.  The flag travels WITH
         // the counts — the fragment phase starts only after every wave has counted — and not with the later expansion: a
         // strip made of ANOTHER wave's entries does not wait for this wave's expansion and must not read "not yet set"
         // (round 3: it used to be set after the look-back below; a strip of the next wave's entries could run before that)
-        if (anybig) __hip_atomic_fetch_or(&S.irregular, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (anybig) __hip_atomic_fetch_or(&C.irregular, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    lds_store(&S.counted[wave], 1u);
+    lds_store(&C.counted[wave], 1u);
+    tk_tri = F2_NOW() - tk0;
 
     // ======================= where do my entries go?  counts of the waves before me =======================
     uint32_t stream0 = 0;              // stream position of my first entry
@@ -295,19 +467,19 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         const unsigned long long tw0 = F2_NOW();
         for (uint32_t k = 0; k < wave && alive; ++k) {
             uint32_t spins = 0;
-            while (lds_load(&S.counted[k]) == 0) {
+            while (lds_load(&C.counted[k]) == 0) {
                 if (++spins > kWaitLimit) { alive = false; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            stream0 += S.total_c[k];
-            out0 += S.total_w[k];
+            stream0 += C.total_c[k];
+            out0 += C.total_w[k];
         }
         tk_cnt = F2_NOW() - tw0;
     }
-    if (!alive && lane == 0) lds_store(&S.error, 1u);
+    if (!alive && lane == 0) lds_store(&C.error, 1u);
     if (alive && (unsigned long long)stream0 + total_c > kEntries) {   // does not fit the LDS stream
         alive = false;
-        if (lane == 0) lds_store(&S.error, 2u);
+        if (lane == 0) lds_store(&C.error, 2u);
     }
 
     float4* stage = S.stage[wave];
@@ -320,13 +492,24 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     // then waited 3.9 k cycles for the base on average).  The predecessors' aggregates are published right after THEIR
     // counting, i.e. at about the time this workgroup has counted too.
 #ifndef M2S_LATE_LOOKBACK
-    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&S.error) == 0) {
+    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&C.error) == 0) {
         const unsigned long long tb0 = F2_NOW();
-        have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+        have_base = f2_get_base(C, chain, chain, b0, lane, epoch, status, base);
         if (!have_base) alive = false;
         tk_base += F2_NOW() - tb0;
     }
 #endif
+
+    if (kPersist) {
+        // Everything above touched registers, global memory and THIS unit's control words only.  From here on the unit writes the
+        // single-buffered arrays (TriShade table, entry stream, staging) which the previous unit's strips may still be reading: all
+        // four waves meet here, i.e. after the slowest one has left the previous unit.  (k_fused2 has this rendezvous implicitly,
+        // and earlier: a workgroup starts when the previous one on its slot has exited — a wave that finishes its strips early
+        // idles until the slowest has finished; here it has done a triangle phase meanwhile.)
+        [[maybe_unused]] const unsigned long long tbar0 = F2_NOW();
+        __syncthreads();
+        tk_bar = F2_NOW() - tbar0;
+    }
 
     // ======================= my TriShade, tskip and entries =======================
     if (alive) {
@@ -347,14 +530,14 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         }
         if (anybig) {   // deferred triangles: reserve their slice of the output, list them for k_emit_big
             unsigned long long base;
-            if (f2_get_base(S, chain, chain, b0, lane, epoch, status, base)) {
+            if (f2_get_base(C, chain, chain, b0, lane, epoch, status, base)) {
                 if (kind == kBig) {
                     const uint32_t slot = atomicAdd(&bigmeta[0], 1u);
                     atomicMax(&bigmeta[1], cnt);
                     atomicAdd(&bigmeta[2], cnt);
-                    BigItem it;
-                    it.t = t; it.cnt = cnt; it.off = base + out0 + toff;
-                    biglist[slot] = it;
+                    BigItem it2;
+                    it2.t = t; it2.cnt = cnt; it2.off = base + out0 + toff;
+                    biglist[slot] = it2;
                 }
                 if (lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else alive = false;
@@ -380,7 +563,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             }
         }
     }
-    lds_store(&S.expanded[wave], 1u);   // release: TriShade, tskip, entries (set even on error so that nobody waits for it)
+    lds_store(&C.expanded[wave], 1u);   // release: TriShade, tskip, entries (set even on error so that nobody waits for it)
 
     // ======================= fragment phase: strips of the workgroup's stream =======================
     // the stream's length needs every wave's count
@@ -392,25 +575,26 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         const unsigned long long tw0 = F2_NOW();
         for (uint32_t k = 0; k < (uint32_t)kTeam; ++k) {
             uint32_t spins = 0;
-            while (lds_load(&S.counted[k]) == 0) {
-                if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&S.error, 1u); break; }
+            while (lds_load(&C.counted[k]) == 0) {
+                if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&C.error, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            stream_total += S.total_c[k];
-            out_total += S.total_w[k];
+            stream_total += C.total_c[k];
+            out_total += C.total_w[k];
             cum[k + 1] = stream_total;
         }
         tk_cnt += F2_NOW() - tw0;
     }
 #ifdef M2S_LATE_LOOKBACK   // A/B switch: round 1's placement (after the last wave's own expansion)
-    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&S.error) == 0) {
-        have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&C.error) == 0) {
+        have_base = f2_get_base(C, chain, chain, b0, lane, epoch, status, base);
         if (!have_base) alive = false;
     }
 #endif
-    while (alive && lds_load(&S.error) == 0) {
+    [[maybe_unused]] const unsigned long long tsl0 = F2_NOW();
+    while (alive && lds_load(&C.error) == 0) {
         uint32_t s = 0;
-        if (lane == 0) s = __hip_atomic_fetch_add(&S.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) s = __hip_atomic_fetch_add(&C.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         s = __builtin_amdgcn_readfirstlane(s);
         const uint32_t pos0 = s * 64u;
         if (pos0 >= stream_total) break;
@@ -420,14 +604,14 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             for (uint32_t k = 0; k < (uint32_t)kTeam && alive; ++k) {
                 if (cum[k + 1] <= pos0 || cum[k] >= pos0 + n) continue;
                 uint32_t spins = 0;
-                while (lds_load(&S.expanded[k]) == 0) {
-                    if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&S.error, 1u); break; }
+                while (lds_load(&C.expanded[k]) == 0) {
+                    if (++spins > kWaitLimit) { alive = false; if (lane == 0) lds_store(&C.error, 1u); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
             tk_ent += F2_NOW() - tw0;
         }
-        if (!alive || lds_load(&S.error)) break;
+        if (!alive || lds_load(&C.error)) break;
         ++n_strips;
         uint32_t en = kInvalidEntry;
         if ((uint32_t)lane < n) en = S.entries[pos0 + lane];
@@ -437,6 +621,10 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         for (int k = 1; k < kTeam; ++k) ow += (pos0 + (uint32_t)lane >= cum[k]) ? 1u : 0u;
         const uint32_t tl = (en >> 24) & 63u;
         float4 rec[6];
+        if (kPersist) {     // (a value on every path: see the triangle phase)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rec[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         uint32_t skip = 0;
         // do all fragments of the strip belong to one mesh?
         uint32_t my_mesh = 0;
@@ -445,7 +633,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
         if (have) {
             const TriShade& ts = *reinterpret_cast<const TriShade*>(&S.tri[ow][tl * 5]);
-            const uint32_t tt = S.t0[ow] + tl;
+            const uint32_t tt = C.t0[ow] + tl;
             skip = S.tskip[ow][tl];
             // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
 #ifdef M2S_FUSED2_LDS_UV
@@ -458,11 +646,11 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         }
         if (!have_base) {
             const unsigned long long tb0 = F2_NOW();
-            if (!f2_get_base(S, chain, chain, b0, lane, epoch, status, base)) break;
+            if (!f2_get_base(C, chain, chain, b0, lane, epoch, status, base)) break;
             have_base = true;
             tk_base += F2_NOW() - tb0;
         }
-        if (lds_load(&S.irregular) == 0) {
+        if (lds_load(&C.irregular) == 0) {
             const unsigned long long o0 = base + pos0;
             uint32_t nvalid = n;
             if (o0 + 64ull > limit) {
@@ -495,10 +683,11 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             }
         }
     }
+    [[maybe_unused]] const unsigned long long tsl1 = F2_NOW();
     // ======================= epilogue: the workgroup's inclusive prefix / the counter =======================
     // (by the wave of the last batch; the base is resolved here if no strip needed it, e.g. a workgroup without fragments)
-    if (alive && wave == nb_here - 1 && lds_load(&S.error) == 0) {
-        if (!have_base) have_base = f2_get_base(S, chain, chain, b0, lane, epoch, status, base);
+    if (alive && wave == nb_here - 1 && lds_load(&C.error) == 0) {
+        if (!have_base) have_base = f2_get_base(C, chain, chain, b0, lane, epoch, status, base);
         if (have_base && lane == 0) {
             chain_store(&chain[b0 + nb_here - 1], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (b0 + nb_here == n_batches) *total_out = base + out_total;
@@ -508,21 +697,75 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
         }
     }
     // status[1] != 0 is what the host acts on; 2 = "a workgroup's entries do not fit", 1 = a bounded wait gave up
-    { const uint32_t e = lds_load(&S.error); if (e && lane == 0) __hip_atomic_store(&status[1], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    { const uint32_t e = lds_load(&C.error); if (e && lane == 0) __hip_atomic_store(&status[1], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     F2_T(0, F2_NOW() - tk0); F2_T(1, tk_cnt); F2_T(2, tk_ent); F2_T(3, tk_base); F2_T(4, n_strips); F2_T(5, (unsigned long long)stream_total);
     F2_T(6, tk_real0); F2_T(7, __builtin_amdgcn_s_memrealtime()); F2_T(8, (unsigned long long)(blockIdx.x & 7u));
+    F2_T(9, tk_bar); F2_T(10, tk_tick); F2_T(11, tk_tri); F2_T(12, (unsigned long long)it);
+    F2_T(13, tsl1 - tsl0); F2_TW(3, 14, tsl1 - tsl0); F2_TW(3, 15, n_strips);
+    }   // units
+}
+
+__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+                                                      unsigned long long limit, float4* __restrict__ out,
+                                                      unsigned long long* __restrict__ total_out,
+                                                      uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
+                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
+                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
+                                                      BandInfo bands, BatchTable bt) {
+    __shared__ F2Lds S;
+    const F2Args a{ sc, chain, limit, out, total_out, status, biglist, bigmeta, R, epoch, tpw, bands, bt, TicketSets{ nullptr, nullptr } };
+    f2_body<false>(S, a, nullptr);
+}
+
+// the persistent form (see "tickets" above): at most as many workgroups as the GPU holds at once, units by ticket.  Its one
+// parameter is never touched by name: the body reads it from the kernel-argument segment (f2_body, args_mem).
+__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2p(F2Args a) {
+    __shared__ F2Lds S;
+    f2_body<true>(S, *reinterpret_cast<const F2Args*>(&S) /* never read */, (F2ArgsConst)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// workgroups of k_fused2p the GPU holds at once (its grid)
+static uint32_t persistent_grid() {
+    static const uint32_t n = [] {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0u;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused2p, kTeamThreads, 0) != hipSuccess || per_cu <= 0) return 0u;
+        return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    }();
+    return n;
 }
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, const BatchTable& bt, hipStream_t st) {
+                   const BandInfo& bands, const BatchTable& bt, const TicketSets& tk, hipStream_t st) {
     const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
     const uint32_t n_batches = bt.first ? bt.n : n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     BandInfo b = bands;
     if (tpw != 64u || kTeam != 4 || bt.first) { b.max_width = 0; b.out = nullptr; }
-    if (b.max_width) { nb = 8u * b.max_width; b.out = nullptr; }
+    if (b.max_width) b.out = nullptr;
+    // The persistent form (units by ticket) is built, bit-identical (tests/test_gpu_persistent.py) and NOT the default: on config 3
+    // it is 11 % slower than one unit per workgroup (0.133 vs 0.118 ms, profiles/r04/ab_persistent_tickets_at_unit_start.log).  It
+    // does what it was built for — 757 of 768 slots busy until the last sixth of the launch instead of ~700 — but (1) a strip
+    // then takes 8.8 k cycles instead of 7.9 k: the memory system, not the number of workgroups in flight, sets the steady-state
+    // rate; (2) the four waves of a team have to meet once per unit before they overwrite the shared tables, and they meet after
+    // the slowest wave's triangle phase: 7.5 k cycles of waiting per unit against the ~4 k the hardware needs to replace an
+    // exited workgroup; (3) the tail is the same 1.3 unit lifetimes.  (profiles/r04/timeline_persistent_*.log.)  Debug switch
+    // M2S_PERSIST=1 selects it for scenes of more than one generation of workgroups.
+    uint32_t pg = persistent_grid();
+    if (const char* v = debug_env("M2S_PERSIST_GRID")) {     // debug: A/B of the grid size
+        static bool said = false;
+        if (!said) { said = true; fprintf(stderr, "[m2s] k_fused2p: occupancy query says %u workgroups, M2S_PERSIST_GRID=%s\n", pg, v); }
+        pg = (uint32_t)strtoul(v, nullptr, 10);
+    }
+    if (tk.use && pg && nb > pg && tpw == 64u && kTeam == 4 && !bt.first && debug_on("M2S_PERSIST")) {
+        const F2Args a{ sc, chain, (unsigned long long)limit, out, total, status, biglist, bigmeta, R, epoch & 0xFFFFu, 64u, b, BatchTable{ nullptr, 0u }, tk };
+        hipLaunchKernelGGL(k_fused2p, dim3(pg), dim3(kTeamThreads), 0, st, a);
+        return;
+    }
+    if (b.max_width) nb = 8u * b.max_width;
     else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
                        epoch & 0xFFFFu, biglist, bigmeta, tpw, b, bt);

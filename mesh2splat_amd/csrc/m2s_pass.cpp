@@ -85,6 +85,16 @@ BatchTable batches_for(const m2s_ctx* c) {
     return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab } : BatchTable{ nullptr, 0u };
 }
 
+// Persistent launches (k_fused2p) draw their units from ticket counters that must be zero when the launch starts: every lane
+// has two sets and alternates — a launch zeroes the set of the NEXT launch on its chain, which is idle because launches that
+// share a chain run in order.
+TicketSets tickets_for(m2s_ctx* c, int lane) {
+    if (!c->d_tickets) return TicketSets{ nullptr, nullptr };
+    const uint32_t turn = c->ticket_turn[lane]++ & 1u;
+    uint32_t* base = c->d_tickets + (size_t)lane * 2 * 8 * kTicketStride;
+    return TicketSets{ base + (size_t)turn * 8 * kTicketStride, base + (size_t)(turn ^ 1u) * 8 * kTicketStride };
+}
+
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
     if (c->cap_policy == 0) return 0;
     if (c->cap_policy > 0) return (uint64_t)c->cap_policy;
@@ -184,6 +194,8 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     // allocations a first conversion would otherwise make inside its own call; best effort (the conversion reports a failure)
     const uint64_t want = cap ? cap : std::max<uint64_t>(total, 1);
     if (!single || total >= 8ull * sc.n_tri) (void)ensure_multipass_buffers(c, std::min<uint64_t>(cap ? cap : want, 0xFFFFFFFFull));
+    // (touching the pool here does not pay: a hipMemset of the part the first conversion writes made that conversion 0.014 ms
+    //  SLOWER on config 3, 0.185 vs 0.171 ms — profiles/r04/first_call_probe.jsonl)
     (void)ensure_records(c, want);
     c->err.clear();
     return M2S_OK;
@@ -293,7 +305,10 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     // The fragment count of a scene is proportional to R^2 (window coordinates scale with R), so the ONE exact count
     // m2s_upload_scene took (warm_scene) decides for every R without touching the device: the threshold is not sharp, and
     // all pipelines produce the same bytes anyway.
-    if (c->frag_per_R2 < 0.0) return fail(c, M2S_ERR_STATE, "the scene has not been analysed (m2s_upload_scene failed?)");
+    if (c->frag_per_R2 < 0.0) {   // only with the debug switch M2S_NO_WARM (round 3's behaviour: the analysis inside the first conversion)
+        const m2s_status s = warm_scene(c, R);
+        if (s != M2S_OK) return s;
+    }
     const double predicted = c->frag_per_R2 * (double)R * (double)R;
     if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, predicted);
 
@@ -334,7 +349,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                       c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), tickets_for(c, 0), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));

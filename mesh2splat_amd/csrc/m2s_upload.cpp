@@ -190,6 +190,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const size_t o_bands = take((size_t)kBandSlots * kBandTableWords * sizeof(unsigned long long));
     const size_t o_wg_base = take(((size_t)n_fused_waves(n_tri) / 4 + 2) * sizeof(unsigned long long));
     const size_t o_batch = take(std::max<size_t>(batch_table_capacity(n_tri), 1) * sizeof(uint32_t));
+    const size_t o_tickets = take(4 * kTicketSetBytes);
     HIPCHK(c, hipMalloc(&c->scene_arena, arena));
     { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
     c->last_upload_ms[3] = ms_since(t_alloc);
@@ -272,6 +273,9 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->d_wg_base = (unsigned long long*)(A + o_wg_base);
     c->d_batch_first = (uint32_t*)(A + o_batch);
     c->n_batch_tab = 0;
+    c->d_tickets = (uint32_t*)(A + o_tickets);
+    c->ticket_turn[0] = c->ticket_turn[1] = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 4 * kTicketSetBytes, c->stream));
     c->chain_words = chain_words;
     HIPCHK(c, hipMemsetAsync(c->d_chain, 0, chain_words * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));

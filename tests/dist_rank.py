@@ -9,7 +9,6 @@ Scenarios (results go to <work dir>/rank<r>.npz; the parent compares them with O
   sort     shard plan -> convert -> m2s_dist_sort_by_depth (sample sort: three all-gathers + one all-pairs exchange)
   empty    as gather, but rank 0's triangle range is empty (it sends nothing and still receives)
 Exit code 0: fine; 1: an m2s call failed (message on stderr) — what a dead peer must turn into, instead of a hang."""
-import ctypes as C
 import os
 import sys
 import time
@@ -32,17 +31,16 @@ def scene_and_view(scenario):
     return synth.cube_sphere(20, tex_size=32), 144, camera.look_at((1.6, 1.1, 2.3), (0.1, 0.0, -0.1))
 
 
-def hip_alloc(hip, nbytes):
-    p = C.c_void_p()
-    assert hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 16))) == 0
-    assert hip.hipMemset(p, 0, C.c_size_t(max(nbytes, 16))) == 0
-    return p
+def merged_buffer(total):
+    """A context that only holds a merged buffer (what the command line's rank 0 does): room in its record pool."""
+    sink = Converter(0)
+    return sink, sink.reserve_records(max(total, 1))
 
 
-def d2h(hip, ptr, rows):
-    out = np.zeros((rows, 24), np.float32)
-    if rows:
-        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(rows * 96), 2) == 0
+def read_back(sink, ptr, total, R):
+    sink.set_records(ptr, total, R)
+    out = sink.download() if total else np.zeros((0, 24), np.float32)
+    sink.close()
     return out
 
 
@@ -65,7 +63,6 @@ def main():
         with open(id_file, "rb") as f:
             return f.read()
 
-    hip = C.CDLL("libamdhip64.so")
     try:
         ex = m2d.RcclExchange(0, rank, world, bootstrap)
         plan = m2d.shard_ranges_native(scene, R, world)
@@ -89,16 +86,16 @@ def main():
             for k in range(4):
                 assert ex.collect_counts()[0][rank] == mine + k
             total = offs[-1]
-            merged = hip_alloc(hip, total * 96)
-            ex.gather_records(c.device_records or 0, counts, merged.value, -1, 0)
+            sink, merged = merged_buffer(total)
+            ex.gather_records(c.device_records or 0, counts, merged, -1, 0)
             ex.wait(0)
-            out.update(counts=np.asarray(counts, np.int64), everybody=d2h(hip, merged, total))
+            out.update(counts=np.asarray(counts, np.int64), everybody=read_back(sink, merged, total, R))
             root = world - 1
-            rooted = hip_alloc(hip, total * 96) if rank == root else None
-            ex.gather_records(c.device_records or 0, counts, rooted.value if rooted is not None else 0, root, 0)
+            sink, rooted = merged_buffer(total) if rank == root else (None, 0)
+            ex.gather_records(c.device_records or 0, counts, rooted, root, 0)
             ex.wait(0)
-            if rooted is not None:
-                out["rooted"] = d2h(hip, rooted, total)
+            if sink is not None:
+                out["rooted"] = read_back(sink, rooted, total, R)
         np.savez(os.path.join(work, f"rank{rank}.npz"), **out)
         c.close()
         ex.close()

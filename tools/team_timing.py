@@ -9,7 +9,7 @@ from mesh2splat_amd import _lib, synth
 from mesh2splat_amd.converter import Converter
 N, R = int(os.environ.get('TT_N', 289)), int(os.environ.get('TT_R', 1024))
 scene = synth.cube_sphere(N, tex_size=2048)
-c = Converter(0); c.set_pipeline("team"); c.upload_scene(scene)
+c = Converter(0); c.set_pipeline("team"); c.set_resolution_hint(R); c.upload_scene(scene)
 c.set_max_gaussians(0)
 for _ in range(3): c.convert(R)
 c.set_profiling(True); n = c.convert(R); print('n', N, 'R', R, 'triangles', scene.n_triangles, "gaussians", n, c.last_kernel_ms())
@@ -23,6 +23,10 @@ def st(x): return f"median {np.median(x):9.0f} mean {x.mean():9.0f} p90 {np.perc
 print("workgroups", nb, "(wave 0 of each)")
 for i, name in enumerate(["total", "wait counts", "wait entries", "wait base", "strips", "entries / workgroup"]):
     print(f"{name:22s}", st(t[i]))
+for i, name in ((9, "at the unit barrier"), (10, "next ticket"), (11, "until counts published"), (12, "units per workgroup"),
+                (13, "wave 0 in strip loop"), (14, "wave 3 in strip loop"), (15, "wave 3 strips")):
+    print(f"{name:22s}", st(t[i]))
+print("cycles per strip: wave 0 %.0f, wave 3 %.0f" % (t[13].sum() / max(t[4].sum(), 1), t[14].sum() / max(t[15].sum(), 1)))
 
 # timeline: how many workgroups are in flight over the kernel's duration, and when each XCD runs out of work
 t0, t1, xcd = t[6], t[7], t[8].astype(int)
