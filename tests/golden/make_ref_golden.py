@@ -81,6 +81,30 @@ def pipeline_cases():
     yield "soup", synth.random_soup(60, seed=9, textures=synth.procedural_textures(8, 2)), 32, dict(indexed=False)
 
 
+def authored_cases():
+    """(name, scene, flags, trs): .glb files written by the REFERENCE's tiny_gltf + stb_image_write (refhost.write_glb_by_tinygltf),
+    not by this repository's gltf_io: the loader then reads assets it did not generate (PNG streams of another encoder, tiny_gltf's
+    own JSON layout, its buffer packing)."""
+    q = np.array([0.2, -0.4, 0.1, 0.88])
+    q /= np.linalg.norm(q)
+    grid = synth.sphere_grid(2, n=2, tex_size=16)
+    grid.meshes[2].textures.pop("metallicRoughnessTexture", None)
+    grid.meshes[5].textures.clear()
+    grid.meshes[6].base_color = (0.9, 0.3, 0.5, 0.7)
+    trs = [((0.5, -1, 2), tuple(q), (1.5, 0.75, 2)), ((0, 0, 0), (0, 0, 0, 1), (1, -1, 1))] + [((k * 0.25, 0, -k), (0, 0, 0, 1), (1, 1, 1)) for k in range(6)]
+    yield "authored_grid_trs", grid, 8, trs
+    yield "authored_interleaved_u16", synth.cube_sphere(3, tex_size=32), 1 | 2, None
+    yield "authored_nonindexed", synth.random_soup(40, seed=5, textures=synth.procedural_textures(8, 4)), 4, None
+
+
+def write_authored(tmp):
+    for name, scene, flags, trs in authored_cases():
+        glb = os.path.join(OUT, name + ".glb")
+        refhost.write_glb_by_tinygltf(scene, glb, tmp, flags=flags, trs=trs)
+        refhost.load_scene(glb, tmp)
+        shutil.copy(os.path.join(tmp, "ref_scene.bin"), os.path.join(OUT, name + ".scene.bin"))
+
+
 def sample_records():
     scene = synth.random_soup(24, seed=11, textures=synth.procedural_textures(16, 2))
     scene.meshes[0].base_color = (1.0, 0.9, 0.8, 1.0)
@@ -96,9 +120,13 @@ def sample_records():
 
 def main():
     assert refhost.available(), "build oracle/_ref first: make -C oracle ref"
+    tmp = tempfile.mkdtemp()
+    if "--only-authored" in sys.argv:        # (adds the tiny_gltf-authored assets without touching the other fixtures)
+        write_authored(tmp)
+        return
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(OUT)
-    tmp = tempfile.mkdtemp()
+    write_authored(tmp)
     for name, scene, kw in scene_cases():
         glb = os.path.join(OUT, name + ".glb")
         gltf_io.write_glb(scene, glb, **kw)

@@ -58,6 +58,38 @@ def load_scene(glb_path: str, tmp_dir: str):
         return parse_scene_dump(f.read())
 
 
+def write_glb_by_tinygltf(scene, glb_path: str, tmp_dir: str, flags: int = 0, trs=None) -> None:
+    """A .glb of `scene` (mesh2splat_amd.scene.Scene) AUTHORED BY THE REFERENCE'S OWN tiny_gltf + stb_image_write
+    (ref_host_check glbwrite): a writer that shares no code with mesh2splat_amd.gltf_io.  The vertex stream is indexed
+    trivially (0 .. n-1) unless flags & 4.  flags: 1 = 16-bit indices, 2 = one interleaved view with byteStride,
+    4 = no indices, 8 = half of every node's translation on a parent node.  trs: per mesh (translation, rotation xyzw, scale)."""
+    spec = os.path.join(tmp_dir, "glb_spec.bin")
+    with open(spec, "wb") as f:
+        f.write(struct.pack("<II", int(flags), scene.n_meshes))
+        for k, m in enumerate(scene.meshes):
+            v = np.ascontiguousarray(m.vertices, np.float32).reshape(-1, m.stride)
+            n = v.shape[0]
+            name = m.name.encode()
+            f.write(struct.pack("<I", len(name)) + name + struct.pack("<I", n))
+            f.write(np.ascontiguousarray(v[:, 0:3]).tobytes()); f.write(np.ascontiguousarray(v[:, 3:6]).tobytes())
+            f.write(np.ascontiguousarray(v[:, 6:10]).tobytes()); f.write(np.ascontiguousarray(v[:, 10:12]).tobytes())
+            idx = np.arange(n, dtype=np.uint32)
+            f.write(struct.pack("<I", n) + idx.tobytes())
+            f.write(np.asarray(m.base_color, np.float32).tobytes())
+            t, r, sc = (trs[k] if trs else ((0, 0, 0), (0, 0, 0, 1), (1, 1, 1)))
+            f.write(np.asarray(t, np.float32).tobytes() + np.asarray(r, np.float32).tobytes() + np.asarray(sc, np.float32).tobytes())
+            for key in TEX_KEYS:
+                img = m.textures.get(key)
+                if img is None:
+                    f.write(struct.pack("<II", 0, 0))
+                else:
+                    img = np.ascontiguousarray(img, np.uint8)
+                    f.write(struct.pack("<II", img.shape[1], img.shape[0]) + img.tobytes())
+    r = subprocess.run([BIN, "glbwrite", spec, glb_path], capture_output=True, text=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference-side .glb writer failed rc={r.returncode}: {r.stderr[-400:]}")
+
+
 def write_ply(records: np.ndarray, ply_path: str, fmt: int, scale_multiplier, tmp_dir: str) -> None:
     rb = os.path.join(tmp_dir, "ref_records.bin")
     np.ascontiguousarray(records, np.float32).tofile(rb)
