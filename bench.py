@@ -496,10 +496,11 @@ def c5_workload(torch, local_rank, steps=8):
     gen_s = time.perf_counter() - t0
     T = scene.n_triangles
     conv = Converter(local_rank)
+    conv.set_max_gaussians(0)          # (before the upload: it prepares the record pool for the conversion below)
+    conv.set_resolution_hint(2048)
     t0 = time.perf_counter()
     conv.upload_scene(scene)
     up_s = time.perf_counter() - t0
-    conv.set_max_gaussians(0)
     conv.set_profiling(True)
     total = conv.convert(2048)
     conv.convert(2048)
@@ -515,6 +516,31 @@ def c5_workload(torch, local_rank, steps=8):
            "pipeline": conv.last_pipeline, "kernels_total_ms": kms, "submission": "one blocking call per step",
            "host_generation_s": gen_s, "upload_s": up_s,
            "roofline_whole_conversion": whole_conversion_roofline(conv.num_stored, T, kms, traffic_key="c5")}
+    # BASELINE config 5's "final radix sort of the merged splat buffer" (RadixSortPass semantics, m2s_sort_by_depth) on these records.
+    # Algorithmic bytes per record: 16 (position read for the key) + 4 x (8 + 8) (four 8-bit passes over key + value, read and
+    # write) + 2 x 96 (gather: read + write) = 272.  first: the sort right after the conversion (keys from the records themselves,
+    # positions left behind as a plane); repeat: what every later frame pays (keys from the plane).
+    try:
+        view = np.eye(4, dtype=np.float32)
+        view[2, 3] = -6.0
+        n = conv.sort_by_depth(view, download=False)          # (allocations, first touch of the buffers)
+        conv.convert(2048)                                    # new records at the same address: the position plane is stale
+        conv.sort_by_depth(view, download=False)
+        first = {"ms": conv.last_sort_ms, **conv.last_sort_stage_ms}
+        rep, stages = [], []
+        for k in range(5):
+            view[2, 3] = -6.0 - 0.25 * (k + 1)
+            conv.sort_by_depth(view, download=False)
+            rep.append(conv.last_sort_ms)
+            stages.append(conv.last_sort_stage_ms)
+        b = 272.0 * n
+        med = float(np.median(rep))
+        res["depth_sort"] = {"records": int(n), "first_after_a_conversion_ms": first, "repeat_ms": med,
+                             "repeat_stages_ms": {k: float(np.median([s_[k] for s_ in stages])) for k in stages[0]},
+                             "algorithmic_bytes": b, "GBps": b / (med * 1e-3) / 1e9, "frac_of_hbm_peak": b / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "sort_core": "rocPRIM radix_sort_pairs (library); key and gather kernels are this repository's"}
+    except Exception as e:  # noqa: BLE001
+        res["depth_sort"] = {"error": str(e)}
     conv.close()
     return res
 

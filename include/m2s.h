@@ -252,6 +252,10 @@ uint32_t m2s_last_resolution(const m2s_ctx* ctx);            /* R of the current
 m2s_status m2s_download_sorted(m2s_ctx* ctx, m2s_gaussian* dst, uint64_t capacity_records);
 /* Duration (ms) of the last profiled sort (key build + radix sort + gather). */
 float m2s_last_sort_ms(const m2s_ctx* ctx);
+/* The three stages of the last m2s_sort_by_depth, ms (m2s_set_profiling on): [0] keys, [1] radix sort, [2] gather of the 96-byte
+ * records.  The first sort after the records changed reads the positions out of the records (every line of the buffer) and leaves
+ * them behind as a compact plane; later sorts of the same records — the reference sorts every frame — build their keys from that. */
+m2s_status m2s_last_sort_stage_ms(const m2s_ctx* ctx, float out_ms[3]);
 
 /* ---- records from elsewhere == Renderer::updateGaussianBuffer after SceneManager::loadPly --------------- */
 /* Makes `n` host records (e.g. the output of m2s_read_ply) the context's current records, as the reference does with a

@@ -34,7 +34,7 @@ EXPORTS = (
     "m2s_dist_shard_ranges", "m2s_dist_all_gather_counts", "m2s_dist_publish_count", "m2s_dist_collect_counts",
     "m2s_dist_clamp_to_cap", "m2s_dist_gather_records", "m2s_dist_wait", "m2s_set_records", "m2s_reserve_records", "m2s_prepare",
     "m2s_dist_local_id", "m2s_dist_sort_by_depth", "m2s_device_sorted_keys", "m2s_num_sorted", "m2s_last_resolution",
-    "m2s_set_resolution_hint", "m2s_last_warm_ms", "m2s_dist_transport",
+    "m2s_set_resolution_hint", "m2s_last_warm_ms", "m2s_dist_transport", "m2s_last_sort_stage_ms",
 )
 
 
@@ -176,6 +176,7 @@ def load():
         "m2s_set_resolution_hint": (C.c_int, [vp, u32]),
         "m2s_last_warm_ms": (C.c_float, [vp]),
         "m2s_dist_transport": (C.c_char_p, [vp]),
+        "m2s_last_sort_stage_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

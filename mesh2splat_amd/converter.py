@@ -201,6 +201,13 @@ class Converter:
     def last_sort_ms(self) -> float:
         return float(self._L.m2s_last_sort_ms(self._h))
 
+    @property
+    def last_sort_stage_ms(self) -> dict:
+        """keys | radix sort | gather of the last sort_by_depth (profiling on)."""
+        ms = (C.c_float * 3)()
+        self._check(self._L.m2s_last_sort_stage_ms(self._h, ms))
+        return {"keys": float(ms[0]), "radix_sort": float(ms[1]), "gather": float(ms[2])}
+
     def upload_records(self, records: np.ndarray):
         """Renderer::updateGaussianBuffer after LoadPly: (n, 24) float32 host records become the context's current records."""
         r = np.ascontiguousarray(records, np.float32).reshape(-1, RECORD_FLOATS)

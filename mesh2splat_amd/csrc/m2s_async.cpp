@@ -186,6 +186,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     if (sl.sync_result) {   // run_pass already filled last_*
         if (out_total) *out_total = sl.sync_total;
         c->last_total = sl.sync_total; c->last_stored = sl.limit; c->last_records = sl.d_out; c->last_R = sl.R;
+        ++c->records_epoch;
         c->records_stale = stale;
         memcpy(c->last_ms, sl.ms, sizeof sl.ms);
         return M2S_OK;
@@ -210,6 +211,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);
     c->last_records = sl.d_out;
+    ++c->records_epoch;
     c->last_R = sl.R;
     c->records_stale = stale;
     if (out_total) *out_total = total;

@@ -178,6 +178,7 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_pp_chain) (void)hipFree(c->d_pp_chain);
     if (c->d_pp_depthtex) (void)hipFree(c->d_pp_depthtex);
     if (c->d_sort_u32) (void)hipFree(c->d_sort_u32);
+    if (c->d_pos_plane) (void)hipFree(c->d_pos_plane);
     if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);

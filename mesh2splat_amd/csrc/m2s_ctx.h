@@ -122,6 +122,13 @@ struct m2s_ctx {
     size_t sort_temp_cap = 0;
     uint64_t sort_u32_cap = 0;
     float last_sort_ms = 0.0f;
+    float last_sort_stage_ms[3] = { 0, 0, 0 };   // keys | radix sort | gather of the last m2s_sort_by_depth (profiling on)
+    // the positions of the current records as a compact plane (16 B each), left behind by the first depth sort after the records
+    // changed and used for the keys of every later one (m2s_sort.hip); valid for (pos_plane_of, pos_plane_n, pos_plane_epoch)
+    void* d_pos_plane = nullptr;
+    uint64_t pos_plane_cap = 0, pos_plane_n = 0, pos_plane_epoch = 0;
+    const void* pos_plane_of = nullptr;
+    uint64_t records_epoch = 1;       // advances whenever the records behind last_records may have changed
     // viewer prepass (m2s_prepass): survivors, their depths, the look-back chain of its kernel, a copy of the depth image
     void* d_quads = nullptr;
     float* d_pp_depths = nullptr;

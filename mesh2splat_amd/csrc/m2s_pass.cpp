@@ -296,6 +296,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             if (s != M2S_OK) return s;
         }
         c->last_records = d_user ? d_user : c->d_records;
+        ++c->records_epoch;
         if (out_total) *out_total = 0;
         return M2S_OK;
     }
@@ -428,6 +429,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     c->last_total = total;
     c->last_stored = std::min(total, limit);
     c->last_records = d_out;
+    ++c->records_epoch;
     if (!d_user) { if (c->buf_R[0] != R) { c->buf_R[0] = R; ++c->buf_gen[0]; } }
     if (out_total) *out_total = total;
     return M2S_OK;

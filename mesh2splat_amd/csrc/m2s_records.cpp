@@ -127,6 +127,7 @@ m2s_status m2s_upload_records(m2s_ctx* c, const m2s_gaussian* records, uint64_t 
     }
     if (n) HIPCHK(c, hipMemcpy(c->d_loaded, records, n * sizeof(m2s_gaussian), hipMemcpyHostToDevice));
     c->last_records = c->d_loaded;
+    ++c->records_epoch;
     c->last_total = c->last_stored = n;
     c->records_stale = false;
     c->last_R = 0;      // uploaded records carry no resolutionTarget: m2s_export_ply (scale multiplier = std / R) refuses them
@@ -142,6 +143,7 @@ m2s_status m2s_set_records(m2s_ctx* c, const void* d_records, uint64_t n, uint32
     if (!c || (!d_records && n)) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     c->last_records = d_records;
+    ++c->records_epoch;
     c->last_total = c->last_stored = n;
     c->last_R = R;
     c->records_stale = false;

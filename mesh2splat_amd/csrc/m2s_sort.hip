@@ -15,14 +15,28 @@
 
 namespace m2s {
 
+// Key = raw bits of view-space z = row 2 of worldToView * (P, 1), pinned association.  The positions sit at a 96-byte stride
+// inside the records: reading them touches EVERY 128-byte line of the record buffer (2.3 GB for BASELINE config 5's 24.3 M
+// records, to use 16 bytes of each 96).  The reference sorts every frame (RadixSortPass runs per frame while the camera moves), so
+// the first sort after the records have changed also leaves the positions behind as a compact plane (16 B per record) and every
+// later sort of the same records builds its keys from that: 389 MB instead of 2.3 GB.
+__device__ __forceinline__ uint32_t depth_key(float4 p, float v02, float v12, float v22, float v32) {
+    const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;
+    return __float_as_uint(z);
+}
 __global__ void __launch_bounds__(kBlock) k_depth_keys(const float4* __restrict__ rec, uint32_t n, float v02, float v12,
-                                                       float v22, float v32, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                       float v22, float v32, uint32_t* __restrict__ key, float4* __restrict__ plane) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 p = rec[(size_t)i * 6];  // position (xyz, 1)
-    const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;   // row 2 of worldToView * (P,1), pinned order
-    key[i] = __float_as_uint(z);
-    val[i] = i;
+    key[i] = depth_key(p, v02, v12, v22, v32);
+    if (plane) plane[i] = p;
+}
+__global__ void __launch_bounds__(kBlock) k_depth_keys_from_plane(const float4* __restrict__ plane, uint32_t n, float v02, float v12,
+                                                                  float v22, float v32, uint32_t* __restrict__ key) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    key[i] = depth_key(plane[i], v02, v12, v22, v32);
 }
 
 // one thread per float4: consecutive lanes write consecutive 16 B of the sorted buffer (fully coalesced
@@ -37,20 +51,28 @@ __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restr
 
 size_t sort_temp_bytes(uint32_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32,
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 32,
                                     (hipStream_t)0);
     return bytes;
 }
 
-hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
-                         uint32_t* vals_out, void* temp, size_t temp_bytes, float4* sorted, hipStream_t st) {
+// plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  stage_ev (or nullptr): four
+// events recorded around the three stages (keys | radix sort | gather).  The values are the record indices: they come from a
+// counting iterator, not from memory.
+hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out,
+                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_depth_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in,
-                       vals_in);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 32, st);
+    const dim3 grid((n + kBlock - 1) / kBlock);
+    if (stage_ev) (void)hipEventRecord(stage_ev[0], st);
+    if (plane && plane_valid) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in);
+    else hipLaunchKernelGGL(k_depth_keys, grid, dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in, plane);
+    if (stage_ev) (void)hipEventRecord(stage_ev[1], st);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
     if (e != hipSuccess) return e;
+    if (stage_ev) (void)hipEventRecord(stage_ev[2], st);
     const size_t nq = (size_t)n * 6;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
+    if (stage_ev) (void)hipEventRecord(stage_ev[3], st);
     return hipGetLastError();
 }
 

@@ -110,6 +110,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->scene.tri_first = (uint32_t)first;
     c->last_total = c->last_stored = 0;
     c->last_records = nullptr;
+    ++c->records_epoch;
     c->records_stale = false;
 
     // ---- layout: geometry planes (144 B / triangle) in one allocation, everything else in a second one -------------

@@ -45,13 +45,22 @@ m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t
         HIPCHK(c, hipMalloc(&c->d_sort_temp, std::max<size_t>(tb, 256)));
         c->sort_temp_cap = tb;
     }
-    uint32_t* u = c->d_sort_u32;
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, sort_by_depth((const float4*)c->last_records, (uint32_t)n, world_to_view, u, u + n, u + 2 * n, u + 3 * n, c->d_sort_temp,
-                            c->sort_temp_cap, (float4*)c->d_sorted, c->stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->pos_plane_cap < n) {
+        if (c->d_pos_plane) { (void)hipFree(c->d_pos_plane); c->d_pos_plane = nullptr; c->pos_plane_cap = 0; }
+        c->pos_plane_n = 0;
+        if (hipMalloc(&c->d_pos_plane, n * 16) == hipSuccess) c->pos_plane_cap = n;   // (without it every sort reads the records: slower, not wrong)
+        else (void)hipGetLastError();
+    }
+    const bool plane_valid = c->d_pos_plane && c->pos_plane_of == c->last_records && c->pos_plane_n == n && c->pos_plane_epoch == c->records_epoch;
+    uint32_t* u = c->d_sort_u32;     // keys_in | (unused) | keys_out | vals_out
+    HIPCHK(c, sort_by_depth((const float4*)c->last_records, (uint32_t)n, world_to_view, u, u + 2 * n, u + 3 * n, c->d_sort_temp,
+                            c->sort_temp_cap, (float4*)c->d_sorted, (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_sort_ms, c->ev[0], c->ev[1]));
+    if (c->d_pos_plane) { c->pos_plane_of = c->last_records; c->pos_plane_n = n; c->pos_plane_epoch = c->records_epoch; }
+    if (c->profiling) {
+        for (int k = 0; k < 3; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_sort_stage_ms[k], c->ev[k], c->ev[k + 1]));
+        HIPCHK(c, hipEventElapsedTime(&c->last_sort_ms, c->ev[0], c->ev[3]));
+    }
     c->sorted_n = n;
     return M2S_OK;
 }
@@ -73,6 +82,11 @@ m2s_status m2s_download_sorted(m2s_ctx* c, m2s_gaussian* dst, uint64_t capacity_
 }
 
 float m2s_last_sort_ms(const m2s_ctx* c) { return c ? c->last_sort_ms : 0.0f; }
+m2s_status m2s_last_sort_stage_ms(const m2s_ctx* c, float out_ms[3]) {
+    if (!c || !out_ms) return M2S_ERR_INVALID;
+    memcpy(out_ms, c->last_sort_stage_ms, sizeof c->last_sort_stage_ms);
+    return M2S_OK;
+}
 
 // GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) + the counter read-back that follows it (RadixSortPass.cpp:18-22).
 m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {

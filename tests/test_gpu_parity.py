@@ -176,6 +176,38 @@ def test_depth_sort_matches_stable_argsort(hiplib, oracle):
     c.close()
 
 
+def test_depth_sort_position_plane_follows_the_records(hiplib, oracle):
+    """The first sort after the records changed reads the positions out of the records and leaves them behind as a compact plane;
+    later sorts (another camera every frame) take their keys from it.  The plane must be dropped whenever the records may have
+    changed: another conversion into the same buffer (another density: other records at the same address), uploaded records,
+    adopted records."""
+    f = np.float32
+
+    def want(rec, view):
+        z = (f(view[2, 0]) * rec[:, 0] + f(view[2, 1]) * rec[:, 1]) + f(view[2, 2]) * rec[:, 2]
+        z = (z + f(view[2, 3])).astype(np.float32)
+        return rec[np.argsort(z.view(np.uint32), kind="stable")]
+
+    def views():
+        for k, ang in enumerate((0.3, 1.1, 2.0)):
+            yield np.array([[np.cos(ang), 0, np.sin(ang), 0.1 * k], [0, 1, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), -4.0 - k], [0, 0, 0, 1]], np.float32)
+
+    scene = synth.sphere_grid(2, n=5, tex_size=16)
+    c = Converter(0)
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    for R in (150, 150, 90, 151):            # same density twice (same records), then fewer records, then about as many again
+        c.convert(R)
+        rec = c.download()
+        for view in views():                 # first view: from the records; the others: from the plane
+            assert np.array_equal(c.sort_by_depth(view).view(np.uint32), want(rec, view).view(np.uint32)), R
+    loaded = np.ascontiguousarray(rec[::-1][:4000])
+    c.upload_records(loaded)                 # other records, possibly at an address seen before
+    for view in views():
+        assert np.array_equal(c.sort_by_depth(view).view(np.uint32), want(loaded, view).view(np.uint32))
+    c.close()
+
+
 @pytest.mark.parametrize("R,tri_size,n", [(1024, 0.08, 3000), (2048, 0.05, 2500), (512, 0.5, 600), (4096, 0.02, 2000)])
 def test_row_walker_counts_mid_size_triangles(conv, oracle, R, tri_size, n):
     """Triangles of 10..300 pixel rows: the division-free row walker (sequential loops), the closed-form spans

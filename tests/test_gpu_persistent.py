@@ -21,7 +21,7 @@ kind, out = sys.argv[1], sys.argv[2]
 if kind == "sphere":
     scene, R = synth.cube_sphere(160, tex_size=256), 700      # 307 200 triangles = 1 200 units: more than one generation
 else:
-    scene, R = synth.sphere_grid(2, n=60, tex_size=64), 900    # 8 meshes, cumulative bounding boxes, units that straddle meshes
+    scene, R = synth.sphere_grid(2, n=60, tex_size=64), 300    # 8 meshes (345 600 triangles), cumulative bounding boxes, units that straddle meshes
 c = Converter(0)
 c.set_pipeline("team")
 c.set_max_gaussians(0)
@@ -51,5 +51,5 @@ def test_persistent_form_is_bit_identical(hiplib, tmp_path, kind):
         outs[name] = np.load(out)
     for k in outs["plain"].files:
         a, b = outs["plain"][k], outs["persistent"][k]
-        assert a.shape == b.shape and a.shape[0] > 100_000
+        assert a.shape == b.shape and a.shape[0] > 50_000
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{kind} {k}: persistent and plain forms differ"
