@@ -159,7 +159,6 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
-    if ((team || sparse) && sl.wrote_bands) pick_bands(c, ri, sl.bands_unit, &res[0], st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));
     if (!second_lane) c->last_submit_stream = st;
@@ -206,7 +205,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
         (void)hipStreamSynchronize(c->stream);
         return fail(c, M2S_ERR_STATE, "asynchronous conversion needed a host decision; convert synchronously");
     }
-    if (sl.wrote_bands && rip) { rip->bands_ready = true; rip->bands_unit = sl.bands_unit; rip->band_width = band_width_of(c, *rip, sl.bands_unit); }   // that launch has completed: its band table is in place
+    if (sl.wrote_bands && rip) { rip->bands_ready = true; rip->bands_unit = sl.bands_unit; }   // that launch has completed: its run table is in place
     if (total > 0xFFFFFFFFull) return fail(c, M2S_ERR_CAPACITY, "more than 2^32-1 fragments: offsets are 32-bit");
     c->last_total = total;
     c->last_stored = std::min(total, sl.limit);

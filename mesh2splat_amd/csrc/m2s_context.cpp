@@ -30,7 +30,7 @@ void free_scene(m2s_ctx* c) {
     // everything below lived inside the arena
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
-    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->d_wg_base = nullptr;
+    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->run_table_words = 0;
     c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0; c->d_tickets = nullptr;
     c->rinfo.clear();
     ++c->rinfo_gen;
@@ -48,7 +48,8 @@ m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     if (it != c->rinfo.end()) return it->second;
     // (a full table starts over; submissions still in flight remember the generation they were made under, so that a band
     //  slot which now belongs to another density is never marked ready on their behalf: m2s_convert_wait)
-    if (c->rinfo.size() >= (size_t)kBandSlots) { c->rinfo.clear(); ++c->rinfo_gen; }
+    // (the slots' run tables are about to be re-used by other densities: nothing in flight may still be reading one)
+    if (c->rinfo.size() >= (size_t)kBandSlots) { drain_in_flight(c); c->rinfo.clear(); ++c->rinfo_gen; }
     m2s_ctx::RInfo ri;
     ri.gen = c->rinfo_gen;
     ri.band_slot = (int)c->rinfo.size();
@@ -133,9 +134,6 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->h_total, (4 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->h_bands, (size_t)kBandSlotsMax * 9 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
-        return bail("hipHostMalloc", e);
-    memset(c->h_bands, 0, (size_t)kBandSlotsMax * 9 * sizeof(unsigned long long));
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto& ev : c->stage_ev)
@@ -182,7 +180,6 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_sort_temp) (void)hipFree(c->d_sort_temp);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->h_total) (void)hipHostFree(c->h_total);
-    if (c->h_bands) (void)hipHostFree(c->h_bands);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : c->slot) {
         if (sl.done) (void)hipEventDestroy(sl.done);

@@ -57,9 +57,8 @@ struct m2s_ctx {
         bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
-        bool bands_ready = false;  // d_bands[band_slot] holds the XCD band table (cuts + bases) for this R ...
-        uint32_t bands_unit = 0;   // ... in workgroups of this many triangles (256: cut from a k_fused2 launch, 512: k_sparse)
-        uint32_t band_width = 0;   // ... whose widest band has this many workgroups (the grid of a banded launch is 8 x this)
+        bool bands_ready = false;  // the run table of this R (slot band_slot of d_bands: where every run's output starts) is in place ...
+        uint32_t bands_unit = 0;   // ... in units of this many triangles (256: recorded by a k_fused2 launch, 512: k_sparse)
         int band_slot = 0;
         uint32_t gen = 0;          // generation of the table this entry belongs to (the table starts over when it is full)
     };
@@ -71,9 +70,8 @@ struct m2s_ctx {
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene: from the exact count m2s_upload_scene takes (warm_scene), refreshed by every conversion
     uint32_t hint_R = 0;                    // m2s_set_resolution_hint: the R the next upload prepares for (0: the last R converted at, else 1024)
     uint32_t warm_R = 0;                    // the R the resident scene was prepared for
-    unsigned long long* d_bands = nullptr;  // kBandSlots x kBandTableWords: XCD band tables (device)
-    unsigned long long* h_bands = nullptr;  // kBandSlots x 9 (pinned): the cuts of each table, written by k_pick_bands itself
-    unsigned long long* d_wg_base = nullptr;   // where every workgroup's output started in the newest launch without bands
+    unsigned long long* d_bands = nullptr;  // kBandSlots run tables of run_table_words words each (RunInfo, m2s_device.h)
+    size_t run_table_words = 0;
     uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
@@ -188,9 +186,7 @@ m2s_status ensure_stage(m2s_ctx* c);
 // m2s_pass.cpp
 bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
-m2s::BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
-void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st);
-uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit);
+m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
 m2s::BatchTable batches_for(const m2s_ctx* c);
 m2s::TicketSets tickets_for(m2s_ctx* c, int lane);   // the ticket sets of the next launch on that lane's chain (advances the turn)
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);

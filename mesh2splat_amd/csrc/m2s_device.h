@@ -94,8 +94,9 @@ void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m,
                         hipStream_t st);
 void launch_count(const SceneDev& sc, uint32_t R, uint32_t* cnt, uint32_t* partials, hipStream_t st);
 void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long long* total, hipStream_t st);
-// where the output of every run of `unit` (256 / 512) triangles starts, from launch_count's counts and the scanned partials
-void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, unsigned long long* wg_base, hipStream_t st);
+// where the output of every RUN (1 << shift units of `unit` = 256 / 512 triangles) starts, from launch_count's counts and the
+// scanned partial sums: the table a launch in runs reads (RunInfo::base)
+void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, uint32_t shift, unsigned long long* run_base, hipStream_t st);
 void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
                     uint32_t n_start, hipStream_t st);
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
@@ -113,36 +114,36 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
 // device-side .ply row encoder, formats 1 and 2 (m2s_export.hip)
 void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float scale_multiplier, uint8_t* out, hipStream_t st);
 
-// XCD bands of k_fused2 / k_sparse (see m2s_fused2.hip): max_width == 0 switches banding off.  XCD x converts the x-th of
-// eight runs of consecutive workgroups.  The band table lives in DEVICE memory: a launch without bands records where every
-// workgroup's output starts (`out`), k_pick_bands cuts eight runs of equal estimated work from that right behind it, and the
-// next launches of the same scene at the same R read the table — no counting kernel, no host round trip.  (Until round 3 the
-// bands were eight runs of equal LENGTH: on config 3 the busiest XCD then had 11 % more work than the average.)
-// words of a band table (device memory, unsigned long long each)
-constexpr uint32_t kBandBase = 0;    // [x], x < 8: record index at which band x's output starts
-constexpr uint32_t kBandWg = 8;      // [x], x <= 8: first workgroup (= chain word / 4) of band x; x = 8: one past the last
-constexpr int kBandTableWords = 24;   // (17 used)
-struct BandInfo {
-    const unsigned long long* table;  // banded launch (max_width != 0): the table above
-    uint32_t max_width;               // banded launch: the widest band's workgroups (the grid is 8 x max_width); 0: no bands
-    unsigned long long* out;          // launch WITHOUT bands, or nullptr: out[workgroup] = record index at which its output starts
+// XCD runs of k_fused2 / k_sparse.  Hardware workgroup h runs on XCD h % 8 and every XCD has a private L2: consecutive units
+// (workgroups' worth of triangles: neighbours on the mesh, neighbouring texels) should meet in ONE L2.  A launch "in runs" gives
+// XCD x the runs x, x + 8, x + 16, ... of `1 << shift` consecutive units each; the look-back chain restarts at every run, whose
+// first unit reads where the run's output starts from a table (`base`) — so a unit still only waits for units dispatched before
+// it (its own run's), whatever the other XCDs are doing.  The table is a by-product: a launch WITHOUT runs (plain order, one
+// chain) stores where every run's output starts (`out`), and so does the exact count m2s_upload_scene takes (k_unit_bases); the
+// next launches of the scene at that R read it.  No counting pass, no host round trip, no picker kernel.
+// (Rounds 1-3 cut the unit list into EIGHT contiguous bands of equal estimated work, one per XCD.  A launch then lasted as long as
+// its slowest band — the linear work model left the XCDs' finishing times 4-9 % apart — and as wide as its widest; the cuts had to
+// travel to the host.  With ~30 runs per XCD the work evens out statistically and every XCD gets work until the end.)
+struct RunInfo {
+    const unsigned long long* base;  // launch in runs: base[j] = record index at which the output of run j starts; else nullptr
+    unsigned long long* out;         // launch without runs: out[j] = the same, recorded for the next launches (or nullptr)
+    uint32_t shift;                  // log2 of the run length in units
 };
-// The bands of the NEXT launches at this R, from what a launch without bands left in `wg_base`: eight runs of consecutive
-// workgroups of equal estimated WORK (not equal length — fragment density varies along the triangle list, and a launch lasts
-// as long as its slowest XCD).  tri_per_wg: 256 (k_fused2) or 512 (k_sparse);
-// *total = the fragment count of that launch.
-void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table,
-                       unsigned long long* host_cuts /* [9], pinned: the cuts, for the host */, hipStream_t st);
-// widest band the picker may cut (a bound on the grid of a banded launch: 8 x the widest band ACTUALLY cut, which the host learns)
-inline uint32_t band_max_width(uint32_t n_wg) { return (n_wg + 7u) / 8u * 4u + 1u; }
+// run length for a scene of n_units units (0: too few units for runs to make sense — plain order)
+inline uint32_t run_shift_for(uint32_t n_units) {
+    uint32_t shift = 4;                                   // 16 units = 4096 triangles of k_fused2
+    if (const char* v = debug_env("M2S_RUN_SHIFT")) shift = (uint32_t)std::atoi(v) & 15u;     // debug: A/B of the run length
+    return n_units >= (32u << shift) ? shift : 0u;        // at least four runs per XCD
+}
+inline uint32_t n_runs(uint32_t n_units, uint32_t shift) { return (n_units + (1u << shift) - 1u) >> shift; }
 // Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
 // = triangles [first[b], first[b + 1]), at most 64, starts at multiples of 8.  first == nullptr: uniform batches of fused_tpw.
 struct BatchTable {
     const uint32_t* first;   // device, n + 1 entries
     uint32_t n;
 };
-// workgroups of k_fused2 for a scene of n_tri triangles that can be converted in bands (0: too small for 64-triangle batches)
+// units (workgroups of 256 triangles) of k_fused2 for a scene of n_tri triangles that can be converted in runs (0: too small for
+// 64-triangle batches)
 uint32_t fused2_band_workgroups(uint32_t n_tri);
 // Ticket counters of the persistent form of the single-pass kernels (k_fused2p, see m2s_fused2.hip): eight counters per set, one
 // 128-byte line each.  A launch draws from `use` (all zero when it starts) and zeroes `clear`, the set the NEXT launch on the same
@@ -152,11 +153,11 @@ constexpr size_t kTicketSetBytes = 8 * kTicketStride * sizeof(uint32_t);
 struct TicketSets { uint32_t* use; uint32_t* clear; };
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, const BatchTable& batches, const TicketSets& tickets, hipStream_t st);
-// sparse form of the single-pass kernel (m2s_sparse.hip); `bands` as for launch_fused2 (k_fused2's band width: rescaled inside)
+                   const RunInfo& runs, const BatchTable& batches, const TicketSets& tickets, hipStream_t st);
+// sparse form of the single-pass kernel (m2s_sparse.hip); `runs` as for launch_fused2, in ITS units (512 triangles)
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, hipStream_t st);
+                   const RunInfo& runs, hipStream_t st);
 bool sparse_supported(uint32_t n_tri);
 uint32_t sparse_workgroups(uint32_t n_tri);   // workgroups of kSpCand = 512 triangles
 constexpr uint32_t kSparseTrianglesPerWorkgroup = 512;

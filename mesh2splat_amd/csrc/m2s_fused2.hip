@@ -42,10 +42,6 @@ constexpr uint32_t kEntries = (uint32_t)M2S_FUSED2_ENTRIES * kTeam;   // entry s
 constexpr int kStageRec = M2S_FUSED2_STAGE;
 constexpr uint32_t kInvalidEntry = 0xFFFFFFFFu;
 constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
-#ifndef M2S_XCD_RUN2
-#define M2S_XCD_RUN2 1
-#endif
-constexpr uint32_t kXcdRun2 = M2S_XCD_RUN2;
 
 #ifdef M2S_TIMING
 // debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
@@ -131,25 +127,28 @@ __device__ __forceinline__ bool f2_get_base(F2Ctl& S, const unsigned long long* 
 
 // ---- persistent form: tickets ------------------------------------------------------------------------------------------
 // k_fused2p keeps (at most) as many workgroups as the GPU holds at once and lets each of them convert unit after unit.  A unit
-// (= what one workgroup of k_fused2 converts: kTeam batches) is handed out by a TICKET (TicketSets, m2s_device.h): eight queues, one per XCD —
-//   banded launch:    queue x = band x of the table (consecutive units first .. first + n, base of the first one known);
-//   launch w/o bands: queue x = units x, x + 8, x + 16, ... (what the hardware's round-robin dispatch gives k_fused2);
-// a workgroup draws from the queue of its own XCD while that has units, then from the queue with the most units left.  Tickets of
-// one queue are drawn in order by workgroups that are RUNNING, so the look-back chain's one requirement holds without any
-// assumption about dispatch: every unit before mine in my queue has been started and will publish its aggregate.  What the
-// dispatcher's order gave k_fused2 for free it also made rigid: a band could not take work from another, and a launch was as
-// wide as its widest band.
-static_assert(kTicketStride == 32, "one 128-byte line per ticket counter");
-
-struct Unit { uint32_t lb; uint32_t first_of_queue; uint32_t queue; };
-struct Queues {      // the eight queues of a launch (see above), from the band table or from the unit count
-    const BandInfo& bands; uint32_t n_wg; bool banded;
-    __device__ __forceinline__ uint32_t first(uint32_t y) const { return banded ? (uint32_t)bands.table[kBandWg + y] : y; }
-    __device__ __forceinline__ uint32_t count(uint32_t y) const {
-        if (banded) return (uint32_t)bands.table[kBandWg + 1u + y] - (uint32_t)bands.table[kBandWg + y];
-        return y < n_wg ? (n_wg - y + 7u) / 8u : 0u;
+// (= what one workgroup of k_fused2 converts: kTeam batches) is handed out by a TICKET (TicketSets, m2s_device.h): eight queues,
+// one per XCD, holding exactly the units the hardware's round-robin dispatch gives that XCD in k_fused2 — its runs (launch in
+// runs) or every eighth unit (plain order), in the same order; a workgroup draws from the queue of its own XCD while that has
+// units, then from the queue with the most units left.  Tickets of one queue are drawn in order by workgroups that are RUNNING,
+// so the look-back chain's one requirement holds without any assumption about dispatch: every unit before mine in my run has
+// been started and will publish its aggregate.
+struct Unit { uint32_t lb; uint32_t first_of_queue; };
+struct Queues {      // the eight queues of a launch (see above)
+    uint32_t n_wg, shift; bool in_runs;
+    // ticket t of queue y -> unit (may be >= n_wg in the last group of runs: drawn and skipped)
+    __device__ __forceinline__ uint32_t unit_of(uint32_t y, uint32_t t) const {
+        return in_runs ? ((((t >> shift) << 3) + y) << shift) + (t & ((1u << shift) - 1u)) : (t << 3) + y;
     }
-    __device__ __forceinline__ Unit unit(uint32_t y, uint32_t t) const { return Unit{ first(y) + t * (banded ? 1u : 8u), (banded && t == 0u) ? 1u : 0u, y }; }
+    __device__ __forceinline__ uint32_t tickets(uint32_t y) const {      // tickets of queue y that can be valid units
+        const uint32_t per_group = in_runs ? (8u << shift) : 8u;
+        const uint32_t groups = (n_wg + per_group - 1u) / per_group;
+        return in_runs ? (groups << shift) : groups;
+    }
+    __device__ __forceinline__ Unit unit(uint32_t y, uint32_t t) const {
+        const uint32_t lb = unit_of(y, t);
+        return Unit{ lb < n_wg ? lb : kNoUnit, (in_runs && (t & ((1u << shift) - 1u)) == 0u) ? 1u : 0u };
+    }
 };
 // lane 0 of one wave.  Two steps, so that the round trip of the atomic (~1-2 us under load) is not waited for where it is issued:
 // ticket_issue draws from the home queue; ticket_resolve, called later, turns the answer into a unit — or, if the home queue was
@@ -158,24 +157,27 @@ __device__ __forceinline__ uint32_t ticket_issue(const TicketSets& tk, uint32_t 
     return __hip_atomic_fetch_add(&tk.use[home * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ Unit ticket_resolve(const TicketSets& tk, const Queues& q, uint32_t home, uint32_t t) {
-    if (t < q.count(home)) return q.unit(home, t);
-    for (int attempt = 0; attempt < 12; ++attempt) {
-        uint32_t best = 0, y = 8;
-        for (uint32_t z = 0; z < 8u; ++z) {
-            const uint32_t nz = q.count(z);
-            const uint32_t tz = __hip_atomic_load(&tk.use[z * kTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t left = nz > tz ? nz - tz : 0u;
-            if (left > best) { best = left; y = z; }
+    uint32_t y = home;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        if (t < q.tickets(y)) {
+            const Unit u = q.unit(y, t);
+            if (u.lb != kNoUnit) return u;
+        } else {      // that queue is empty: the one with the most tickets left
+            uint32_t best = 0;
+            y = 8;
+            for (uint32_t z = 0; z < 8u; ++z) {
+                const uint32_t nz = q.tickets(z);
+                const uint32_t tz = __hip_atomic_load(&tk.use[z * kTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t left = nz > tz ? nz - tz : 0u;
+                if (left > best) { best = left; y = z; }
+            }
+            if (y == 8u) break;
         }
-        if (y == 8u) break;
-        const uint32_t t2 = __hip_atomic_fetch_add(&tk.use[y * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t2 < q.count(y)) return q.unit(y, t2);
+        t = __hip_atomic_fetch_add(&tk.use[y * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return Unit{ kNoUnit, 0u, 0u };
+    return Unit{ kNoUnit, 0u };
 }
 
-// One kernel body, two launch forms: kPersist = false is k_fused2 (one unit per workgroup, which unit follows from blockIdx),
-// kPersist = true is k_fused2p (units by ticket, a loop).
 // the launch parameters of both forms
 struct F2Args {
     SceneDev sc;
@@ -187,7 +189,7 @@ struct F2Args {
     BigItem* biglist;
     uint32_t* bigmeta;
     uint32_t R, epoch, tpw;    // tpw: triangles per wave, 64, 32 or 16 (fused_tpw)
-    BandInfo bands;
+    RunInfo runs;
     BatchTable bt;
     TicketSets tk;
 };
@@ -206,7 +208,7 @@ template <class T> __device__ __forceinline__ T ld_const(const __attribute__((ad
 // config 3, profiles/r04/ab_persistent_first_version_spills.log).
 template <bool kPersist>
 __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2ArgsConst args_mem) {
-    const BandInfo bands = kPersist ? ld_const(&args_mem->bands) : args_direct.bands;     // (prologue and ticket code: a few scalar loads)
+    const RunInfo runs = kPersist ? ld_const(&args_mem->runs) : args_direct.runs;     // (prologue and ticket code: a few scalar loads)
     const TicketSets tk = kPersist ? ld_const(&args_mem->tk) : args_direct.tk;
     const BatchTable bt = kPersist ? BatchTable{ nullptr, 0u } : args_direct.bt;
     const uint32_t tpw = kPersist ? 64u : args_direct.tpw;
@@ -220,16 +222,14 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     // triangles, starts at multiples of 8): with one generation the kernel lasts as long as its slowest workgroup.
     const uint32_t n_batches = bt.first ? bt.n : (n_tri_all + tpw - 1u) / tpw;
     const uint32_t n_wg = (n_batches + (uint32_t)kTeam - 1u) / (uint32_t)kTeam;
-    // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  With BANDS (a table in device memory, cut by
-    // k_pick_bands from what an earlier launch at this R recorded: where each of eight runs of consecutive workgroups starts
-    // and where its output starts) XCD x converts the x-th run: neighbouring triangles — neighbouring texels — meet in ONE
-    // L2 instead of eight, and the look-back chain restarts at every band (a workgroup still only waits for workgroups
-    // dispatched before it: h - 8, h - 16, ...).  The runs carry equal estimated work, not equal numbers of workgroups.
-    // Without bands: plain round-robin (or runs of kXcdRun2, which the chain does not like: see DESIGN.md).
+    // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  A launch in RUNS (RunInfo, m2s_device.h) gives XCD x
+    // the runs x, x + 8, ... of consecutive units: neighbouring triangles — neighbouring texels — meet in ONE L2 instead of
+    // eight, and the look-back chain restarts at every run, whose base comes from a table.  Without runs: plain order, one chain.
     const uint32_t hb = blockIdx.x, xcd = hb & 7u;
-    const bool banded = bands.max_width != 0u;
+    const bool in_runs = runs.base != nullptr;
+    const uint32_t rmask = (1u << runs.shift) - 1u;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
-    const Queues queues{ bands, n_wg, banded };
+    const Queues queues{ n_wg, runs.shift, in_runs };
 
     if (kPersist) {
         // LDS is not zero on entry: `ready` of both control sets and the draw counter are cleared before anybody looks at them.
@@ -265,12 +265,9 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     if (!kPersist) {
         if (it) return;
         const uint32_t round = hb >> 3;
-        lb = ((round / kXcdRun2) * 8u + xcd) * kXcdRun2 + (round % kXcdRun2);
-        if (banded) {   // (scalar loads: the band's first workgroup and the next band's)
-            lb = (uint32_t)bands.table[kBandWg + xcd] + round;
-            if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
-        }
-        band_first = banded && round == 0;     // this workgroup's base is the band's base: known
+        lb = hb;
+        if (in_runs) lb = ((((round >> runs.shift) << 3) + xcd) << runs.shift) + (round & rmask);
+        band_first = in_runs && (round & rmask) == 0u;     // first unit of its run: its base is the run's, known
         if (lb * (uint32_t)kTeam >= n_batches) return;
         // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
         // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed.
@@ -280,7 +277,7 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         if (wave == 0 && lane == 0) {
             C.claimed = 0; C.irregular = 0; C.error = 0;
             C.base_state = (lb == 0 || band_first) ? 2u : 0u;
-            C.base = band_first ? bands.table[xcd] : 0ull;   // scalar load from device memory
+            C.base = band_first ? runs.base[lb >> runs.shift] : 0ull;   // scalar load from device memory
         }
         __syncthreads();
     } else {
@@ -301,7 +298,7 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
                     C.unit = u.lb; C.first_of_queue = u.first_of_queue;
                     C.claimed = 0; C.irregular = 0; C.error = 0;
                     C.base_state = (u.lb == 0u || u.first_of_queue) ? 2u : 0u;
-                    C.base = u.first_of_queue ? bands.table[kBandBase + u.queue] : 0ull;
+                    C.base = (u.first_of_queue && u.lb != kNoUnit) ? runs.base[u.lb >> runs.shift] : 0ull;
 #pragma unroll
                     for (int k = 0; k < kTeam; ++k) { C.counted[k] = 0; C.expanded[k] = 0; }
                     tk_tick = F2_NOW() - ttk0;
@@ -325,8 +322,7 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
     const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
     const bool has_batch = wave < nb_here;
-    // (the band of a unit: its base is table[band]; a stolen first unit still takes its OWN band's base, read back from the words)
-    const unsigned long long band_base = band_first ? C.base : 0ull;
+    const unsigned long long band_base = band_first ? C.base : 0ull;     // (of the unit's run)
 
     // ======================= triangle phase: one batch per wave (as in k_fused) =======================
     uint32_t t0 = b * tpw, nt = tpw;
@@ -691,9 +687,8 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         if (have_base && lane == 0) {
             chain_store(&chain[b0 + nb_here - 1], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (b0 + nb_here == n_batches) *total_out = base + out_total;
-            // by-product of a launch without bands: where every workgroup's output starts (k_pick_bands cuts the bands of the
-            // NEXT launches at this R from it)
-            if (bands.out) bands.out[lb] = base;
+            // by-product of a launch without runs: where every run's output starts (the table of the NEXT launches at this R)
+            if (runs.out && (lb & rmask) == 0u) runs.out[lb >> runs.shift] = base;
         }
     }
     // status[1] != 0 is what the host acts on; 2 = "a workgroup's entries do not fit", 1 = a bounded wait gave up
@@ -711,9 +706,9 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
                                                       uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
                                                       BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
                                                       uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
-                                                      BandInfo bands, BatchTable bt) {
+                                                      RunInfo runs, BatchTable bt) {
     __shared__ F2Lds S;
-    const F2Args a{ sc, chain, limit, out, total_out, status, biglist, bigmeta, R, epoch, tpw, bands, bt, TicketSets{ nullptr, nullptr } };
+    const F2Args a{ sc, chain, limit, out, total_out, status, biglist, bigmeta, R, epoch, tpw, runs, bt, TicketSets{ nullptr, nullptr } };
     f2_body<false>(S, a, nullptr);
 }
 
@@ -738,14 +733,14 @@ static uint32_t persistent_grid() {
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const BandInfo& bands, const BatchTable& bt, const TicketSets& tk, hipStream_t st) {
+                   const RunInfo& runs, const BatchTable& bt, const TicketSets& tk, hipStream_t st) {
     const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
     const uint32_t n_batches = bt.first ? bt.n : n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
-    BandInfo b = bands;
-    if (tpw != 64u || kTeam != 4 || bt.first) { b.max_width = 0; b.out = nullptr; }
-    if (b.max_width) b.out = nullptr;
+    RunInfo r = runs;
+    if (tpw != 64u || kTeam != 4 || bt.first) r = RunInfo{ nullptr, nullptr, 0u };
+    if (r.base) r.out = nullptr;
     // The persistent form (units by ticket) is built, bit-identical (tests/test_gpu_persistent.py) and NOT the default: on config 3
     // it is 11 % slower than one unit per workgroup (0.133 vs 0.118 ms, profiles/r04/ab_persistent_tickets_at_unit_start.log).  It
     // does what it was built for — 757 of 768 slots busy until the last sixth of the launch instead of ~700 — but (1) a strip
@@ -761,62 +756,20 @@ void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
         pg = (uint32_t)strtoul(v, nullptr, 10);
     }
     if (tk.use && pg && nb > pg && tpw == 64u && kTeam == 4 && !bt.first && debug_on("M2S_PERSIST")) {
-        const F2Args a{ sc, chain, (unsigned long long)limit, out, total, status, biglist, bigmeta, R, epoch & 0xFFFFu, 64u, b, BatchTable{ nullptr, 0u }, tk };
+        const F2Args a{ sc, chain, (unsigned long long)limit, out, total, status, biglist, bigmeta, R, epoch & 0xFFFFu, 64u, r, BatchTable{ nullptr, 0u }, tk };
         hipLaunchKernelGGL(k_fused2p, dim3(pg), dim3(kTeamThreads), 0, st, a);
         return;
     }
-    if (b.max_width) nb = 8u * b.max_width;
-    else nb = (nb + 8 * kXcdRun2 - 1) / (8 * kXcdRun2) * (8 * kXcdRun2);   // whole XCD runs; surplus workgroups exit at once
+    if (r.base) nb = ((nb + (8u << r.shift) - 1u) / (8u << r.shift)) * (8u << r.shift);   // whole groups of eight runs; surplus workgroups exit at once
+    else nb = (nb + 7u) & ~7u;
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta, tpw, b, bt);
+                       epoch & 0xFFFFu, biglist, bigmeta, tpw, r, bt);
 }
 
-// workgroups of k_fused2 for a scene that can be converted in bands (64-triangle batches, no batch table); 0: no bands
+// units of k_fused2 for a scene that can be converted in runs (64-triangle batches, no batch table); 0: no runs
 uint32_t fused2_band_workgroups(uint32_t n_tri) {
     if (fused_tpw(n_tri) != 64u || kTeam != 4) return 0;
     return (n_fused_waves(n_tri) + 3u) / 4u;
-}
-
-// One wave; lanes 0..8 each find one cut.  cost(w) = the estimated work before workgroup w (the batch table's weights: 214 per
-// triangle, 140 per fragment) is monotone in w: cut k is the first workgroup with cost >= k / 8 of the whole.
-__global__ void __launch_bounds__(64) k_pick_bands(const unsigned long long* __restrict__ wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                                                   const unsigned long long* __restrict__ total, uint32_t max_width,
-                                                   uint32_t cost_tri, uint32_t cost_frag, unsigned long long* __restrict__ table,
-                                                   unsigned long long* __restrict__ host_cuts /* [9], pinned host memory */) {
-    __shared__ uint32_t cut[9];
-    const uint32_t k = threadIdx.x;
-    const unsigned long long tot = *total;
-    auto cost = [&](uint32_t w) -> unsigned long long {
-        const unsigned long long tri = min((unsigned long long)w * tri_per_wg, (unsigned long long)n_tri);
-        return (unsigned long long)cost_tri * tri + (unsigned long long)cost_frag * (w < n_wg ? wg_base[w] : tot);
-    };
-    if (k <= 8u) {
-        const unsigned long long target = cost(n_wg) / 8ull * k;
-        uint32_t lo = 0, hi = n_wg;          // first w in [0, n_wg] with cost(w) >= target
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2u;
-            if (cost(mid) >= target) hi = mid; else lo = mid + 1u;
-        }
-        cut[k] = k == 0u ? 0u : k == 8u ? n_wg : lo;
-    }
-    __syncthreads();
-    if (k == 0u) {
-        // no band wider than max_width (that is what the launch provides), cuts in order
-        for (uint32_t j = 1; j < 8u; ++j) {
-            const uint32_t rest = (8u - j) * max_width;                     // what the bands after cut j can hold
-            const uint32_t lo = max(cut[j - 1], n_wg > rest ? n_wg - rest : 0u), hi = min(cut[j - 1] + max_width, n_wg);
-            cut[j] = min(max(cut[j], lo), hi);
-        }
-        for (uint32_t j = 0; j < 8u; ++j) table[kBandBase + j] = cut[j] < n_wg ? wg_base[cut[j]] : tot;
-        for (uint32_t j = 0; j <= 8u; ++j) table[kBandWg + j] = cut[j];
-        // the host learns the cuts too (it waits for this conversion before it uses them): a banded launch is as wide as the widest band
-        for (uint32_t j = 0; j <= 8u; ++j) __hip_atomic_store(&host_cuts[j], (unsigned long long)cut[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-void launch_pick_bands(const unsigned long long* wg_base, uint32_t n_wg, uint32_t tri_per_wg, uint32_t n_tri,
-                       const unsigned long long* total, uint32_t max_width, uint32_t cost_tri, uint32_t cost_frag, unsigned long long* table, unsigned long long* host_cuts, hipStream_t st) {
-    hipLaunchKernelGGL(k_pick_bands, dim3(1), dim3(64), 0, st, wg_base, n_wg, tri_per_wg, n_tri, total, max_width, cost_tri, cost_frag, table, host_cuts);
 }
 
 #ifdef M2S_TIMING

@@ -212,12 +212,12 @@ void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long
 }
 
 // ============================================================================================
-// K_unit_bases: where the output of every run of `unit` (256 or 512) consecutive triangles starts, from the exact counts and
-// the scanned partial sums — what a launch of the single-pass kernels without bands records as a by-product
-// (BandInfo::out), here from the count m2s_upload_scene takes, so that the FIRST conversion of a scene already runs in bands.
+// K_unit_bases: where the output of every RUN of units starts (unit = 256 or 512 triangles, run = 1 << shift units), from the
+// exact counts and the scanned partial sums — what a launch of the single-pass kernels without runs records as a by-product
+// (RunInfo::out), here from the count m2s_upload_scene takes, so that the FIRST conversion of a scene already runs in runs.
 // ============================================================================================
 __global__ void __launch_bounds__(kBlock) k_unit_bases(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ partials,
-                                                       uint32_t n_tri, uint32_t unit, unsigned long long* __restrict__ wg_base) {
+                                                       uint32_t n_tri, uint32_t unit, uint32_t shift, unsigned long long* __restrict__ run_base) {
     __shared__ uint32_t red[kTriPerBlock / kBlock][kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = blockIdx.x * kTriPerBlock;
@@ -230,17 +230,18 @@ __global__ void __launch_bounds__(kBlock) k_unit_bases(const uint32_t* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long run = partials[blockIdx.x];
-        const uint32_t per = unit / kBlock;                        // 256-triangle groups per unit (1 or 2)
+        const uint32_t tri_per_run = unit << shift;                // (a multiple of 256: runs start on 256-triangle boundaries)
         for (int it = 0; it < kTriPerBlock / kBlock; ++it) {
-            if (it % per == 0 && blockBase + it * kBlock < n_tri) wg_base[(blockBase + it * kBlock) / unit] = run;
+            const uint32_t t = blockBase + it * kBlock;
+            if (t < n_tri && t % tri_per_run == 0) run_base[t / tri_per_run] = run;
             run += red[it][0] + red[it][1] + red[it][2] + red[it][3];
         }
     }
 }
 
-void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, unsigned long long* wg_base, hipStream_t st) {
+void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, uint32_t shift, unsigned long long* run_base, hipStream_t st) {
     if (!n_tri) return;
-    hipLaunchKernelGGL(k_unit_bases, dim3(n_count_blocks(n_tri)), dim3(kBlock), 0, st, cnt, partials, n_tri, unit, wg_base);
+    hipLaunchKernelGGL(k_unit_bases, dim3(n_count_blocks(n_tri)), dim3(kBlock), 0, st, cnt, partials, n_tri, unit, shift, run_base);
 }
 
 // ============================================================================================

@@ -22,9 +22,9 @@ namespace {
 // fragments per triangle (a workgroup's stream overflows from ~2.5); with 1 M triangles — 2.5 generations of its 512-triangle
 // workgroups — k_fused2 is ahead down to 0.68 at least.
 static double sparse_frags_per_triangle(uint32_t n_tri) { return n_tri >= 2000000u ? 1.75 : 0.5; }
-// XCD bands for this launch of k_fused2 (unit 256) or k_sparse (unit 512 triangles per workgroup): the table an earlier launch
-// of the same kernel at this R left behind — or, if there is none, ask this launch to record where every workgroup's output
-// starts, from which the table is cut right behind it (second lane: never asked to — two lanes would race on d_wg_base)
+// XCD runs (RunInfo, m2s_device.h) for this launch of k_fused2 (unit 256) or k_sparse (unit 512 triangles): the table an earlier
+// launch of the same kernel at this R — or the count at upload — left behind; or, if there is none, ask this launch to record
+// where every run's output starts (second lane: never asked to — two lanes would race on the table)
 static uint32_t band_workgroups(const m2s_ctx* c, uint32_t unit) {
     const uint32_t team = fused2_band_workgroups(c->scene.n_tri);
     return !team ? 0u : unit == 256u ? team : sparse_workgroups(c->scene.n_tri);
@@ -42,43 +42,18 @@ bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
     return (c->pipeline == M2S_PIPELINE_SPARSE || (c->pipeline == M2S_PIPELINE_AUTO && ri.sparse)) && !ri.sparse_off &&
            sparse_supported(c->scene.n_tri);
 }
-BandInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes) {
-    BandInfo b{};
+RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes) {
+    RunInfo r{ nullptr, nullptr, 0u };
     if (writes) *writes = false;
     const uint32_t n_wg = band_workgroups(c, unit);
-    if (!n_wg || !c->d_bands || (unit == 256u && c->n_batch_tab) || debug_on("M2S_NO_BANDS")) return b;
-    if (ri.bands_ready && ri.bands_unit == unit && ri.band_width) {
-        b.table = c->d_bands + (size_t)ri.band_slot * kBandTableWords;
-        b.max_width = ri.band_width;
-    }
-    else if (may_write) { b.out = c->d_wg_base; if (writes) *writes = true; }
-    return b;
-}
-// behind a launch that recorded its workgroups' bases: cut the bands of the next launches at this R
-void pick_bands(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, const unsigned long long* total, hipStream_t st) {
-    const uint32_t n_wg = band_workgroups(c, unit);
-    // estimated work per triangle / per fragment.  k_fused2: 214 / 140 (cycles of its triangle phase per 64 triangles and of a strip per 64
-    // fragments, tools/team_timing.py; config 3 is insensitive between 100 and 300 per triangle).  k_sparse: most triangles only pay
-    // tier 1: 115 / 140, measured on config 5 at full size (profiles/r03/ab_band_cost_weights_c5.log: 100 / 140 2.86 ms, 115 2.86,
-    // 130 2.90, 145 2.93, 160 2.99, 85 2.96).  (Cutting by MEASURED workgroup lifetimes instead was no better there and much worse
-    // on config 3: a lifetime in the unbanded launch includes waits that depend on where the workgroup was dispatched.)
-    uint32_t cost_tri = unit == 256u ? 214u : 115u, cost_frag = 140;
-    if (const char* v = debug_env("M2S_BAND_COST")) { unsigned a = 0, b = 0; if (sscanf(v, "%u,%u", &a, &b) == 2 && (a || b)) { cost_tri = a; cost_frag = b; } }   // debug
-    launch_pick_bands(c->d_wg_base, n_wg, unit, c->scene.n_tri, total, band_max_width(n_wg), cost_tri, cost_frag,
-                      c->d_bands + (size_t)ri.band_slot * kBandTableWords, c->h_bands + (size_t)ri.band_slot * 9, st);
-}
-
-// the conversion that cut the bands has completed: how wide is the widest one?  (0: the cuts do not describe this scene — never used)
-uint32_t band_width_of(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit) {
-    const unsigned long long* cut = c->h_bands + (size_t)ri.band_slot * 9;
-    const uint32_t n_wg = band_workgroups(c, unit);
-    if (!n_wg || cut[0] != 0 || cut[8] != n_wg) return 0;
-    uint32_t w = 0;
-    for (int x = 0; x < 8; ++x) {
-        if (cut[x + 1] < cut[x]) return 0;
-        w = std::max<uint32_t>(w, (uint32_t)(cut[x + 1] - cut[x]));
-    }
-    return w;
+    const uint32_t shift = run_shift_for(n_wg);
+    if (!n_wg || !shift || !c->d_bands || !c->run_table_words || (unit == 256u && c->n_batch_tab) || debug_on("M2S_NO_BANDS")) return r;
+    if ((size_t)n_runs(n_wg, shift) > c->run_table_words) return r;
+    unsigned long long* table = c->d_bands + (size_t)ri.band_slot * c->run_table_words;
+    r.shift = shift;
+    if (ri.bands_ready && ri.bands_unit == unit) r.base = table;
+    else if (may_write) { r.out = table; if (writes) *writes = true; }
+    return r;
 }
 
 BatchTable batches_for(const m2s_ctx* c) {
@@ -127,8 +102,7 @@ namespace m2s_host {
 // default: the last R this context converted at, else 1024).  The reference converts right after SceneManager::loadModel at the
 // RenderContext's current resolutionTarget (guiRendererConcreteMediator.cpp:11-29), never twice at one (scene, R): its first
 // conversion is the one that counts.  Left behind: the scene's fragments / R^2 (AUTO's decision and the pool size at ANY R
-// without touching the device), and for R itself the decision, the XCD band table cut from the exact counts (k_unit_bases +
-// k_pick_bands), the batch table of one-generation scenes, the multi-pass work buffers, the record pool.
+// without touching the device), and for R itself the decision, the XCD run table from the exact counts (k_unit_bases), the batch table of one-generation scenes, the multi-pass work buffers, the record pool.
 m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     const SceneDev& sc = c->scene;
     if (!sc.n_tri || R == 0 || R > 4096) return M2S_OK;
@@ -179,16 +153,15 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     const uint64_t cap = resolve_cap(c, R);
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
     if (single && (use_sparse(c, ri) || use_team(c, ri)) && !debug_on("M2S_NO_WARM_BANDS")) {
-        // the band table of the first launch at R, from the exact counts (the same table a launch without bands leaves behind)
+        // the run table of the first launch at R, from the exact counts (the same table a launch without runs leaves behind)
         const uint32_t unit = use_sparse(c, ri) ? kSparseTrianglesPerWorkgroup : 256u;
         bool writes = false;
-        (void)bands_for(c, ri, unit, true, &writes);
+        const RunInfo table = bands_for(c, ri, unit, true, &writes);
         if (writes) {
-            launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, c->d_wg_base, st);
-            pick_bands(c, ri, unit, c->d_total, st);
+            launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, table.shift, table.out, st);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));
-            ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit);
+            ri.bands_ready = true; ri.bands_unit = unit;
         }
     }
     // allocations a first conversion would otherwise make inside its own call; best effort (the conversion reports a failure)
@@ -354,14 +327,13 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
-            if ((team || sparse) && wrote_bands) pick_bands(c, ri, unit, &c->h_total[0], st);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; ri.band_width = band_width_of(c, ri, unit); }
+            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
             if (err && debug_on("M2S_DEBUG"))
                 fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
             if (!(err && (team || sparse))) break;

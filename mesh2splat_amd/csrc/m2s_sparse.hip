@@ -188,20 +188,18 @@ __device__ __forceinline__ bool sp_get_base(SpLds& S, const unsigned long long* 
 __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain, unsigned long long limit,
                                                          float4* __restrict__ out, unsigned long long* __restrict__ total_out,
                                                          uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                         BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta, BandInfo bands) {
+                                                         BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta, RunInfo runs) {
     __shared__ SpLds S;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_wg = (sc.n_tri + kSpCand - 1u) / kSpCand;
-    // XCD bands exactly as in k_fused2 (here in workgroups of kSpCand triangles: the table was cut from a k_sparse launch)
+    // XCD runs exactly as in k_fused2 (here in units of kSpCand triangles: the table was recorded by a k_sparse launch)
     const uint32_t hb = blockIdx.x, xcd = hb & 7u, rnd = hb >> 3;
-    const bool banded = bands.max_width != 0u;
+    const bool in_runs = runs.base != nullptr;
+    const uint32_t rmask = (1u << runs.shift) - 1u;
     uint32_t lb = hb;
-    if (banded) {
-        lb = (uint32_t)bands.table[kBandWg + xcd] + rnd;
-        if (lb >= (uint32_t)bands.table[kBandWg + 1u + xcd]) return;
-    }
-    const bool band_first = banded && rnd == 0;
+    if (in_runs) lb = ((((rnd >> runs.shift) << 3) + xcd) << runs.shift) + (rnd & rmask);
+    const bool band_first = in_runs && (rnd & rmask) == 0u;
     if (lb >= n_wg) return;
     const uint32_t t_wg = lb * kSpCand;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
@@ -216,7 +214,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     if (threadIdx.x == 0) {
         S.claimed_round = 0; S.claimed_strip = 0; S.irregular = 0; S.error = 0; S.done_waves = 0;
         S.base_state = (lb == 0 || band_first) ? 2u : 0u;
-        S.base = band_first ? bands.table[xcd] : 0ull;
+        S.base = band_first ? runs.base[lb >> runs.shift] : 0ull;
         S.pre_w[0] = 0; S.pre_c[0] = 0;
     }
 
@@ -277,7 +275,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     SP_T(1, SP_NOW() - tk0);
     const uint32_t nr = (NS + 63u) / 64u;
     const bool knows = lb == 0 || band_first;            // this workgroup's base is known without a look-back
-    const unsigned long long before = band_first ? bands.table[xcd] : 0ull;
+    const unsigned long long before = band_first ? runs.base[lb >> runs.shift] : 0ull;
     if (nr == 0 && wave == 0 && lane == 0)               // nothing survived: the aggregate is zero
         chain_store(&chain[lb], (knows ? kFlagPrefix : kFlagAgg) | etag | (before & kValMask));
 
@@ -634,7 +632,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         if (have_base && lane == 0) {
             chain_store(&chain[lb], kFlagPrefix | etag | ((base + out_total) & kValMask));
             if (lb + 1u == n_wg) *total_out = base + out_total;
-            if (bands.out) bands.out[lb] = base;     // (k_pick_bands cuts the bands of the next launches at this R from these)
+            if (runs.out && (lb & rmask) == 0u) runs.out[lb >> runs.shift] = base;     // (the run table of the next launches at this R)
         }
     }
     // status[1] != 0 is what the host acts on; the value says why (1 / 3 / 4 / 5: a wait gave up, 2: entries do not fit) and where.
@@ -647,14 +645,14 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
 }
 
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out, unsigned long long* total,
-                   uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, const BandInfo& bands, hipStream_t st) {
+                   uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, const RunInfo& runs, hipStream_t st) {
     if (!sc.n_tri) return;
     const uint32_t n_wg = sparse_workgroups(sc.n_tri);
     uint32_t nb = (n_wg + 7u) & ~7u;
-    BandInfo b = bands;
-    if (b.max_width) { nb = 8u * b.max_width; b.out = nullptr; }
+    RunInfo r = runs;
+    if (r.base) { nb = ((n_wg + (8u << r.shift) - 1u) / (8u << r.shift)) * (8u << r.shift); r.out = nullptr; }
     hipLaunchKernelGGL(k_sparse, dim3(nb), dim3(kSpThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta, b);
+                       epoch & 0xFFFFu, biglist, bigmeta, r);
 }
 
 bool sparse_supported(uint32_t n_tri) { return fused_tpw(n_tri) == 64u; }

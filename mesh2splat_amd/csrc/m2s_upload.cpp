@@ -188,8 +188,10 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const size_t o_chain = take(chain_words * sizeof(unsigned long long));
     const size_t o_biglist = take(np * sizeof(BigItem));
     const size_t o_bigmeta = take(4 * sizeof(uint32_t));
-    const size_t o_bands = take((size_t)kBandSlots * kBandTableWords * sizeof(unsigned long long));
-    const size_t o_wg_base = take(((size_t)n_fused_waves(n_tri) / 4 + 2) * sizeof(unsigned long long));
+    // run tables (RunInfo): one per remembered density, one word per run of the kernel with the most units (k_fused2)
+    const uint32_t units = fused2_band_workgroups(n_tri);
+    const size_t run_words = run_shift_for(units) ? (size_t)n_runs(units, run_shift_for(units)) + 1 : 0;
+    const size_t o_bands = take(std::max<size_t>((size_t)kBandSlots * run_words, 1) * sizeof(unsigned long long));
     const size_t o_batch = take(std::max<size_t>(batch_table_capacity(n_tri), 1) * sizeof(uint32_t));
     const size_t o_tickets = take(4 * kTicketSetBytes);
     HIPCHK(c, hipMalloc(&c->scene_arena, arena));
@@ -271,7 +273,7 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->d_biglist = (BigItem*)(A + o_biglist);
     c->d_bigmeta = (uint32_t*)(A + o_bigmeta);
     c->d_bands = (unsigned long long*)(A + o_bands);
-    c->d_wg_base = (unsigned long long*)(A + o_wg_base);
+    c->run_table_words = run_words;
     c->d_batch_first = (uint32_t*)(A + o_batch);
     c->n_batch_tab = 0;
     c->d_tickets = (uint32_t*)(A + o_tickets);
