@@ -623,13 +623,8 @@ __device__ __forceinline__ void combo_tap(uint32_t level_off, uint32_t W, uint32
     j0 = j0 < 0 ? j0 + (int)H : j0;
     j1 = j1 >= (int)H ? j1 - (int)H : j1;
     const uint32_t stride = W + 1;
-#ifdef M2S_ABL_COHERENT   // debug ablation: perfectly coalesced texel addresses (wrong results, timing only)
-    t.o0 = level_off + ((threadIdx.x & 63u) * 6u + (blockIdx.x & 31u) * 768u) % 30000u;
-    t.o1 = t.o0 + 384u + (uint32_t)(i0 + j0 + j1) * 0u + stride * 0u;
-#else
     t.o0 = level_off + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u;
     t.o1 = level_off + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u;
-#endif
     const float na = 1.0f - a, nb = 1.0f - b;
     t.w00 = na * nb; t.w10 = a * nb; t.w01 = na * b; t.w11 = a * b;
 }
@@ -743,24 +738,17 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     // The UV planes are requested FIRST: vector-memory results return in issue order, so the texture
     // coordinates (and with them the dependent texel fetches) need to wait only for these two loads while
     // the other nine attribute loads are still in flight.
-#ifdef M2S_SKIP_ATTR
-    const float4 a0 = make_float4(ts.inva, 1, 2, 3), a1 = a0, b0 = make_float4(0.1f, 0.2f, 0.3f, ts.inva), c0 = a0, c1 = a0, d0 = a0, d1 = a0, d2 = a0;
-    const float a2 = 1, c2 = 2; const float2 b1 = make_float2(0.5f, 0.7f);
-#else
     float4 b0 = make_float4(0, 0, 0, 0);
     float2 b1 = make_float2(0, 0);
     if (uvl == nullptr) {
         b0 = ld_plane(tp.B0, t);
         b1 = ld_plane(tp.B1, t);
     }
-#if !defined(M2S_LATE_ATTR) && !defined(M2S_MID_ATTR)
     const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
     const float a2 = ld_plane(tp.A2, t);
     const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
     const float c2 = ld_plane(tp.C2, t);
     const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
-#endif
-#endif
     float U, V;
     {   // texture coordinates: exact oracle sequence (no FMA), see tri_shade_setup
 #pragma clang fp contract(off)
@@ -787,28 +775,10 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     float nrm[3] = { 0.0f, 0.0f, 1.0f };
     float metal = 0.1f, rough = 0.5f;            // FS:87-95 defaults
     const uint32_t* __restrict__ cmb = mp->combo.texels;
-#ifdef M2S_SKIP_TEX
-    cmb = nullptr; xa = nullptr; xn = nullptr; xm = nullptr;
-#endif
-#if defined(M2S_MID_ATTR) && !defined(M2S_SKIP_ATTR)
-    // A/B switch: the texel reads are requested BEFORE position / normal / tangent (results return in issue order: the filter then
-    // does not wait behind nine attribute loads, which in turn arrive while it runs)
-    ComboFetch cfetch;
-    if (cmb != nullptr) combo_issue(mp, ta, uf, vf, ts, cfetch);
-    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
-    const float a2 = ld_plane(tp.A2, t);
-    const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
-    const float c2 = ld_plane(tp.C2, t);
-    const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
-#endif
     if (cmb != nullptr) {
         // all three maps, same size: one LOD state, interleaved texels, 2 x 24-byte row reads per level
         float acc[9];
-#if defined(M2S_MID_ATTR) && !defined(M2S_SKIP_ATTR)
-        combo_finish(cfetch, acc);
-#else
         combo_sample(mp, ta, uf, vf, ts, acc);
-#endif
         col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2]; col[3] = acc[3];
         nrm[0] = acc[4]; nrm[1] = acc[5]; nrm[2] = acc[6];
         rough = acc[7]; metal = acc[8];
@@ -839,15 +809,6 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         }
     }
     if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();   // texels arrived and filtered
-#if defined(M2S_LATE_ATTR) && !defined(M2S_SKIP_ATTR)
-    // A/B switch: request position / normal / tangent only now (fewer registers live during the texel fetch; their latency is
-    // then exposed unless another wave covers it)
-    const float4 a0 = ld_plane(tp.A0, t), a1 = ld_plane(tp.A1, t);
-    const float a2 = ld_plane(tp.A2, t);
-    const float4 c0 = ld_plane(tp.C0, t), c1 = ld_plane(tp.C1, t);
-    const float c2 = ld_plane(tp.C2, t);
-    const float4 d0 = ld_plane(tp.D0, t), d1 = ld_plane(tp.D1, t), d2 = ld_plane(tp.D2, t);
-#endif
     // the remaining varyings: by now their loads have had the whole texture fetch to arrive
     const float Pxw = M2S_LERP(a0.x, a0.w, a1.z), Pyw = M2S_LERP(a0.y, a1.x, a1.w), Pzw = M2S_LERP(a0.z, a1.y, a2);
     const float Nx = M2S_LERP(c0.x, c0.w, c1.z), Ny = M2S_LERP(c0.y, c1.x, c1.w), Nz = M2S_LERP(c0.z, c1.y, c2);
@@ -908,127 +869,6 @@ __device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, i
 __device__ __forceinline__ void nt_store(float4* p, float4 v) {
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // merged into one dwordx4 nt
-}
-
-// ============================================================================================
-// shade_from_tri for K fragments per lane at once (K = 2: "dual strip")
-// ============================================================================================
-// The same operations as shade_from_tri, per fragment, in the same order — hence the same bits — but written stage by stage
-// over K independent fragments so that ALL their loads of a stage are in flight together: K x the memory-level parallelism per
-// wave at the price of K x the registers (the single-fragment form keeps 3 waves per SIMD busy with one strip each; two
-// waves with two strips each have four strips in flight).  Fragment k of the 64 lanes forms strip k: wave-uniform decisions
-// (does any lane of the strip blend two mip levels?) are taken per k, exactly as the single-fragment code takes them per strip.
-// Fast path only: wave-uniform mesh WITH a combo texture (the caller falls back to shade_from_tri otherwise).
-template <int K, class MP>
-__device__ __forceinline__ void shade_from_tri_x(const TriPlanes& tp, const uint32_t t[K], const int x[K], const int y[K], MP mp,
-                                                 const TriShade* const ts[K], float4 rec[K][6]) {
-    float l1[K], l2[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int dx256 = (x[k] - (int)(ts[k]->org & 0xFFFu)) * 256, dy256 = (y[k] - (int)(ts[k]->org >> 12)) * 256;
-        const long long E1 = ts[k]->e1 + (long long)ts[k]->a1 * dx256 + (long long)ts[k]->b1 * dy256;
-        const long long E2 = ts[k]->e2 + (long long)ts[k]->a2 * dx256 + (long long)ts[k]->b2 * dy256;
-        {
-#pragma clang fp contract(off)
-            l1[k] = i64_to_f32(E1) * ts[k]->inva;
-            l2[k] = i64_to_f32(E2) * ts[k]->inva;
-        }
-    }
-    // ---- attribute planes of all K fragments: UV first (the texel addresses depend on them) ----
-    float4 b0[K], a0[K], a1[K], c0[K], c1[K], d0[K], d1[K], d2[K];
-    float2 b1[K];
-    float a2[K], c2[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { b0[k] = ld_plane(tp.B0, t[k]); b1[k] = ld_plane(tp.B1, t[k]); }
-    const auto ta = &mp->tex[0];
-    const uint32_t w = ta->w, h = ta->h;
-    const uint32_t* __restrict__ base = mp->combo.texels;
-    // ---- texel addresses of all K fragments ----
-    ComboTap tlo[K], thi[K];
-    float f[K];
-    bool two[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float U, V;
-        {
-#pragma clang fp contract(off)
-            U = (b0[k].x + l1[k] * (b0[k].z - b0[k].x)) + l2[k] * (b1[k].x - b0[k].x);
-            V = (b0[k].y + l1[k] * (b0[k].w - b0[k].y)) + l2[k] * (b1[k].y - b0[k].y);
-        }
-        const float uf = frac_repeat(U), vf = frac_repeat(V);
-        f[k] = ts[k]->lod0;
-        const uint32_t off0 = __float_as_uint(ts[k]->lod1), off1 = __float_as_uint(ts[k]->lod2);
-        const uint32_t lv0 = (ts[k]->mesh >> 24) & 15u, lv1 = ts[k]->mesh >> 28;
-        combo_tap(off0, max(1u, w >> lv0), max(1u, h >> lv0), uf, vf, tlo[k]);
-        two[k] = __ballot(f[k] != 0.0f) != 0ull;
-        thi[k] = tlo[k];
-        if (two[k]) combo_tap(off1, max(1u, w >> lv1), max(1u, h >> lv1), uf, vf, thi[k]);
-    }
-    // ---- ALL row reads of all fragments and levels before the first one is consumed ----
-    ComboPair pa0[K], pa1[K], pb0[K], pb1[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        pa0[k] = ld_combo(as_global(base), tlo[k].o0);
-        pa1[k] = ld_combo(as_global(base), tlo[k].o1);
-        if (two[k]) {
-            pb0[k] = ld_combo(as_global(base), thi[k].o0);
-            pb1[k] = ld_combo(as_global(base), thi[k].o1);
-        } else { pb0[k] = pa0[k]; pb1[k] = pa1[k]; }
-    }
-    // the remaining planes (position, normal, tangent) are requested only now, behind the texel reads: with K strips in
-    // flight their latency hides behind the filter arithmetic below, and they do not occupy registers during the texel fetch
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        a0[k] = ld_plane(tp.A0, t[k]); a1[k] = ld_plane(tp.A1, t[k]); a2[k] = ld_plane(tp.A2, t[k]);
-        c0[k] = ld_plane(tp.C0, t[k]); c1[k] = ld_plane(tp.C1, t[k]); c2[k] = ld_plane(tp.C2, t[k]);
-        d0[k] = ld_plane(tp.D0, t[k]); d1[k] = ld_plane(tp.D1, t[k]); d2[k] = ld_plane(tp.D2, t[k]);
-    }
-    float acc[K][9];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (two[k]) {
-            const float klo = (1.0f - f[k]) * kUnorm8, khi = f[k] * kUnorm8;
-            ComboTap lo = tlo[k], hi = thi[k];
-            lo.w00 *= klo; lo.w10 *= klo; lo.w01 *= klo; lo.w11 *= klo;
-            hi.w00 *= khi; hi.w10 *= khi; hi.w01 *= khi; hi.w11 *= khi;
-            float vlo[9], vhi[9];
-            combo_filter(pa0[k], pa1[k], lo, vlo);
-            combo_filter(pb0[k], pb1[k], hi, vhi);
-#pragma unroll
-            for (int ch = 0; ch < 9; ch++) acc[k][ch] = vlo[ch] + vhi[ch];
-        } else {
-            ComboTap lo = tlo[k];
-            lo.w00 *= kUnorm8; lo.w10 *= kUnorm8; lo.w01 *= kUnorm8; lo.w11 *= kUnorm8;
-            combo_filter(pa0[k], pa1[k], lo, acc[k]);
-        }
-    }
-    const bool has_normal_map = mp->tex[1].texels != nullptr;   // (a combo texture implies all three maps)
-    (void)has_normal_map;
-#define M2S_LERPK(f0, f1, f2) fma_(l2[k], (f2) - (f0), fma_(l1[k], (f1) - (f0), (f0)))
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float Pxw = M2S_LERPK(a0[k].x, a0[k].w, a1[k].z), Pyw = M2S_LERPK(a0[k].y, a1[k].x, a1[k].w), Pzw = M2S_LERPK(a0[k].z, a1[k].y, a2[k]);
-        const float Nx = M2S_LERPK(c0[k].x, c0[k].w, c1[k].z), Ny = M2S_LERPK(c0[k].y, c1[k].x, c1[k].w), Nz = M2S_LERPK(c0[k].z, c1[k].y, c2[k]);
-        const float Tx = M2S_LERPK(d0[k].x, d1[k].x, d2[k].x), Ty = M2S_LERPK(d0[k].y, d1[k].y, d2[k].y), Tz = M2S_LERPK(d0[k].z, d1[k].z, d2[k].z);
-        const float Tw = M2S_LERPK(d0[k].w, d1[k].w, d2[k].w);
-        float rx = fma_(acc[k][4], 2.0f, -1.0f), ry = fma_(acc[k][5], 2.0f, -1.0f), rz = fma_(acc[k][6], 2.0f, -1.0f);
-        float inv = fast_rsq(dot3_(rx, ry, rz, rx, ry, rz));
-        rx *= inv; ry *= inv; rz *= inv;
-        float bx = fma_(Ny, Tz, -(Nz * Ty)), by = fma_(Nz, Tx, -(Nx * Tz)), bz = fma_(Nx, Ty, -(Ny * Tx));
-        inv = fast_rsq(dot3_(bx, by, bz, bx, by, bz)) * Tw;
-        bx *= inv; by *= inv; bz *= inv;
-        inv = fast_rsq(dot3_(Nx, Ny, Nz, Nx, Ny, Nz));
-        const float nnx = Nx * inv, nny = Ny * inv, nnz = Nz * inv;
-        const float wx = fma_(nnx, rz, fma_(bx, ry, Tx * rx)), wy = fma_(nny, rz, fma_(by, ry, Ty * rx)), wz = fma_(nnz, rz, fma_(bz, ry, Tz * rx));
-        inv = fast_rsq(dot3_(wx, wy, wz, wx, wy, wz));
-        rec[k][0] = make_float4(Pxw, Pyw, Pzw, 1.0f);
-        rec[k][1] = make_float4(acc[k][0] * mp->color[0], acc[k][1] * mp->color[1], acc[k][2] * mp->color[2], acc[k][3] * mp->color[3]);
-        rec[k][2] = make_float4(ts[k]->sx, ts[k]->sy, 1e-7f, 0.0f);
-        rec[k][3] = make_float4(wx * inv, wy * inv, wz * inv, 0.0f);
-        rec[k][4] = ts[k]->rot;
-        rec[k][5] = make_float4(acc[k][8], acc[k][7], 0.0f, 1.0f);
-    }
-#undef M2S_LERPK
 }
 
 }  // namespace m2s

@@ -39,11 +39,8 @@ constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_sca
 #ifndef M2S_COUNT_WAVES
 #define M2S_COUNT_WAVES 4
 #endif
-#ifndef M2S_EMIT2_DUAL
-#define M2S_EMIT2_DUAL 0
-#endif
 #ifndef M2S_EMIT2_WAVES
-#define M2S_EMIT2_WAVES (M2S_EMIT2_DUAL ? 2 : 4)   // round 3: 122 VGPRs since both mip levels are read without a branch: four waves per SIMD, no scratch
+#define M2S_EMIT2_WAVES 4   // round 3: 122 VGPRs since both mip levels are read without a branch: four waves per SIMD, no scratch
 #endif
 
 // What k_emit2 needs to know about a triangle: the fragment stage's constants plus the third edge function and the
@@ -320,58 +317,6 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
         wave_lds_sync();
         // ---- fragment phase: strips of 64 entries ----
         uint32_t s_begin = pos;
-#if M2S_EMIT2_DUAL
-        // two strips per iteration while at least 65 entries remain: lane l shades entries s0 + l and s0 + 64 + l with
-        // all loads of both in flight together (shade_from_tri_x<2>: same operations per fragment, same bits)
-        for (; s_begin + 64u < bend; s_begin += 128u) {
-            const uint32_t s0 = s_begin, n = min(128u, bend - s0);
-            uint32_t en[2], tl[2], my_mesh[2];
-            bool have[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t i = (uint32_t)lane + 64u * k;
-                have[k] = i < n;
-                en[k] = L.entries[s0 - wbase + min(i, n - 1u)];        // lanes beyond the end re-shade the last entry (never stored)
-                tl[k] = (en[k] >> 24) & 63u;
-                my_mesh[k] = reinterpret_cast<const uint32_t*>(&L.tri[tl[k] * 5 + 4])[3] & 0xFFFFFFu;
-            }
-            const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh[0]);
-            const bool uniform = sc.n_meshes == 1 || __ballot(my_mesh[0] != m_first || my_mesh[1] != m_first) == 0ull;
-            float4 rec2[2][6];
-            if (uniform && kConstMesh(sc.meshes + m_first)->combo.texels != nullptr) {
-                const uint32_t tt[2] = { t_cur + tl[0], t_cur + tl[1] };
-                const int xs[2] = { (int)(en[0] & 0xFFFu), (int)(en[1] & 0xFFFu) }, ys[2] = { (int)((en[0] >> 12) & 0xFFFu), (int)((en[1] >> 12) & 0xFFFu) };
-                const TriShade* const tsp[2] = { reinterpret_cast<const TriShade*>(&L.tri[tl[0] * 5]), reinterpret_cast<const TriShade*>(&L.tri[tl[1] * 5]) };
-                shade_from_tri_x<2>(sc.tri, tt, xs, ys, kConstMesh(sc.meshes + m_first), tsp, rec2);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const TriShade& ts = *reinterpret_cast<const TriShade*>(&L.tri[tl[k] * 5]);
-                    if (uniform) shade_from_tri(sc.tri, t_cur + tl[k], (int)(en[k] & 0xFFFu), (int)((en[k] >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec2[k]);
-                    else shade_from_tri(sc.tri, t_cur + tl[k], (int)(en[k] & 0xFFFu), (int)((en[k] >> 12) & 0xFFFu), sc.meshes + my_mesh[k], ts, rec2[k]);
-                }
-            }
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {        // four half-strips through the staging area (unrolled: rec2 stays in registers)
-                const int k = q4 >> 1, half = q4 & 1;
-                if (have[k] && (lane >> 5) == half) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) L.stage[(lane & 31) * 6 + c] = rec2[k][c];
-                }
-                wave_lds_sync();
-                const uint32_t first = 64u * k + 32u * half;
-                float4* __restrict__ dsto = out + ((size_t)s0 + first) * 6;
-                const uint32_t nv = n > first ? min(32u, n - first) : 0u;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const uint32_t q = (uint32_t)lane + 64u * j;
-                    const uint32_t r = q / 6u;
-                    if (r < nv) nt_store(&dsto[q], L.stage[q]);
-                }
-                wave_lds_sync();
-            }
-        }
-#endif
         for (uint32_t s0 = s_begin; s0 < bend; s0 += 64) {
             const uint32_t n = min(64u, bend - s0);
             const bool have = (uint32_t)lane < n;

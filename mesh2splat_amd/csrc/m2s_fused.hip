@@ -68,10 +68,6 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                                                   BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
                                                   uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */) {
     __shared__ WaveLds lds_all[kBlock / 64];
-#ifdef M2S_LDS_PAD   // debug: lower the occupancy artificially
-    __shared__ volatile uint32_t lds_pad[M2S_LDS_PAD / 4];
-    if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
-#endif
     const int lane = threadIdx.x & 63;
     WaveLds& L = lds_all[threadIdx.x >> 6];
     // Optional XCD-aware placement (kXcdRun > 1): hardware workgroup b runs on XCD b % 8 (private L2 each);
@@ -238,7 +234,6 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         if (lane == 0) __hip_atomic_store(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---------------- fragment phase, in windows of kWaveEntryCap ----------------
-#ifndef M2S_ABLATE_NOFRAG
     for (uint32_t win = 0; win < total_c; win += kWaveEntryCap) {
         const uint32_t wend = win + kWaveEntryCap;
         {
@@ -297,11 +292,7 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
             if (!have_base) resolve_base();
             if (win == 0 && e0 == 0) M2S_STAMP(7);  // base resolved
             const unsigned long long oidx = base + skipped + win + e;
-#ifdef M2S_DIRECT_STORE   // debug A/B: per-lane strided record stores instead of LDS-staged coalesced runs
-            if (false) {
-#else
             if (!anybig) {
-#endif
                 // the strip's records are consecutive in the output: stage half a wave at a time, then
                 // 16 B/lane fully coalesced stores (3 KiB contiguous per half)
                 const unsigned long long o0 = base + win + e0;
@@ -323,13 +314,9 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
                     for (int j = 0; j < 3; ++j) {
                         const uint32_t q = (uint32_t)lane + 64u * j;
                         const uint32_t r = q / 6u;
-#ifndef M2S_SKIP_STORE
                         // non-temporal: the records are never re-read by this kernel; keeping them out of the
                         // 4 MiB L2 leaves it to the texture / vertex lines (measured: k_fused 0.236 -> 0.200 ms)
                         if (r < nv) nt_store(&dsto[q], L.stage[q]);
-#else
-                        if (r < nv && L.stage[q].x == 123.456f) dsto[q] = L.stage[q];
-#endif
                     }
                     wave_lds_sync();
                 }
@@ -341,7 +328,6 @@ __global__ void __launch_bounds__(kBlock, M2S_FUSED_WAVES) k_fused(SceneDev sc, 
         }
         wave_lds_sync();  // the next window overwrites entries
     }
-#endif
     M2S_STAMP(8);  // done
 #ifdef M2S_TIMING
     if (lane == 0 && wid < kTimingWaves) { g_timing[9 * kTimingWaves + wid] = total_c; g_timing[10 * kTimingWaves + wid] = __builtin_amdgcn_s_getreg(6164) /*XCC_ID*/; }

@@ -81,9 +81,6 @@ struct F2Ctl {
 struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
-#ifdef M2S_FUSED2_LDS_UV
-    float2 uv[kTeam][64 * 3];              // per triangle: (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0): texture coordinates without a global round trip
-#endif
     uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
     float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
     F2Ctl ctl[2];
@@ -487,14 +484,12 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     // time anybody reaches a store, the base is there (round 1 took the look-back after the last wave's expansion: wave 0
     // then waited 3.9 k cycles for the base on average).  The predecessors' aggregates are published right after THEIR
     // counting, i.e. at about the time this workgroup has counted too.
-#ifndef M2S_LATE_LOOKBACK
     if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&C.error) == 0) {
         const unsigned long long tb0 = F2_NOW();
         have_base = f2_get_base(C, chain, chain, b0, lane, epoch, status, base);
         if (!have_base) alive = false;
         tk_base += F2_NOW() - tb0;
     }
-#endif
 
     if (kPersist) {
         // Everything above touched registers, global memory and THIS unit's control words only.  From here on the unit writes the
@@ -518,11 +513,6 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
 #pragma unroll
             for (int k = 0; k < 5; ++k) S.tri[wave][lane * 5 + k] = src[k];
             S.tskip[wave][lane] = (uint32_t)((out0 + toff) - ((unsigned long long)stream0 + ctoff));
-#ifdef M2S_FUSED2_LDS_UV
-            S.uv[wave][lane * 3 + 0] = make_float2(uvb0.x, uvb0.y);
-            S.uv[wave][lane * 3 + 1] = make_float2(uvb0.z - uvb0.x, uvb0.w - uvb0.y);
-            S.uv[wave][lane * 3 + 2] = make_float2(uvb1.x - uvb0.x, uvb1.y - uvb0.y);
-#endif
         }
         if (anybig) {   // deferred triangles: reserve their slice of the output, list them for k_emit_big
             unsigned long long base;
@@ -581,12 +571,6 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         }
         tk_cnt += F2_NOW() - tw0;
     }
-#ifdef M2S_LATE_LOOKBACK   // A/B switch: round 1's placement (after the last wave's own expansion)
-    if (alive && wave == (uint32_t)kTeam - 1 && lds_load(&C.error) == 0) {
-        have_base = f2_get_base(C, chain, chain, b0, lane, epoch, status, base);
-        if (!have_base) alive = false;
-    }
-#endif
     [[maybe_unused]] const unsigned long long tsl0 = F2_NOW();
     while (alive && lds_load(&C.error) == 0) {
         uint32_t s = 0;
@@ -632,11 +616,7 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
             const uint32_t tt = C.t0[ow] + tl;
             skip = S.tskip[ow][tl];
             // a strip inside one mesh (the common case): wave-uniform descriptor pointer in the constant address space
-#ifdef M2S_FUSED2_LDS_UV
-            const float2* uvl = &S.uv[ow][tl * 3];
-#else
             const float2* uvl = nullptr;
-#endif
             if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec, nullptr, uvl);
             else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec, nullptr, uvl);
         }

@@ -222,11 +222,6 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     const uint32_t lastT = min(t_wg + kSpCand, sc.n_tri) - 1u;
     bool uniform_mesh;
     const uint32_t m0 = mesh_of_range(sc, t_wg, lastT, uniform_mesh);   // one scalar load (was: a binary search)
-#ifdef M2S_SPARSE_NOCULL   // experiment: the pooled-rounds structure WITHOUT tier 1 (every candidate "survives")
-    uint32_t NS = min(kSpCand, sc.n_tri - t_wg);
-    for (uint32_t i = threadIdx.x; i < kSpCand; i += kSpThreads) S.surv[i] = (uint16_t)i;
-    __syncthreads();
-#else
     unsigned long long passm[kSpPer];
     bool pass[kSpPer];
     {
@@ -270,7 +265,6 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
             if (pass[k]) S.surv[my_off[k] + lanes_below(passm[k])] = (uint16_t)((wave + (uint32_t)k * kSpWaves) * 64u + (uint32_t)lane);
     }
     __syncthreads();
-#endif
     NS = __builtin_amdgcn_readfirstlane(NS);
     SP_T(1, SP_NOW() - tk0);
     const uint32_t nr = (NS + 63u) / 64u;
@@ -323,10 +317,8 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         for (int i = 0; i < 9; ++i) p[i] = pn[i];
         const float4 uvb0 = uvn0;
         const float2 uvb1 = uvn1;
-#ifndef M2S_SPARSE_NO_PREFETCH
         r_next = claim_round();
         request_round(r_next);
-#endif
         Geo g;
         Raster rs;
         rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
@@ -483,10 +475,6 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
         if (stamp) SP_T(20, SP_NOW() - q0);   // + entries written
         sp_store(&S.expanded[r], 1u);   // release (set even on error so that nobody waits for it)
         if (!alive) break;
-#ifdef M2S_SPARSE_NO_PREFETCH   // A/B switch: request a round's inputs only when it is about to be computed
-        r_next = claim_round();
-        request_round(r_next);
-#endif
     }
 
     // ======================= fragment phase: strips of the workgroup's stream =======================
