@@ -34,11 +34,12 @@ log("scene ready:", T, "triangles,", sum(m.vertices.nbytes for m in scene.meshes
 
 res = {"scene": f"{count} x cube-sphere n={n} ({T} triangles), {tex}^2 maps, R={R}, cap lifted", "triangles": T}
 conv = Converter(0)
+conv.set_max_gaussians(0)          # (before the upload: it prepares the record pool and the run table for the conversion below)
+conv.set_resolution_hint(R)
 t = time.perf_counter()
 conv.upload_scene(scene)
 res["upload_s"] = time.perf_counter() - t
 log("uploaded in", round(res["upload_s"], 3), "s")
-conv.set_max_gaussians(0)
 conv.set_profiling(True)
 t = time.perf_counter()
 total = conv.convert(R)

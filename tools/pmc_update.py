@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""After tools/r3_final.sh: fold the PMC summaries of the closing run into profiles/pmc_traffic.json (HBM bytes per launch =
+"""After tools/r4_final.sh (r3_final.sh): fold the PMC summaries of the closing run into profiles/pmc_traffic.json (HBM bytes per launch =
 2 x FETCH_SIZE KB (gfx950 tallies 128-byte requests at 64) + WRITE_SIZE KB x the k_repack calibration) together with the sha of
-the library they were measured on, and copy the evidence files to profiles/r03/.   usage: python tools/pmc_update.py [tag]"""
+the library they were measured on, and copy the evidence files to profiles/<round>/.   usage: python tools/pmc_update.py [tag] [round dir, default r04]"""
 import json
 import os
 import shutil
@@ -9,8 +9,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r3fin"
-P = os.path.join(ROOT, "profiles", "r03")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r4fin"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+P = os.path.join(ROOT, "profiles", RND)
+os.makedirs(P, exist_ok=True)
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 t = json.load(open(path))
 sha = open(os.path.join(O, TAG + "_binary_sha.txt")).read().strip()
@@ -27,9 +29,8 @@ c2 = json.load(open(os.path.join(O, TAG + "_pmc_c2_summary.json")))["m2s::k_fuse
 r, w = traffic(c3)
 t.update({"FETCH_SIZE_KB": c3["FETCH_SIZE"], "WRITE_SIZE_KB": c3["WRITE_SIZE"], "k_fused2_read_bytes": r, "k_fused2_write_bytes": w,
           "k_fused2_hbm_bytes_per_launch": r + w, "binary_sha": {"k_fused2": sha, "k_sparse": sha}})
-t["source_round3"] = ("profiles/r03/final_pmc_c3_summary.json, final_pmc_c5_summary.json, final_pmc_c2_summary.json (tools/r3_final.sh: separate --pmc "
-                      "passes FETCH_SIZE / WRITE_SIZE / two SQ sets, 23 blocking launches each for c3 and c2, 8 for c5; mean per launch, the first — "
-                      "unbanded — launch included); library sha256[:16] " + sha)
+t["source_round" + RND[-1]] = ("profiles/" + RND + "/final_pmc_c3_summary.json, final_pmc_c5_summary.json, final_pmc_c2_summary.json (tools/" + RND.replace("0", "") + "_final.sh: separate --pmc "
+                      "passes FETCH_SIZE / WRITE_SIZE / two SQ sets, 23 blocking launches each for c3 and c2, 8 for c5; mean per launch); library sha256[:16] " + sha)
 r5, w5 = traffic(c5)
 t["c5"] = {"workload": "c5 at full size (50 037 168 triangles, 24 267 048 Gaussians)", "kernel": "k_sparse", "algorithmic_bytes": 9534988800.0,
            "k_sparse_read_bytes": r5, "k_sparse_write_bytes": w5, "k_sparse_hbm_bytes_per_launch": r5 + w5,
