@@ -129,11 +129,16 @@ struct RunInfo {
     unsigned long long* out;         // launch without runs: out[j] = the same, recorded for the next launches (or nullptr)
     uint32_t shift;                  // log2 of the run length in units
 };
-// run length for a scene of n_units units (0: too few units for runs to make sense — plain order)
+// run length for a scene of n_units units (0: too few units for runs to make sense — plain order): 32 units (8192 triangles of
+// k_fused2) where that still leaves every XCD four runs, else 16 or 8.  Measured on config 3 (3916 units), kernel time / read
+// traffic: runs of 8 / 16 / 32 / 64 units 0.117-0.118 / 0.120 / 0.118-0.119 / 0.124-0.125 ms, eight equal-work bands 0.118-0.119
+// (profiles/r04/ab_xcd_runs_vs_equal_work_bands.log); longer runs keep more neighbours in one L2 (fewer texel re-reads), shorter
+// ones even the XCDs' work out.
 inline uint32_t run_shift_for(uint32_t n_units) {
-    uint32_t shift = 4;                                   // 16 units = 4096 triangles of k_fused2
-    if (const char* v = debug_env("M2S_RUN_SHIFT")) shift = (uint32_t)std::atoi(v) & 15u;     // debug: A/B of the run length
-    return n_units >= (32u << shift) ? shift : 0u;        // at least four runs per XCD
+    if (const char* v = debug_env("M2S_RUN_SHIFT")) { const uint32_t s = (uint32_t)std::atoi(v) & 15u; return n_units >= (32u << s) ? s : 0u; }   // debug: A/B
+    for (uint32_t shift = 5; shift >= 3; --shift)
+        if (n_units >= (32u << shift)) return shift;      // at least four runs per XCD
+    return 0u;
 }
 inline uint32_t n_runs(uint32_t n_units, uint32_t shift) { return (n_units + (1u << shift) - 1u) >> shift; }
 // Work-balanced batches of k_fused2 for scenes that one generation of workgroups converts (fewer than ~172 k triangles): batch b
