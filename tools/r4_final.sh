@@ -5,7 +5,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r4fin}
 cd $R
 sha256sum mesh2splat_amd/_build/libm2s_hip.so | cut -c1-16 > $O/${TAG}_binary_sha.txt; cat $O/${TAG}_binary_sha.txt
-bash tools/r4_check.sh ${TAG}
+python __graft_entry__.py smoke 2>&1 | tail -1
+timeout 400 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; tail -2 $O/${TAG}_bench.err; python -c "
+import json; d=json.loads(open('$O/${TAG}_bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('frac_dedicated_sample'), (d.get('overlapped') or {}).get('ms_per_step'), {k:(round(v.get('ms_per_step',0),4),v.get('kernel_ms'),v.get('roofline_whole_conversion',{}).get('frac_of_hbm_peak')) for k,v in d.get('extra_workloads',{}).items()}); print({k: d['roofline'].get(k) for k in ('frac_step','frac_first_call','frac_new_R','frac_cold_inputs')}, d['extra_workloads'].get('c5',{}).get('depth_sort',{}).get('repeat_ms'))"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bench -o k -- python $R/bench.py > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace_bench.err || echo "trace of bench failed"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_c3 -o k -- python $R/bench.py --no-overlap-extra --no-c5 --no-cpu-baseline --no-viewer-extra --no-cold --no-extra-workloads > $O/${TAG}_trace_c3.json 2> $O/${TAG}_trace_c3.err || echo "trace of c3 failed"
@@ -33,3 +35,19 @@ for k, v in d.items():
 PY
 done
 for t in bench c3; do f=$(ls $O/${TAG}_trace_$t/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -8 $f; done
+
+# the command line: what the first conversion of a model costs inside the one-shot converter (config 3 as a .glb)
+cd $R
+python - <<PY > $O/${TAG}_cli.log 2>&1
+import os, subprocess, sys, json
+sys.path.insert(0, "$R")
+from mesh2splat_amd import gltf_io, synth
+glb = "/tmp/c3_cli.glb"
+gltf_io.write_glb(synth.cube_sphere(289, tex_size=2048), glb, indexed=False)
+for fmt in (2, 1):
+    r = subprocess.run(["$R/mesh2splat_amd/_build/mesh2splat", glb, "/tmp/c3_cli.ply", "--density", "1024", "--format", str(fmt), "--timing"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-1500:], r.stderr[-300:])
+PY
+tail -12 $O/${TAG}_cli.log
+# the GPU suite last (its CPU side — the oracle — can take several minutes on a busy box)
+timeout 1500 python -m pytest tests -m gpu -q -x --durations=8 > $O/${TAG}_tests.log 2>&1; grep -E "passed|failed|^[0-9.]+s (call|setup)" $O/${TAG}_tests.log | head -12
