@@ -103,8 +103,10 @@ m2s_status m2s_set_triangle_range(m2s_ctx* ctx, uint64_t first, uint64_t count);
 m2s_status m2s_upload_scene(m2s_ctx* ctx, const m2s_mesh* meshes, uint32_t n_meshes);
 
 /* Optional: allocate now what the first upload (M2S_PREPARE_UPLOAD: pinned + device staging chunks) and the first export
- * (M2S_PREPARE_EXPORT: pinned chunks for the device-to-host copies) would otherwise allocate on their own critical path. */
-enum { M2S_PREPARE_UPLOAD = 1, M2S_PREPARE_EXPORT = 2 };
+ * (M2S_PREPARE_EXPORT: pinned chunks for the device-to-host copies) would otherwise allocate on their own critical path;
+ * M2S_PREPARE_KERNELS: have the HIP runtime load the code objects of every kernel now instead of inside the first conversion /
+ * export / viewer pass of the process (m2s_upload_scene does it for the conversion pipeline it chooses in any case). */
+enum { M2S_PREPARE_UPLOAD = 1, M2S_PREPARE_EXPORT = 2, M2S_PREPARE_KERNELS = 4 };
 m2s_status m2s_prepare(m2s_ctx* ctx, uint32_t flags);
 
 /* Wall-clock breakdown (ms) of the last m2s_upload_scene: [0] whole call, [1] geometry (pinned staging + re-layout kernel),

@@ -90,6 +90,13 @@ class Converter:
     def set_triangle_range(self, first: int, count: Optional[int]):
         self._check(self._L.m2s_set_triangle_range(self._h, int(first), (1 << 64) - 1 if count is None else int(count)))
 
+    PREPARE_UPLOAD, PREPARE_EXPORT, PREPARE_KERNELS = 1, 2, 4
+
+    def prepare(self, flags: int = 7):
+        """m2s_prepare: staging buffers (upload / export) and the kernels' code objects now, not inside the first upload /
+        export / conversion of the process (the command line does this on a second thread while it parses the file)."""
+        self._check(self._L.m2s_prepare(self._h, int(flags)))
+
     def set_resolution_hint(self, R: int):
         """The resolutionTarget the next upload_scene prepares for (0: the last R converted at, else 1024)."""
         self._check(self._L.m2s_set_resolution_hint(self._h, int(R)))

@@ -204,6 +204,17 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
 void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st);
 void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long long* splitters, uint32_t m, unsigned long long* out, hipStream_t st);
 
+// The runtime loads a file's code object inside the first launch of one of its kernels (0.2-0.6 ms each: the first conversion of
+// a PROCESS).  These make it happen now — hipFuncGetAttributes on one kernel of the file — without launching anything:
+// m2s_upload_scene asks for the pipeline it has just decided on, m2s_prepare(M2S_PREPARE_KERNELS) for all of them.
+hipError_t preload_fused2();
+hipError_t preload_sparse();
+hipError_t preload_fused();
+hipError_t preload_multipass();
+hipError_t preload_export();
+hipError_t preload_prepass();
+hipError_t preload_sort();
+
 inline uint32_t n_count_blocks(uint32_t n_tri) { return (n_tri + kTriPerBlock - 1) / kTriPerBlock; }
 // fused kernel: triangles per wave.  64 as soon as that fills the GPU's 3072 wave slots once.  A smaller scene gets just
 // enough triangles per wave to occupy every slot ONCE (one round of waves instead of two: the C2 stand-in, 69 312

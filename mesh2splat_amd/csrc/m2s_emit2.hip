@@ -380,4 +380,7 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
                        (const float4*)setup, out, run);
 }
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_multipass() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_emit2)); }
+
 }  // namespace m2s

@@ -124,4 +124,7 @@ void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float sm
                        reinterpret_cast<uint32_t*>(out));
 }
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_export() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_encode_rows)); }
+
 }  // namespace m2s

@@ -351,4 +351,7 @@ extern "C" int m2s_debug_read_timing(unsigned long long* dst, size_t n) {
 }
 #endif
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_fused() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fused)); }
+
 }  // namespace m2s

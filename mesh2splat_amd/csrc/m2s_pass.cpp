@@ -152,6 +152,14 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total);
     const uint64_t cap = resolve_cap(c, R);
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
+    // the code object of the pipeline this scene is about to run: loaded here, not inside the first conversion of the process
+    if (!debug_on("M2S_NO_PRELOAD")) {
+        if (!single) { (void)preload_multipass(); }
+        else if (use_sparse(c, ri)) { (void)preload_sparse(); (void)preload_fused2(); }   // (the sparse form falls back to the team on a stream overflow)
+        else if (use_team(c, ri)) { (void)preload_fused2(); }
+        else { (void)preload_fused(); }
+        (void)hipGetLastError();
+    }
     if (single && (use_sparse(c, ri) || use_team(c, ri)) && !debug_on("M2S_NO_WARM_BANDS")) {
         // the run table of the first launch at R, from the exact counts (the same table a launch without runs leaves behind)
         const uint32_t unit = use_sparse(c, ri) ? kSparseTrianglesPerWorkgroup : 256u;

@@ -400,4 +400,7 @@ void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out) {
     k.global_w = gx ? gx * 16u : 16u;
 }
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_prepass() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_prepass)); }
+
 }  // namespace m2s

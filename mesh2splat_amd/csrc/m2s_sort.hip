@@ -140,4 +140,7 @@ void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long l
     hipLaunchKernelGGL(k_lower_bounds, dim3((m + 63) / 64), dim3(64), 0, st, keys, (unsigned long long)n, splitters, m, out);
 }
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_sort() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_gather_records)); }
+
 }  // namespace m2s

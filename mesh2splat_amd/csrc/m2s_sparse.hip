@@ -660,4 +660,7 @@ extern "C" int m2s_debug_read_xcd_spans_sparse(unsigned long long* dst /* [32] *
 }
 #endif
 
+// (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
+hipError_t preload_sparse() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_sparse)); }
+
 }  // namespace m2s

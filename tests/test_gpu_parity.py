@@ -37,6 +37,23 @@ def test_pipelines_bit_identical(hiplib):
     a.close(); b.close()
 
 
+def test_prepare_loads_the_kernels_and_changes_nothing(hiplib):
+    """m2s_prepare(M2S_PREPARE_KERNELS) (code objects loaded ahead of the first conversion of the process: what the command line
+    does on its second thread) is idempotent, needs no scene, and a conversion after it gives the bytes of one without it."""
+    a, b = Converter(0), Converter(0)
+    a.prepare(Converter.PREPARE_KERNELS)
+    a.prepare(Converter.PREPARE_UPLOAD | Converter.PREPARE_EXPORT | Converter.PREPARE_KERNELS)
+    scene = synth.cube_sphere(24, tex_size=64)
+    outs = []
+    for c in (a, b):
+        c.set_resolution_hint(200)
+        c.upload_scene(scene)
+        outs.append((c.convert(200), c.download()))
+    assert outs[0][0] == outs[1][0] > 0
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    a.close(); b.close()
+
+
 def run_both(conv, oracle, scene, R, cap=None):
     conv.set_triangle_range(0, None)
     conv.upload_scene(scene)

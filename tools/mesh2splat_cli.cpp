@@ -79,7 +79,7 @@ int convert_one(const Options& o) {
     std::thread init([&] {
         const auto a = Clock::now();
         create_status = m2s_create((int)o.device, &ctx);
-        if (create_status == M2S_OK) (void)m2s_prepare(ctx, M2S_PREPARE_UPLOAD | M2S_PREPARE_EXPORT);   // pinned buffers: off the critical path
+        if (create_status == M2S_OK) (void)m2s_prepare(ctx, M2S_PREPARE_UPLOAD | M2S_PREPARE_EXPORT | M2S_PREPARE_KERNELS);   // pinned buffers, code objects: off the critical path
         create_ms = ms_between(a, Clock::now());
     });
     m2s_host_scene* scene = nullptr;
@@ -93,6 +93,7 @@ int convert_one(const Options& o) {
     auto die = [&](const char* what) { std::fprintf(stderr, "%s: %s\n", what, m2s_last_error(ctx)); m2s_destroy(ctx); m2s_free_host_scene(scene); return 1; };
     if (m2s_set_pipeline(ctx, o.pipeline) != M2S_OK) return die("set_pipeline");
     if (m2s_set_max_gaussians(ctx, o.cap) != M2S_OK) return die("set_max_gaussians");
+    (void)m2s_set_resolution_hint(ctx, o.R());   // the upload prepares for the conversion below
     if (m2s_upload_scene(ctx, m2s_host_scene_meshes(scene), m2s_host_scene_num_meshes(scene)) != M2S_OK) return die("upload");
     const auto t2 = Clock::now();
     uint64_t total = 0;
@@ -170,6 +171,7 @@ int rank_main(const Options& o, const m2s_host_scene* scene, Shared* sh, int ran
     (void)m2s_set_pipeline(ctx, o.pipeline);
     (void)m2s_set_max_gaussians(ctx, 0);
     (void)m2s_set_triangle_range(ctx, first[(size_t)rank], count[(size_t)rank]);
+    (void)m2s_set_resolution_hint(ctx, R);
     if (m2s_upload_scene(ctx, meshes, n_meshes) != M2S_OK) return fail("upload", m2s_last_error(ctx));
     const auto t2 = Clock::now();
     uint64_t total = 0;
@@ -347,6 +349,7 @@ int batch_on_device(const Options& o, const std::vector<std::pair<std::string, s
         { std::unique_lock<std::mutex> lk(slot_m); slot_cv.wait(lk, [&] { return !slot_busy[slot]; }); slot_busy[slot] = true; }
         Converted c; c.in = l.in; c.out = l.out; c.slot = slot; c.load_ms = l.load_ms;
         auto a = Clock::now();
+        (void)m2s_set_resolution_hint(ctx[slot], o.R());
         bool ok = m2s_upload_scene(ctx[slot], m2s_host_scene_meshes(l.scene), m2s_host_scene_num_meshes(l.scene)) == M2S_OK;
         c.upload_ms = ms_between(a, Clock::now());
         a = Clock::now();
