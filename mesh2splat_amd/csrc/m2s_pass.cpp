@@ -124,7 +124,9 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
             std::vector<uint32_t> cnt(sc.n_tri), first;
             HIPCHK(c, hipMemcpy(cnt.data(), c->d_cnt, (size_t)sc.n_tri * sizeof(uint32_t), hipMemcpyDeviceToHost));
             const uint32_t n_target = n_fused_waves(sc.n_tri);
-            const double ct = 214.0, cf = 140.0;
+            double ct = 214.0;
+            const double cf = 140.0;
+            if (const char* v = debug_env("M2S_BATCH_CT")) ct = atof(v);   // debug: A/B of the work model
             double total = 0.0;
             for (uint32_t t = 0; t < sc.n_tri; ++t) total += ct + cf * (double)cnt[t];
             const double quota = total / (double)n_target;

@@ -39,3 +39,13 @@ if t1.max() > 0:
     for x in range(8):
         m = xcd == x
         if m.any(): print(f"XCD {x}: workgroups {m.sum():5d} first start {t0[m].min():7.0f} last start {t0[m].max():7.0f} last end {t1[m].max():7.0f} entries {t[5][m].sum():9.0f} busy {(t1[m] - t0[m]).sum():11.0f}")
+
+if os.environ.get("TT_DETAIL"):
+    # what makes the slow workgroups slow: duration against the number of strips wave 0 shaded and the entries of the workgroup
+    tot, strips0, ent = t[0], t[4].astype(int), t[5]
+    for k in sorted(set(strips0)):
+        m = strips0 == k
+        print(f"wave 0 shaded {k} strips: {m.sum():5d} workgroups, total median {np.median(tot[m]):8.0f} max {tot[m].max():8.0f}, entries median {np.median(ent[m]):6.0f} max {ent[m].max():6.0f}, counts published after {np.median(t[11][m]):7.0f}")
+    q = np.argsort(-tot)[:8]
+    print("slowest:", [(int(tot[i]), int(strips0[i]), int(ent[i]), int(t[11][i]), int(t[2][i]), int(t[3][i])) for i in q], "(total, strips of wave 0, entries, until counts, wait entries, wait base)")
+    print("entries per workgroup: min %d p10 %d median %d p90 %d max %d; more than 1024: %d, more than 768: %d" % (ent.min(), np.percentile(ent, 10), np.median(ent), np.percentile(ent, 90), ent.max(), (ent > 1024).sum(), (ent > 768).sum()))
