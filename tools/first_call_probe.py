@@ -16,12 +16,20 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 scene = synth.cube_sphere(n, tex_size=2048)
 first, second, steady, warm, up = [], [], [], [], []
+# FCP_PRE=other: between the upload and the first conversion, ANOTHER context converts its own scene a few times (same kernel, other
+# buffers): separates "the GPU / the kernel's code is cold after an upload" from "this context's buffers are cold"
+pre = os.environ.get("FCP_PRE")
+other = None
+if pre:
+    other = Converter(0); other.set_resolution_hint(R); other.upload_scene(scene if pre == "same" else synth.cube_sphere(76, tex_size=2048))
 for _ in range(reps):
     c = Converter(0)
     c.set_resolution_hint(R)
     c.upload_scene(scene)
     u = c.last_upload_ms()
     up.append(u["total"]); warm.append(u["warm"])
+    if other is not None:
+        for _k in range(3): other.convert(R)
     t0 = time.perf_counter(); c.convert(R); first.append((time.perf_counter() - t0) * 1e3)
     t0 = time.perf_counter(); c.convert(R); second.append((time.perf_counter() - t0) * 1e3)
     s = []
