@@ -152,7 +152,8 @@ m2s_status m2s_convert_into(m2s_ctx* ctx, uint32_t R, void* d_records, uint64_t 
 /* lanes = 2: context-owned submissions alternate between two streams, each with its own look-back chain and record
  * buffer, so consecutive single-kernel conversions OVERLAP (the tail of one, where the GPU drains, with the head of the
  * next: C3 0.132 -> 0.108 ms per conversion at three in flight) instead of running back to back with ~8 us between
- * dependent kernels.  Records then alternate between two buffers; m2s_device_records / m2s_download / m2s_export_ply
+ * dependent kernels; multi-pass conversions likewise — the second lane has its own offsets / slice starts / per-triangle
+ * setup records, so k_count_scan of one conversion runs beside k_emit2 of the one before.  Records then alternate between two buffers; m2s_device_records / m2s_download / m2s_export_ply
  * follow the conversion last waited for.  Default 1 (one stream, one buffer). */
 m2s_status m2s_set_async_lanes(m2s_ctx* ctx, int lanes);
 m2s_status m2s_convert_submit(m2s_ctx* ctx, uint32_t R, void* d_records, uint64_t capacity_records, void* hip_stream);

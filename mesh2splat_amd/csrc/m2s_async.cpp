@@ -65,19 +65,33 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
         const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
         if (c->start_cap >= n_start && (multipass_v1() || c->d_setup)) {
-            HIPCHK(c, chain_behind_newest(st));
+            // odd slots of a two-lane context: the second lane, with work buffers of its own — nothing is shared with the
+            // conversion before it, so its k_count_scan runs beside that conversion's k_emit2
+            bool second_lane = false;
+            if (!d_records && (k & 1u) && c->lanes == 2 && !multipass_v1()) {
+                { const m2s_status s2 = ensure_second_lane(c); if (s2 != M2S_OK) return s2; }
+                { const m2s_status s2 = ensure_second_lane_multipass(c, n_start); if (s2 != M2S_OK) return s2; }
+                st = c->stream_b;
+                d_out = c->d_records_b;
+                second_lane = true;
+                sl.own_lane = 1;
+            }
+            if (!second_lane) HIPCHK(c, chain_behind_newest(st));
+            if (sl.own_lane >= 0) {
+                if (c->buf_R[sl.own_lane] != R) { c->buf_R[sl.own_lane] = R; ++c->buf_gen[sl.own_lane]; }
+                sl.gen = c->buf_gen[sl.own_lane];
+            }
             unsigned long long* res = &c->h_total[2 + 2 * k];
             res[0] = 0; res[1] = 0;
-            { const m2s_status ms_ = enqueue_multipass(c, R, (float4*)d_out, limit, false, res, st); if (ms_ != M2S_OK) return ms_; }
+            { const m2s_status ms_ = enqueue_multipass(c, R, (float4*)d_out, limit, false, res, st, second_lane); if (ms_ != M2S_OK) return ms_; }
             HIPCHK(c, hipEventRecord(sl.done, st));
             c->last_pipeline = M2S_PIPELINE_MULTIPASS;
-            c->last_submit_stream = st;
+            if (!second_lane) c->last_submit_stream = st;
             sl.prof = false;
             sl.sync_result = false;
             sl.limit = limit;
             sl.d_out = d_out;
-            sl.gen = c->buf_gen[0];
-            sl.st = st; sl.shared_work = true;
+            sl.st = st; sl.shared_work = !second_lane; sl.ri_gen = ri.gen;
             ++c->slot_count;
             return M2S_OK;
         }
@@ -110,22 +124,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         if ((k & 1u) && c->lanes == 2) {
             // odd slots: the second lane (allocated on first use).  Records of consecutive conversions then alternate
             // between two context-owned buffers; m2s_device_records / m2s_download follow the conversion last waited for.
-            if (!c->stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-            if (!c->d_chain_b) {
-                const size_t words = std::max<size_t>(c->chain_words, 1);
-                HIPCHK(c, hipMalloc((void**)&c->d_chain_b, words * sizeof(unsigned long long)));
-                HIPCHK(c, hipMemsetAsync(c->d_chain_b, 0, words * sizeof(unsigned long long), c->stream_b));
-            }
-            if (c->records_b_cap < c->records_cap) {
-                for (uint32_t q = 0; q < c->slot_count; ++q) {   // nothing may still be writing the old second buffer
-                    auto& o = c->slot[(c->slot_head + q) % M2S_MAX_IN_FLIGHT];
-                    if (o.own_lane == 1 && !o.sync_result) (void)hipEventSynchronize(o.done);
-                }
-                if (c->d_records_b) { (void)hipFree(c->d_records_b); c->d_records_b = nullptr; c->records_b_cap = 0; }
-                HIPCHK(c, hipMalloc(&c->d_records_b, c->records_cap * sizeof(m2s_gaussian)));
-                c->records_b_cap = c->records_cap;
-                ++c->buf_gen[1];
-            }
+            { const m2s_status s2 = ensure_second_lane(c); if (s2 != M2S_OK) return s2; }
             st = c->stream_b;
             chain = c->d_chain_b;
             d_out = c->d_records_b;

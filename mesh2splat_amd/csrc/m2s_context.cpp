@@ -25,7 +25,12 @@ void free_scene(m2s_ctx* c) {
     if (c->scene_arena) (void)hipFree(c->scene_arena);
     if (c->d_chain_b) (void)hipFree(c->d_chain_b);
     if (c->d_setup) (void)hipFree(c->d_setup);
+    if (c->d_off_b) (void)hipFree(c->d_off_b);
+    if (c->d_start_b) (void)hipFree(c->d_start_b);
+    if (c->d_setup_b) (void)hipFree(c->d_setup_b);
+    if (c->d_total_b) (void)hipFree(c->d_total_b);
     c->d_chain_b = nullptr; c->d_setup = nullptr;
+    c->d_off_b = nullptr; c->d_start_b = nullptr; c->start_b_cap = 0; c->d_setup_b = nullptr; c->d_total_b = nullptr;
     c->tri_mem = nullptr; c->scene_arena = nullptr;
     // everything below lived inside the arena
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;

@@ -87,6 +87,13 @@ struct m2s_ctx {
     unsigned long long* d_chain_b = nullptr;
     void* d_records_b = nullptr;
     uint64_t records_b_cap = 0;
+    // ... and multi-pass conversions too: the second lane's own offsets / slice starts / TriSetup records / counter (allocated at
+    // its first multi-pass submission), so that k_count_scan of conversion i + 1 runs beside k_emit2 of conversion i
+    uint32_t* d_off_b = nullptr;
+    uint32_t* d_start_b = nullptr;
+    size_t start_b_cap = 0;
+    void* d_setup_b = nullptr;
+    unsigned long long* d_total_b = nullptr;
     int pipeline = M2S_PIPELINE_AUTO;
     uint32_t epoch = 0;                     // launch counter of the fused kernel (tags the chain words)
 
@@ -193,7 +200,9 @@ uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
 bool multipass_v1();
 m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
-                             unsigned long long* h_res, hipStream_t st);
+                             unsigned long long* h_res, hipStream_t st, bool second_lane = false);
+m2s_status ensure_second_lane(m2s_ctx* c);                       // stream, chain and record buffer of the second lane
+m2s_status ensure_second_lane_multipass(m2s_ctx* c, uint32_t n_start);   // ... and its multi-pass work buffers
 m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hipStream_t st, uint64_t* out_total,
                     bool from_submit = false);
 }  // namespace m2s_host

@@ -206,10 +206,62 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
 }
 
 namespace m2s_host {
+// The second lane of asynchronous submissions (m2s_set_async_lanes(2)): its stream, its look-back chain and its record buffer,
+// allocated at its first use.  A record buffer that has become too small is replaced after every conversion still writing it has finished.
+m2s_status ensure_second_lane(m2s_ctx* c) {
+    if (!c->stream_b) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    if (!c->d_chain_b) {
+        const size_t words = std::max<size_t>(c->chain_words, 1);
+        HIPCHK(c, hipMalloc((void**)&c->d_chain_b, words * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_chain_b, 0, words * sizeof(unsigned long long), c->stream_b));
+    }
+    if (c->records_b_cap < c->records_cap) {
+        for (uint32_t q = 0; q < c->slot_count; ++q) {   // nothing may still be writing the old second buffer
+            auto& o = c->slot[(c->slot_head + q) % M2S_MAX_IN_FLIGHT];
+            if (o.own_lane == 1 && !o.sync_result) (void)hipEventSynchronize(o.done);
+        }
+        if (c->d_records_b) { (void)hipFree(c->d_records_b); c->d_records_b = nullptr; c->records_b_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_records_b, c->records_cap * sizeof(m2s_gaussian)));
+        c->records_b_cap = c->records_cap;
+        ++c->buf_gen[1];
+    }
+    return M2S_OK;
+}
+
+// ... and what a MULTI-PASS conversion on that lane works in: offsets, slice starts, TriSetup records, counter (second generation
+// of the pipeline only).  With these, k_count_scan of one conversion runs beside k_emit2 of the previous one.
+m2s_status ensure_second_lane_multipass(m2s_ctx* c, uint32_t n_start) {
+    const size_t np = std::max<size_t>(c->scene.n_tri, 1);
+    if (!c->d_off_b) HIPCHK(c, hipMalloc((void**)&c->d_off_b, (np + 1) * sizeof(uint32_t)));
+    if (!c->d_setup_b) HIPCHK(c, hipMalloc(&c->d_setup_b, setup_bytes(c->scene.n_tri)));
+    if (!c->d_total_b) HIPCHK(c, hipMalloc((void**)&c->d_total_b, sizeof(unsigned long long)));
+    if (c->start_b_cap < n_start) {
+        for (uint32_t q = 0; q < c->slot_count; ++q) {   // (a second-lane conversion in flight reads the old table)
+            auto& o = c->slot[(c->slot_head + q) % M2S_MAX_IN_FLIGHT];
+            if (o.own_lane == 1 && !o.sync_result) (void)hipEventSynchronize(o.done);
+        }
+        if (c->d_start_b) { (void)hipFree(c->d_start_b); c->d_start_b = nullptr; c->start_b_cap = 0; }
+        const size_t want = std::max<size_t>(std::max<size_t>(n_start, c->start_cap), 16384);
+        HIPCHK(c, hipMalloc((void**)&c->d_start_b, want * sizeof(uint32_t)));
+        c->start_b_cap = want;
+    }
+    return M2S_OK;
+}
+
 // enqueues the pipeline's kernels and the read-back of the counter into *h_res (pinned); no synchronisation
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
-                                    unsigned long long* h_res, hipStream_t st) {
+                                    unsigned long long* h_res, hipStream_t st, bool second_lane) {
     const SceneDev& sc = c->scene;
+    if (second_lane) {   // the second lane's own work buffers (ensure_second_lane_multipass); second generation only
+        uint32_t epoch;
+        HIPCHK(c, next_epoch(c, &epoch));
+        launch_count_scan(sc, R, c->d_off_b, c->d_start_b, emit2_slices(limit), c->d_chain_b, epoch, c->d_total_b, c->d_setup_b,
+                          reinterpret_cast<uint32_t*>(&h_res[1]), st);
+        launch_emit2(sc, R, c->d_off_b, c->d_start_b, c->d_total_b, limit, c->d_setup_b, d_out, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total_b, 8, hipMemcpyDeviceToHost, st));
+        return M2S_OK;
+    }
     if (multipass_v1()) {
         if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
         launch_count(sc, R, c->d_cnt, c->d_partials, st);

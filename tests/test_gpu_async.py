@@ -162,3 +162,51 @@ def test_two_lanes_overlap_gives_the_same_records(hiplib, oracle):
     c.submit(R)
     assert c.wait() == want_total
     c.close()
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_two_lanes_multipass_gives_the_same_records(hiplib, oracle, forced):
+    """The multi-pass pipeline on two lanes: the second lane has its own offsets / slice starts / TriSetup records / counter, so
+    k_count_scan of one conversion runs beside k_emit2 of the one before — same counters, same bytes, whichever lane the conversion
+    last waited for ran on; a change of density in between re-sizes the second lane's tables."""
+    scene = synth.cube_sphere(40, tex_size=64)         # 19 200 triangles; at R = 640 about 50 fragments each: AUTO takes the multi-pass pipeline
+    c = Converter(0)
+    if forced:
+        c.set_pipeline("multipass")
+    c.upload_scene(scene)
+    c.set_max_gaussians(0)
+    wants = {}
+    for R in (640, 900):
+        total = c.convert(R)
+        assert c.last_pipeline == "multipass"
+        rec = c.download()
+        ototal, orec, _ = oracle.convert(scene, R, cap=0)
+        assert total == ototal
+        assert_records_match(rec, orec, f"blocking R={R}")
+        wants[R] = (total, rec)
+    c.set_async_lanes(2)
+    for R in (640, 900, 640):
+        want_total, want = wants[R]
+        for depth in (2, 3, 4):
+            for _ in range(depth):
+                c.submit(R)
+            for i in range(9):
+                assert c.wait() == want_total
+                if i % 4 == 0:
+                    assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32))
+                c.submit(R)
+            for _ in range(depth):
+                assert c.wait() == want_total
+            assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32))
+    # alternating densities: every conversion waited for has its own counter, and the records follow it
+    seq = [640, 900, 900, 640, 640, 900]
+    for R in seq[:3]:
+        c.submit(R)
+    for i, R in enumerate(seq):
+        assert c.wait() == wants[R][0]
+        if i + 3 < len(seq):
+            c.submit(seq[i + 3])
+    c.set_async_lanes(1)
+    assert c.convert(640) == wants[640][0]
+    assert np.array_equal(c.download().view(np.uint32), wants[640][1].view(np.uint32))
+    c.close()
