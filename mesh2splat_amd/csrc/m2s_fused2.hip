@@ -503,7 +503,11 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     }
 
     // ======================= my TriShade, tskip and entries =======================
+#if defined(M2S_PROBE_STOP) && M2S_PROBE_STOP >= 2      // instruction-count probes (wrong output): tools/r4_valu.sh
+    if (false) {
+#else
     if (alive) {
+#endif
         if (cntc) {
             TriShade ts;
             if (uniform_mesh_w) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0w), uvb0, uvb1, ts);
@@ -572,6 +576,9 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         tk_cnt += F2_NOW() - tw0;
     }
     [[maybe_unused]] const unsigned long long tsl0 = F2_NOW();
+#if defined(M2S_PROBE_STOP) && M2S_PROBE_STOP >= 1
+    stream_total = 0;
+#endif
     while (alive && lds_load(&C.error) == 0) {
         uint32_t s = 0;
         if (lane == 0) s = __hip_atomic_fetch_add(&C.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
