@@ -1,0 +1,92 @@
+"""-m gpu: randomised differential parity.  Seeded random scenes (triangle soups of random size classes, cube-spheres, multi-mesh
+grids; with / without textures; 12- and 17-float vertices), random densities, random caps and triangle ranges — every pipeline
+(auto / team / wave / multipass / sparse) must give the SAME BYTES, and those bytes the oracle's records within tolerance and the
+oracle's counter exactly.  M2S_FUZZ_CASES (default 24) scales it; the report goes to gpurun_out/parity_fuzz.json."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from mesh2splat_amd import synth
+from mesh2splat_amd.converter import Converter
+from mesh2splat_amd.scene import Scene
+from parity import assert_records_match
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("M2S_FUZZ_CASES", "24"))
+PIPELINES = ("auto", "team", "wave", "multipass", "sparse")
+
+
+def make_case(k: int):
+    rng = np.random.default_rng(0x4D32 + k)
+    kind = rng.integers(0, 5) if k % 8 == 7 else rng.integers(0, 4)      # (every eighth case may be a large one)
+    tex = int(rng.choice([0, 16, 64]))
+    stride = int(rng.choice([12, 17]))
+    textures = synth.procedural_textures(tex, seed=int(rng.integers(1, 1 << 30))) if tex else None
+    if kind == 0:        # soup, size class from sub-pixel to hundreds of pixels
+        n = int(rng.integers(1, 6000))
+        scene = synth.random_soup(n, seed=int(rng.integers(1, 1 << 30)), tri_size=float(10.0 ** rng.uniform(-3.0, -0.3)), stride=stride, textures=textures)
+    elif kind == 1:
+        scene = synth.cube_sphere(int(rng.integers(1, 40)), tex_size=tex, seed=int(rng.integers(1, 1 << 30)), stride=stride)
+    elif kind == 2:
+        scene = synth.sphere_grid(int(rng.integers(1, 4)), n=int(rng.integers(1, 9)), tex_size=max(tex, 16))
+    elif kind == 4:      # enough triangles for 64-triangle batches (>= 172 k): the sparse form of the single-pass kernel runs here
+        if rng.random() < 0.5:
+            scene = synth.random_soup(int(rng.integers(180_000, 320_000)), seed=int(rng.integers(1, 1 << 30)), tri_size=float(10.0 ** rng.uniform(-3.0, -1.7)), stride=stride, textures=textures)
+        else:
+            scene = synth.cube_sphere(int(rng.integers(121, 180)), tex_size=tex, seed=int(rng.integers(1, 1 << 30)), stride=stride)
+    else:                # two soups of very different triangle sizes in one scene (cumulative bounding box, mixed kinds per wave)
+        a = synth.random_soup(int(rng.integers(1, 3000)), seed=int(rng.integers(1, 1 << 30)), tri_size=float(10.0 ** rng.uniform(-3.0, -1.5)), stride=stride, textures=textures, name="a")
+        b = synth.random_soup(int(rng.integers(1, 200)), seed=int(rng.integers(1, 1 << 30)), tri_size=float(10.0 ** rng.uniform(-1.0, 0.0)), stride=stride, name="b")
+        scene = Scene(a.meshes + b.meshes)
+    R = int(rng.choice([int(rng.integers(1, 64)), int(rng.integers(64, 700)), int(rng.choice([255, 256, 257, 511, 512, 513]))]))
+    cap = [None, 0, int(rng.integers(1, 5000))][int(rng.integers(0, 3))]
+    T = scene.n_triangles
+    rng_range = None
+    if rng.random() < 0.3 and T > 2:
+        f = int(rng.integers(0, T - 1))
+        rng_range = (f, int(rng.integers(1, T - f + 1)))
+    return scene, R, cap, rng_range, {"kind": int(kind), "tex": tex, "stride": stride, "triangles": T, "meshes": scene.n_meshes, "R": R, "cap": cap, "range": rng_range}
+
+
+def test_random_scenes_all_pipelines_same_bytes_and_oracle(hiplib, oracle):
+    convs = {}
+    for p in PIPELINES:
+        convs[p] = Converter(0)
+        convs[p].set_pipeline(p)
+    report, t0 = [], time.time()
+    for k in range(CASES):
+        scene, R, cap, tri_range, desc = make_case(k)
+        first, count = tri_range if tri_range else (0, None)
+        ototal, orec, _ = oracle.convert(scene, R, cap=cap, tri_first=first, tri_count=count)
+        ref_bytes = None
+        ran = {}
+        for p, c in convs.items():
+            c.set_triangle_range(first, count)
+            c.upload_scene(scene)
+            c.set_max_gaussians(-1 if cap is None else cap)
+            total = c.convert(R)
+            rec = c.download()
+            assert total == ototal, (k, p, desc, total, ototal)
+            ran[p] = c.last_pipeline
+            if ref_bytes is None:
+                ref_bytes = rec
+                bit = assert_records_match(rec, orec[:rec.shape[0]], f"case {k} {desc}")
+            else:
+                assert rec.shape == ref_bytes.shape and np.array_equal(rec.view(np.uint32), ref_bytes.view(np.uint32)), (k, p, desc)
+        desc.update({"gaussians": int(ototal), "stored": int(ref_bytes.shape[0]), "frac_bit_identical_to_oracle": bit, "ran": ran})
+        report.append(desc)
+    for c in convs.values():
+        c.close()
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fuzz.json")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        import hashlib
+        from mesh2splat_amd import _lib
+        with open(out, "w") as fh:
+            json.dump({"cases": len(report), "seconds": time.time() - t0, "library_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16],
+                       "gaussians_total": int(sum(r["gaussians"] for r in report)), "cases_detail": report}, fh, indent=0)
+    except OSError:
+        pass
