@@ -87,6 +87,10 @@ def test_random_scenes_all_pipelines_same_bytes_and_oracle(hiplib, oracle):
         from mesh2splat_amd import _lib
         with open(out, "w") as fh:
             json.dump({"cases": len(report), "seconds": time.time() - t0, "library_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16],
-                       "gaussians_total": int(sum(r["gaussians"] for r in report)), "cases_detail": report}, fh, indent=0)
+                       "gaussians_total": int(sum(r["gaussians"] for r in report)),
+                       "auto_ran": {p: sum(1 for r in report if r["ran"]["auto"] == p) for p in ("team", "wave", "multipass", "sparse")},
+                       "forced_sparse_ran_sparse": sum(1 for r in report if r["ran"]["sparse"] == "sparse"),
+                       "min_frac_bit_identical_to_oracle": min(r["frac_bit_identical_to_oracle"] for r in report),
+                       "cases_detail": report if len(report) <= 300 else report[:300]}, fh, indent=0)
     except OSError:
         pass
