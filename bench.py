@@ -772,7 +772,7 @@ def main():
     res = None
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        kname = {"team": "k_fused2", "wave": "k_fused", "sparse": "k_sparse"}.get(last_pipeline, "k_emit2")
+        kname = {"team": "k_fused2", "lean": "k_fused3", "wave": "k_fused", "sparse": "k_sparse"}.get(last_pipeline, "k_emit2")
         emit_ms = kms[dom]
         # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.
@@ -790,6 +790,7 @@ def main():
                                    (f"I-3 cube-sphere n={n} ({tri_per_mesh} triangles/mesh) x {world} mesh(es), "
                                     f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
+                       "pipeline": last_pipeline,
                        "rccl_ranks": (dist.get_world_size() if multi else 1),
                        "exchange": ("per step: 8-byte counter all-gather, two in flight; transport: " + exchange.transport) if multi else "none (single GPU)",
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",

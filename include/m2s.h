@@ -372,9 +372,13 @@ enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
        M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2), k_fused where a workgroup
                                 does not fit its LDS stream */,
        M2S_PIPELINE_SPARSE = 4 /* always the sparse form of the single-pass kernel (k_sparse) where the scene is large enough for
-                                  it (>= ~172 k triangles), k_fused2 / k_fused where a workgroup does not fit its LDS stream */ };
+                                  it (>= ~172 k triangles), k_fused2 / k_fused where a workgroup does not fit its LDS stream */,
+       M2S_PIPELINE_LEAN = 5 /* the team kernel in its lean form (k_fused3: four waves per SIMD; shades triangles of at most 8 x 8
+                                pixels itself and defers the rest to k_emit_big) where the scene allows it — every mesh samples
+                                three equally sized maps or none —, else as TEAM.  AUTO prefers it to k_fused2 under the same
+                                condition and returns to k_fused2 at an R where many triangles were deferred */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
-/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2) or _SPARSE (k_sparse); 0 before any. */
+/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2), _LEAN (k_fused3) or _SPARSE (k_sparse); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

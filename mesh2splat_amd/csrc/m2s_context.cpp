@@ -41,7 +41,8 @@ void free_scene(m2s_ctx* c) {
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
     c->warm_R = 0;
-    c->sparse_off_R = c->team_off_R = UINT32_MAX;
+    c->sparse_off_R = c->team_off_R = c->lean_off_R = UINT32_MAX;
+    c->lean_ok = false;
     c->scene = SceneDev{};
     c->has_scene = false;
 }
@@ -60,6 +61,7 @@ m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     ri.band_slot = (int)c->rinfo.size();
     ri.sparse_off = R >= c->sparse_off_R;
     ri.team_off = R >= c->team_off_R;
+    ri.lean_off = R >= c->lean_off_R;
     return c->rinfo.emplace(R, ri).first->second;
 }
 
@@ -217,7 +219,7 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
 
 m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (!c) return M2S_ERR_INVALID;
-    if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_SPARSE) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_LEAN) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
         c->rinfo.clear();

@@ -32,6 +32,7 @@ struct m2s_ctx {
     uint32_t* d_mesh_first = nullptr;
     uint32_t n_meshes_total = 0;
     bool has_scene = false;
+    bool lean_ok = false;                   // every mesh of the scene samples its combo texture or no map at all: k_fused3 may run
     uint64_t range_first = 0, range_count = UINT64_MAX;
 
     // work buffers (sized by the scene)
@@ -55,6 +56,7 @@ struct m2s_ctx {
         bool sparse = false;       // AUTO: fewer fragments than triangles, the sparse form of the single-pass kernel (k_sparse)
         bool sparse_off = false;   // k_sparse reported a workgroup that did not fit its LDS stream: use k_fused2
         bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
+        bool lean_off = false;     // k_fused3 overflowed its LDS stream or deferred many triangles at this R: use k_fused2
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
         bool bands_ready = false;  // the run table of this R (slot band_slot of d_bands: where every run's output starts) is in place ...
@@ -64,7 +66,7 @@ struct m2s_ctx {
     };
     // smallest R at which a workgroup of k_sparse / k_fused2 did not fit its LDS stream: a property of the SCENE (fragments grow
     // with R), so a new R above it starts with the next form at once instead of re-discovering the overflow
-    uint32_t sparse_off_R = UINT32_MAX, team_off_R = UINT32_MAX;
+    uint32_t sparse_off_R = UINT32_MAX, team_off_R = UINT32_MAX, lean_off_R = UINT32_MAX;   // (lean: k_fused3 -> k_fused2)
     uint32_t rinfo_gen = 0;
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene: from the exact count m2s_upload_scene takes (warm_scene), refreshed by every conversion
@@ -192,6 +194,7 @@ m2s_status ensure_records(m2s_ctx* c, uint64_t want);
 m2s_status ensure_stage(m2s_ctx* c);
 // m2s_pass.cpp
 bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
+bool use_lean(const m2s_ctx* c, const m2s_ctx::RInfo& ri);   // the team kernel in its lean form (k_fused3)
 bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
 m2s::BatchTable batches_for(const m2s_ctx* c);

@@ -718,18 +718,26 @@ __device__ __forceinline__ T ld_plane(const T* base, uint32_t t) {
 // descriptor fields when the pointer is wave-uniform, even after the kernel's own record stores (which otherwise make
 // every later global read a vector load: alias analysis cannot tell the records from the table).
 
-template <class MP, class TS = TriShade>   // TS: TriShade, or the 64-byte TriShadeS of the sparse kernel (same field names)
+// kComboOnly (k_fused3): the caller guarantees that the mesh samples through its combo texture or has no map at all; the
+// separate-maps sampler is then not compiled into the caller (it is what sets the register count of the fragment stage).
+template <class MP, class TS = TriShade, bool kComboOnly = false>   // TS: TriShade, or the 64-byte TriShadeS (same field names)
 __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, int x, int y, MP mp,
                                                const TS& ts, float4 rec[6], unsigned long long* stamps = nullptr,
                                                const float2* uvl = nullptr /* (u0,v0), (u1-u0,v1-v0), (u2-u0,v2-v0) kept by the caller */) {
     // screen-linear barycentrics from the exact integer edge functions, evaluated relative to the
     // triangle's bbox origin pixel: E_i(x,y) = E_i(x0,y0) + a_i*256*(x-x0) + b_i*256*(y-y0)
     const int dx256 = (x - (int)(ts.org & 0xFFFu)) * 256, dy256 = (y - (int)(ts.org >> 12)) * 256;
-    const long long E1 = ts.e1 + (long long)ts.a1 * dx256 + (long long)ts.b1 * dy256;
-    const long long E2 = ts.e2 + (long long)ts.a2 * dx256 + (long long)ts.b2 * dy256;
     float l1, l2;
-    {
-#pragma clang fp contract(off)
+    if constexpr (sizeof(ts.e1) == 4) {
+        // TriShadeS: |a|, |b| <= 2304 and the box is at most 8 x 8 pixels, so every edge value inside it stays below 2^31 (at a
+        // covered pixel: 0 <= E <= area2 <= 2304^2): 32-bit integers, and (float)int32 rounds once like i64_to_f32
+        const int E1 = ts.e1 + (int)ts.a1 * dx256 + (int)ts.b1 * dy256;
+        const int E2 = ts.e2 + (int)ts.a2 * dx256 + (int)ts.b2 * dy256;
+        l1 = (float)E1 * ts.inva;
+        l2 = (float)E2 * ts.inva;
+    } else {
+        const long long E1 = ts.e1 + (long long)ts.a1 * dx256 + (long long)ts.b1 * dy256;
+        const long long E2 = ts.e2 + (long long)ts.a2 * dx256 + (long long)ts.b2 * dy256;
         l1 = i64_to_f32(E1) * ts.inva;
         l2 = i64_to_f32(E2) * ts.inva;
     }
@@ -782,7 +790,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
         col[0] = acc[0]; col[1] = acc[1]; col[2] = acc[2]; col[3] = acc[3];
         nrm[0] = acc[4]; nrm[1] = acc[5]; nrm[2] = acc[6];
         rough = acc[7]; metal = acc[8];
-    } else {
+    } else if constexpr (!kComboOnly) {
         // separate maps (sizes differ, or a map is missing): the sampling state of every present map first, then ALL texel
         // reads (up to 24), then the filters — one memory round trip for the whole texture stage (round 3; was up to six)
         TexState sa, sn, sm;

@@ -159,6 +159,11 @@ struct TicketSets { uint32_t* use; uint32_t* clear; };
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const RunInfo& runs, const BatchTable& batches, const TicketSets& tickets, hipStream_t st);
+// lean form of the team kernel (m2s_fused3.hip): same units, same run tables, same output; only for scenes whose meshes all sample
+// a combo texture or no map at all (m2s_ctx::lean_ok); triangles larger than an 8 x 8 pixel box are deferred to k_emit_big
+void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
+                   unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
+                   const RunInfo& runs, const BatchTable& batches, hipStream_t st);
 // sparse form of the single-pass kernel (m2s_sparse.hip); `runs` as for launch_fused2, in ITS units (512 triangles)
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
@@ -208,6 +213,7 @@ void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long l
 // a PROCESS).  These make it happen now — hipFuncGetAttributes on one kernel of the file — without launching anything:
 // m2s_upload_scene asks for the pipeline it has just decided on, m2s_prepare(M2S_PREPARE_KERNELS) for all of them.
 hipError_t preload_fused2();
+hipError_t preload_fused3();
 hipError_t preload_sparse();
 hipError_t preload_fused();
 hipError_t preload_multipass();

@@ -37,6 +37,14 @@ namespace m2s_host {
 bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
     return !(c->pipeline == M2S_PIPELINE_WAVE || ri.team_off);
 }
+// the team kernel in its lean form (m2s_fused3.hip): LEAN uses it where the scene allows it (m2s_ctx::lean_ok) unless a launch at
+// this R overflowed its LDS stream; AUTO only for scenes of more than one generation of workgroups (64 triangles per wave: a fourth
+// workgroup per CU does nothing for a launch that fits the GPU once — C2 stand-in 0.0354 (k_fused2) vs 0.0362 ms, config 3 0.1170 vs
+// 0.1138, profiles/r05/ab_lean_team_kernel.log) and while few triangles are deferred
+bool use_lean(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    if (!(use_team(c, ri) && c->lean_ok && !ri.lean_off) || debug_on("M2S_NO_LEAN")) return false;
+    return c->pipeline == M2S_PIPELINE_LEAN || (c->pipeline == M2S_PIPELINE_AUTO && fused_tpw(c->scene.n_tri) == 64u);
+}
 // ... or its sparse form (m2s_sparse.hip): meshes with fewer fragments than triangles, large enough for 64-triangle batches
 bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
     return (c->pipeline == M2S_PIPELINE_SPARSE || (c->pipeline == M2S_PIPELINE_AUTO && ri.sparse)) && !ri.sparse_off &&
@@ -159,6 +167,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     if (!debug_on("M2S_NO_PRELOAD")) {
         if (!single) { (void)preload_multipass(); }
         else if (use_sparse(c, ri)) { (void)preload_sparse(); (void)preload_fused2(); }   // (the sparse form falls back to the team on a stream overflow)
+        else if (use_lean(c, ri)) { (void)preload_fused3(); }
         else if (use_team(c, ri)) { (void)preload_fused2(); }
         else { (void)preload_fused(); }
         (void)hipGetLastError();
@@ -374,9 +383,10 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         // counter and its two status words straight into pinned host memory.
         uint32_t any_big = 0, err = 0;
         bool wrote_bands = false;
-        for (int attempt = 0; attempt < 3; ++attempt) {
+        for (int attempt = 0; attempt < 4; ++attempt) {
             const bool sparse = use_sparse(c, ri);
             const bool team = !sparse && use_team(c, ri);
+            const bool lean = team && use_lean(c, ri);
             c->h_total[0] = 0;
             c->h_total[1] = 0;
             uint32_t epoch;
@@ -385,6 +395,8 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                       c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), st);
+            else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), tickets_for(c, 0), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
@@ -395,16 +407,31 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
-            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
             if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
             if (err && debug_on("M2S_DEBUG"))
-                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : team ? "team" : "wave", err, R);
+                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : lean ? "lean" : team ? "team" : "wave", err, R);
+            if (lean && !err && any_big && c->pipeline == M2S_PIPELINE_AUTO) {
+                // k_fused3 shades only triangles of at most 8 x 8 pixels itself.  A few deferred ones are what k_emit_big is for;
+                // MANY mean the scene at this R belongs to k_fused2, which expands triangles of up to 16 pixel rows in the
+                // workgroup: remember that (for this R and every larger one) and convert again
+                uint32_t meta[4] = { 0, 0, 0, 0 };
+                HIPCHK(c, hipMemcpyAsync(meta, c->d_bigmeta, sizeof meta, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (meta[0] > 64u && (uint64_t)meta[0] * 256u > sc.n_tri) {
+                    ri.lean_off = true;
+                    c->lean_off_R = std::min(c->lean_off_R, R);
+                    HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, sizeof meta, st));
+                    continue;
+                }
+            }
             if (!(err && (team || sparse))) break;
             // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
             // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
             // launch listed, try again.
             // (error value 2 = "entries do not fit": true of every larger R as well)
             if (sparse) { ri.sparse_off = true; if ((err & 0xFu) == 2u) c->sparse_off_R = std::min(c->sparse_off_R, R); }
+            else if (lean) { ri.lean_off = true; if ((err & 0xFu) == 2u) c->lean_off_R = std::min(c->lean_off_R, R); }
             else { ri.team_off = true; if ((err & 0xFu) == 2u) c->team_off_R = std::min(c->team_off_R, R); }
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
         }

@@ -256,6 +256,10 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
         for (int k = 0; k < 3; ++k) if (mesh_tex[i][k] >= 0) p.tex[k] = tex_plan[mesh_tex[i][k]].d;
         if (mesh_combo[i] >= 0) p.combo = combo_plan[mesh_combo[i]].d;
     }
+    // k_fused3's fragment stage has no sampler for separately sized maps: it may run if every mesh has a combo texture or no map
+    c->lean_ok = true;
+    for (uint32_t i = 0; i < n_meshes; ++i)
+        if (mesh_combo[i] < 0 && (mesh_tex[i][0] >= 0 || mesh_tex[i][1] >= 0 || mesh_tex[i][2] >= 0)) c->lean_ok = false;
     c->d_meshes = (MeshParams*)(A + o_meshes);
     c->d_mesh_first = (uint32_t*)(A + o_mesh_first);
     HIPCHK(c, hipMemcpyAsync(c->d_meshes, mp.data(), mp.size() * sizeof(MeshParams), hipMemcpyHostToDevice, c->stream));
@@ -308,7 +312,7 @@ m2s_status m2s_prepare(m2s_ctx* c, uint32_t flags) {
         for (int k = 0; k < 2; ++k)
             if (!c->h_export[k]) HIPCHK(c, hipHostMalloc((void**)&c->h_export[k], m2s_ply::kChunkRows * sizeof(m2s_gaussian), hipHostMallocDefault));
     if ((flags & M2S_PREPARE_KERNELS) && !debug_on("M2S_NO_PRELOAD")) {
-        HIPCHK(c, preload_fused2()); HIPCHK(c, preload_sparse()); HIPCHK(c, preload_fused()); HIPCHK(c, preload_multipass());
+        HIPCHK(c, preload_fused2()); HIPCHK(c, preload_fused3()); HIPCHK(c, preload_sparse()); HIPCHK(c, preload_fused()); HIPCHK(c, preload_multipass());
         HIPCHK(c, preload_export()); HIPCHK(c, preload_prepass()); HIPCHK(c, preload_sort());
     }
     return M2S_OK;

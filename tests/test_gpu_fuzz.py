@@ -1,7 +1,7 @@
 """-m gpu: randomised differential parity.  Seeded random scenes (triangle soups of random size classes, cube-spheres, multi-mesh
 grids; with / without textures; 12- and 17-float vertices), random densities, random caps and triangle ranges — every pipeline
-(auto / team / wave / multipass / sparse) must give the SAME BYTES, and those bytes the oracle's records within tolerance and the
-oracle's counter exactly.  M2S_FUZZ_CASES (default 24) scales it; the report goes to gpurun_out/parity_fuzz.json."""
+(auto / team / lean / wave / multipass / sparse) must give the SAME BYTES, and those bytes the oracle's records within tolerance and the
+oracle's counter exactly.  M2S_FUZZ_CASES (default 200) scales it; the report goes to gpurun_out/parity_fuzz.json."""
 import json
 import os
 import time
@@ -15,8 +15,8 @@ from mesh2splat_amd.scene import Scene
 from parity import assert_records_match
 
 pytestmark = pytest.mark.gpu
-CASES = int(os.environ.get("M2S_FUZZ_CASES", "24"))
-PIPELINES = ("auto", "team", "wave", "multipass", "sparse")
+CASES = int(os.environ.get("M2S_FUZZ_CASES", "200"))
+PIPELINES = ("auto", "team", "lean", "wave", "multipass", "sparse")
 
 
 def make_case(k: int):
@@ -88,8 +88,9 @@ def test_random_scenes_all_pipelines_same_bytes_and_oracle(hiplib, oracle):
         with open(out, "w") as fh:
             json.dump({"cases": len(report), "seconds": time.time() - t0, "library_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16],
                        "gaussians_total": int(sum(r["gaussians"] for r in report)),
-                       "auto_ran": {p: sum(1 for r in report if r["ran"]["auto"] == p) for p in ("team", "wave", "multipass", "sparse")},
+                       "auto_ran": {p: sum(1 for r in report if r["ran"]["auto"] == p) for p in ("team", "lean", "wave", "multipass", "sparse")},
                        "forced_sparse_ran_sparse": sum(1 for r in report if r["ran"]["sparse"] == "sparse"),
+                       "forced_lean_ran_lean": sum(1 for r in report if r["ran"]["lean"] == "lean"),
                        "min_frac_bit_identical_to_oracle": min(r["frac_bit_identical_to_oracle"] for r in report),
                        "cases_detail": report if len(report) <= 300 else report[:300]}, fh, indent=0)
     except OSError:
