@@ -156,8 +156,7 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     else if (lean) launch_fused3(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                             c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c), st);
     else if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c),
-                            tickets_for(c, second_lane ? 1 : 0), st);
+                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c), st);
     else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                       c->d_biglist, c->d_bigmeta, st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
@@ -192,7 +191,7 @@ m2s_status m2s_convert_wait(m2s_ctx* c, uint64_t* out_total) {
         memcpy(c->last_ms, sl.ms, sizeof sl.ms);
         return M2S_OK;
     }
-    HIPCHK(c, hipEventSynchronize(sl.done));
+    HIPCHK(c, wait_event(sl.done));
     const uint64_t total = c->h_total[2 + 2 * k];
     const uint32_t any_big = (uint32_t)(c->h_total[3 + 2 * k] & 0xFFFFFFFFull), err = (uint32_t)(c->h_total[3 + 2 * k] >> 32);
     memset(c->last_ms, 0, sizeof c->last_ms);

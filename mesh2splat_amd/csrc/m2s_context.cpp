@@ -35,8 +35,8 @@ void free_scene(m2s_ctx* c) {
     // everything below lived inside the arena
     c->d_meshes = nullptr; c->d_mesh_first = nullptr;
     c->d_cnt = c->d_off = c->d_partials = nullptr;
-    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->run_table_words = 0;
-    c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0; c->d_tickets = nullptr;
+    c->d_chain = nullptr; c->d_biglist = nullptr; c->d_bigmeta = nullptr; c->d_bands = nullptr; c->run_table_words = 0; c->d_run_order = nullptr; c->run_order_unit = 0;
+    c->d_batch_first = nullptr; c->n_batch_tab = 0; c->chain_words = 0;
     c->rinfo.clear();
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
@@ -64,6 +64,23 @@ m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     ri.lean_off = R >= c->lean_off_R;
     return c->rinfo.emplace(R, ri).first->second;
 }
+
+static bool spin_waits() { static const bool on = !debug_on("M2S_NO_SPIN"); return on; }
+template <class Query, class Block>
+static hipError_t spin_then_block(Query query, Block block) {
+    if (spin_waits()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t i = 0;; ++i) {
+            const hipError_t e = query();
+            if (e != hipErrorNotReady) return e;
+            if ((i & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+        }
+        (void)hipGetLastError();   // (hipErrorNotReady is sticky in hipGetLastError)
+    }
+    return block();
+}
+hipError_t wait_stream(hipStream_t st) { return spin_then_block([&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); }); }
+hipError_t wait_event(hipEvent_t ev) { return spin_then_block([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); }); }
 
 // every conversion still in flight has finished when this returns (their slots stay queued for m2s_convert_wait)
 void drain_in_flight(m2s_ctx* c) {

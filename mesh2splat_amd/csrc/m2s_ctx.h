@@ -74,11 +74,11 @@ struct m2s_ctx {
     uint32_t warm_R = 0;                    // the R the resident scene was prepared for
     unsigned long long* d_bands = nullptr;  // kBandSlots run tables of run_table_words words each (RunInfo, m2s_device.h)
     size_t run_table_words = 0;
+    uint32_t* d_run_order = nullptr;        // dispatch order of the runs (launch_run_order), built by warm_scene from the exact counts ...
+    uint32_t run_order_unit = 0, run_order_shift = 0;   // ... for runs of (1 << shift) units of this many triangles (0: none)
     uint32_t* d_batch_first = nullptr;      // work-balanced batches of k_fused2 (small scenes; built from the first exact count)
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
-    uint32_t* d_tickets = nullptr;          // 4 ticket sets (TicketSets, m2s_device.h): two per lane, used alternately
-    uint32_t ticket_turn[2] = { 0, 0 };     // per lane: which of its two sets the next persistent launch draws from
     void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
@@ -185,6 +185,11 @@ inline m2s_status fail(m2s_ctx* c, m2s_status s, const std::string& msg) {
 constexpr int kBandSlots = kBandSlotsMax;
 
 // m2s_context.cpp
+// Waiting for a conversion.  The runtime's hipStreamSynchronize / hipEventSynchronize hand the caller back 10-18 us after the last
+// kernel has finished — 8-13 % of a 0.12 ms conversion, the reference's glFinish (ConversionPass.cpp:54).  These poll the same
+// completion signal (hipStreamQuery / hipEventQuery: the stream's own "all work done") for up to 400 us and only then block.
+hipError_t wait_stream(hipStream_t st);
+hipError_t wait_event(hipEvent_t ev);
 void free_scene(m2s_ctx* c);
 m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R);
 void drain_in_flight(m2s_ctx* c);          // every conversion still in flight has finished when this returns
@@ -198,7 +203,6 @@ bool use_lean(const m2s_ctx* c, const m2s_ctx::RInfo& ri);   // the team kernel 
 bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
 m2s::BatchTable batches_for(const m2s_ctx* c);
-m2s::TicketSets tickets_for(m2s_ctx* c, int lane);   // the ticket sets of the next launch on that lane's chain (advances the turn)
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
 bool multipass_v1();
 m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident

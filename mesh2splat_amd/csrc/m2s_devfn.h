@@ -680,6 +680,9 @@ __device__ __forceinline__ void combo_issue(MP mp, TD t, float uf, float vf, con
     cf.a1 = ld_combo(gb, tlo.o1);
     cf.b0 = ld_combo(gb, thi.o0);
     cf.b1 = ld_combo(gb, thi.o1);
+#ifdef M2S_FUSED3_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 __device__ __forceinline__ void combo_finish(ComboFetch& cf, float out[9]) {
     ComboTap& tlo = cf.tlo;

@@ -97,6 +97,13 @@ void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long
 // where the output of every RUN (1 << shift units of `unit` = 256 / 512 triangles) starts, from launch_count's counts and the
 // scanned partial sums: the table a launch in runs reads (RunInfo::base)
 void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, uint32_t shift, unsigned long long* run_base, hipStream_t st);
+// Dispatch order of the runs of a launch in runs: order[slot] = run, runs sorted by fragment count, heaviest first (LPT).  A launch
+// lasts until its last workgroup has finished; in mesh order the units dispatched last are as heavy as any (config 3: 9 ... 1592
+// fragments per unit), so the GPU drains for a whole heavy workgroup's lifetime.  With the light runs last the drain is short.  Runs
+// are independent (the look-back chain restarts at every run, whose base comes from the table), so any order is correct.
+// n_slots = runs rounded up to whole groups of eight (slots past the last run map to themselves: their workgroups exit at once).
+void launch_run_order(const unsigned long long* run_base, uint32_t n_runs, const unsigned long long* total, uint32_t* order, uint32_t n_slots, hipStream_t st);
+inline uint32_t run_order_slots(uint32_t n_units, uint32_t shift) { return ((n_units + (8u << shift) - 1u) / (8u << shift)) * 8u; }
 void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
                     uint32_t n_start, hipStream_t st);
 void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
@@ -128,6 +135,7 @@ struct RunInfo {
     const unsigned long long* base;  // launch in runs: base[j] = record index at which the output of run j starts; else nullptr
     unsigned long long* out;         // launch without runs: out[j] = the same, recorded for the next launches (or nullptr)
     uint32_t shift;                  // log2 of the run length in units
+    const uint32_t* order;           // launch in runs: dispatch slot -> run (heaviest runs first, see launch_run_order); nullptr: identity
 };
 // run length for a scene of n_units units (0: too few units for runs to make sense — plain order): 32 units (8192 triangles of
 // k_fused2) where that still leaves every XCD four runs, else 16 or 8.  Measured on config 3 (3916 units), kernel time / read
@@ -150,15 +158,9 @@ struct BatchTable {
 // units (workgroups of 256 triangles) of k_fused2 for a scene of n_tri triangles that can be converted in runs (0: too small for
 // 64-triangle batches)
 uint32_t fused2_band_workgroups(uint32_t n_tri);
-// Ticket counters of the persistent form of the single-pass kernels (k_fused2p, see m2s_fused2.hip): eight counters per set, one
-// 128-byte line each.  A launch draws from `use` (all zero when it starts) and zeroes `clear`, the set the NEXT launch on the same
-// chain uses (launches that share a chain are serialised, so that set is idle); use == nullptr: launch the one-unit-per-workgroup form.
-constexpr uint32_t kTicketStride = 32;                   // dwords between two counters
-constexpr size_t kTicketSetBytes = 8 * kTicketStride * sizeof(uint32_t);
-struct TicketSets { uint32_t* use; uint32_t* clear; };
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const RunInfo& runs, const BatchTable& batches, const TicketSets& tickets, hipStream_t st);
+                   const RunInfo& runs, const BatchTable& batches, hipStream_t st);
 // lean form of the team kernel (m2s_fused3.hip): same units, same run tables, same output; only for scenes whose meshes all sample
 // a combo texture or no map at all (m2s_ctx::lean_ok); triangles larger than an 8 x 8 pixel box are deferred to k_emit_big
 void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,

@@ -78,14 +78,15 @@ void load_rccl() {
     // process), then an RCCL that is already in the process (PyTorch's), then the system one
     if (const char* e = std::getenv("M2S_RCCL_PATH")) {
         r.handle = dlopen(e, RTLD_NOW | RTLD_LOCAL);
-        if (!r.handle) { r.error = std::string("M2S_RCCL_PATH: ") + (dlerror() ? dlerror() : "could not be loaded"); return; }
+        // (dlerror() clears the error it returns: ask once — ADVICE r4: the second call returned NULL into std::string's operator+)
+        if (!r.handle) { const char* de = dlerror(); r.error = std::string("M2S_RCCL_PATH: ") + (de ? de : "could not be loaded"); return; }
         r.path = e;
     }
     const char* names[] = { "librccl.so.1", "librccl.so" };
     for (const char* n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     const char* paths[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
     for (const char* n : paths) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!r.handle) { const char* de = dlerror(); r.error = std::string("librccl could not be loaded: ") + (de ? de : "?"); return; }
     auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + s; return p; };
     r.GetUniqueId = reinterpret_cast<int (*)(ncclUniqueId_t*)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<int (*)(ncclComm_p*, int, ncclUniqueId_t, int)>(sym("ncclCommInitRank"));

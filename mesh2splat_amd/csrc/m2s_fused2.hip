@@ -46,8 +46,7 @@ constexpr uint32_t kWaitLimit = 1u << 24;  // LDS polls before giving up
 #ifdef M2S_TIMING
 // debug build only: per-workgroup cycle counts of wave 0, read back by tools/team_timing.py
 //   [0] total, [1] waiting for counts, [2] waiting for entries, [3] waiting for the base, [4] strips, [5] entries of the workgroup,
-//   [6] start and [7] end of wave 0 (s_memrealtime: 100 MHz, common to all XCDs), [8] XCD (blockIdx & 7),
-//   [9] k_fused2p: at the unit's barrier, [10] resolving the next ticket, [11] until the counts are published, [12] unit number of the workgroup
+//   [6] start and [7] end of wave 0 (s_memrealtime: 100 MHz, common to all XCDs), [8] XCD (blockIdx & 7), [11] until the counts are published
 constexpr int kF2TimingSlots = 16, kF2TimingBlocks = 8192;
 __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 #define F2_T(slot, v) do { if (wave == 0 && lane == 0 && lb < kF2TimingBlocks) g_f2_timing[(slot) * kF2TimingBlocks + lb] = (v); } while (0)
@@ -59,9 +58,7 @@ __device__ unsigned long long g_f2_timing[kF2TimingSlots * kF2TimingBlocks];
 #define F2_NOW() 0ull
 #endif
 
-// control words of ONE unit of work (a run of kTeam batches).  k_fused2 converts one unit per workgroup and uses ctl[0];
-// the persistent form k_fused2p alternates between the two sets, so that a wave that has finished its strips of unit i can start
-// the triangle phase of unit i + 1 while its team mates still read unit i's words
+// control words of the workgroup's unit of work (kTeam batches)
 struct F2Ctl {
     unsigned long long base;               // record index of stream position 0
     unsigned long long total_w[kTeam];     // fragments (all kinds) per batch
@@ -73,20 +70,14 @@ struct F2Ctl {
     uint32_t base_state;                   // 0 unknown, 1 being resolved, 2 known
     uint32_t irregular;                    // 1: record index != base + stream position somewhere (deferred triangles)
     uint32_t error;
-    uint32_t unit;                         // k_fused2p: the unit (logical workgroup) these words belong to, kNoUnit: none left
-    uint32_t first_of_queue;               // k_fused2p: 1 = first unit of its band (its base is the band's, known)
-    uint32_t ready;                        // k_fused2p: iteration number + 1 once `unit` and the words above are initialised
-    uint32_t pad_;
 };
 struct F2Lds {
     float4 tri[kTeam][64 * 5];             // TriShade of the four batches
     uint32_t tskip[kTeam][64];             // per triangle: (record index - stream position) of its fragments
     uint32_t entries[kEntries];            // lane << 24 | y << 12 | x  (the owning wave follows from the stream position)
     float4 stage[kTeam][kStageRec * 6];    // record staging, one per wave (half a strip, or a quarter)
-    F2Ctl ctl[2];
-    uint32_t drawn;                        // k_fused2p: units this workgroup has drawn a ticket for
+    F2Ctl ctl;
 };
-constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -122,199 +113,52 @@ __device__ __forceinline__ bool f2_get_base(F2Ctl& S, const unsigned long long* 
     return true;
 }
 
-// ---- persistent form: tickets ------------------------------------------------------------------------------------------
-// k_fused2p keeps (at most) as many workgroups as the GPU holds at once and lets each of them convert unit after unit.  A unit
-// (= what one workgroup of k_fused2 converts: kTeam batches) is handed out by a TICKET (TicketSets, m2s_device.h): eight queues,
-// one per XCD, holding exactly the units the hardware's round-robin dispatch gives that XCD in k_fused2 — its runs (launch in
-// runs) or every eighth unit (plain order), in the same order; a workgroup draws from the queue of its own XCD while that has
-// units, then from the queue with the most units left.  Tickets of one queue are drawn in order by workgroups that are RUNNING,
-// so the look-back chain's one requirement holds without any assumption about dispatch: every unit before mine in my run has
-// been started and will publish its aggregate.
-struct Unit { uint32_t lb; uint32_t first_of_queue; };
-struct Queues {      // the eight queues of a launch (see above)
-    uint32_t n_wg, shift; bool in_runs;
-    // ticket t of queue y -> unit (may be >= n_wg in the last group of runs: drawn and skipped)
-    __device__ __forceinline__ uint32_t unit_of(uint32_t y, uint32_t t) const {
-        return in_runs ? ((((t >> shift) << 3) + y) << shift) + (t & ((1u << shift) - 1u)) : (t << 3) + y;
-    }
-    __device__ __forceinline__ uint32_t tickets(uint32_t y) const {      // tickets of queue y that can be valid units
-        const uint32_t per_group = in_runs ? (8u << shift) : 8u;
-        const uint32_t groups = (n_wg + per_group - 1u) / per_group;
-        return in_runs ? (groups << shift) : groups;
-    }
-    __device__ __forceinline__ Unit unit(uint32_t y, uint32_t t) const {
-        const uint32_t lb = unit_of(y, t);
-        return Unit{ lb < n_wg ? lb : kNoUnit, (in_runs && (t & ((1u << shift) - 1u)) == 0u) ? 1u : 0u };
-    }
-};
-// lane 0 of one wave.  Two steps, so that the round trip of the atomic (~1-2 us under load) is not waited for where it is issued:
-// ticket_issue draws from the home queue; ticket_resolve, called later, turns the answer into a unit — or, if the home queue was
-// empty, draws from the queue with the most units left (its CUs would be the last to finish otherwise).  kNoUnit: all empty.
-__device__ __forceinline__ uint32_t ticket_issue(const TicketSets& tk, uint32_t home) {
-    return __hip_atomic_fetch_add(&tk.use[home * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ Unit ticket_resolve(const TicketSets& tk, const Queues& q, uint32_t home, uint32_t t) {
-    uint32_t y = home;
-    for (int attempt = 0; attempt < 64; ++attempt) {
-        if (t < q.tickets(y)) {
-            const Unit u = q.unit(y, t);
-            if (u.lb != kNoUnit) return u;
-        } else {      // that queue is empty: the one with the most tickets left
-            uint32_t best = 0;
-            y = 8;
-            for (uint32_t z = 0; z < 8u; ++z) {
-                const uint32_t nz = q.tickets(z);
-                const uint32_t tz = __hip_atomic_load(&tk.use[z * kTicketStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t left = nz > tz ? nz - tz : 0u;
-                if (left > best) { best = left; y = z; }
-            }
-            if (y == 8u) break;
-        }
-        t = __hip_atomic_fetch_add(&tk.use[y * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return Unit{ kNoUnit, 0u };
-}
-
-// the launch parameters of both forms
-struct F2Args {
-    SceneDev sc;
-    unsigned long long* chain;
-    unsigned long long limit;
-    float4* out;
-    unsigned long long* total_out;
-    uint32_t* status;          // [0] = any big, [1] = error
-    BigItem* biglist;
-    uint32_t* bigmeta;
-    uint32_t R, epoch, tpw;    // tpw: triangles per wave, 64, 32 or 16 (fused_tpw)
-    RunInfo runs;
-    BatchTable bt;
-    TicketSets tk;
-};
-typedef const __attribute__((address_space(4))) F2Args* F2ArgsConst;
-template <class T> __device__ __forceinline__ T ld_const(const __attribute__((address_space(4))) T* p) {
-    T v;
-    __builtin_memcpy(&v, p, sizeof(T));
-    return v;
-}
-
-// k_fused2p reads its parameters from the kernel-argument segment AGAIN for every unit, through a pointer the compiler cannot see
-// through (`args_mem`): the unit is then compiled like the body of k_fused2 — parameters arrive, are used, die.  Compiled as an
-// ordinary loop over values that live in registers, everything derived from a parameter (R / 2 as a float, plane addresses, the
-// queues' lengths, ...) is computed once in front of the loop and held through every strip: 194 vector registers instead of 157,
-// i.e. 26 of them spilled to scratch at three waves per SIMD, and the kernel 1.47x SLOWER than k_fused2 (0.176 vs 0.120 ms on
-// config 3, profiles/r04/ab_persistent_first_version_spills.log).
-template <bool kPersist>
-__device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2ArgsConst args_mem) {
-    const RunInfo runs = kPersist ? ld_const(&args_mem->runs) : args_direct.runs;     // (prologue and ticket code: a few scalar loads)
-    const TicketSets tk = kPersist ? ld_const(&args_mem->tk) : args_direct.tk;
-    const BatchTable bt = kPersist ? BatchTable{ nullptr, 0u } : args_direct.bt;
-    const uint32_t tpw = kPersist ? 64u : args_direct.tpw;
-    const uint32_t epoch = kPersist ? args_mem->epoch : args_direct.epoch;
-    const uint32_t n_tri_all = kPersist ? args_mem->sc.n_tri : args_direct.sc.n_tri;
-    const int lane_id = threadIdx.x & 63;
-    int lane = lane_id;
+__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
+                                                      unsigned long long limit, float4* __restrict__ out,
+                                                      unsigned long long* __restrict__ total_out,
+                                                      uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
+                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
+                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
+                                                      RunInfo runs, BatchTable bt) {
+    __shared__ F2Lds S;
+    F2Ctl& C = S.ctl;
+    const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Batches are `tpw` consecutive triangles each — or, for a scene small enough to be converted by ONE generation of
     // workgroups, the entries of a table whose batches carry equal estimated WORK (bt.first[b] .. bt.first[b + 1], at most 64
     // triangles, starts at multiples of 8): with one generation the kernel lasts as long as its slowest workgroup.
-    const uint32_t n_batches = bt.first ? bt.n : (n_tri_all + tpw - 1u) / tpw;
-    const uint32_t n_wg = (n_batches + (uint32_t)kTeam - 1u) / (uint32_t)kTeam;
+    const uint32_t n_batches = bt.first ? bt.n : (sc.n_tri + tpw - 1u) / tpw;
     // Hardware workgroup h runs on XCD h % 8, and every XCD has a private L2.  A launch in RUNS (RunInfo, m2s_device.h) gives XCD x
     // the runs x, x + 8, ... of consecutive units: neighbouring triangles — neighbouring texels — meet in ONE L2 instead of
     // eight, and the look-back chain restarts at every run, whose base comes from a table.  Without runs: plain order, one chain.
-    const uint32_t hb = blockIdx.x, xcd = hb & 7u;
+    const uint32_t hb = blockIdx.x, xcd = hb & 7u, round = hb >> 3;
     const bool in_runs = runs.base != nullptr;
     const uint32_t rmask = (1u << runs.shift) - 1u;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
-    const Queues queues{ n_wg, runs.shift, in_runs };
-
-    if (kPersist) {
-        // LDS is not zero on entry: `ready` of both control sets and the draw counter are cleared before anybody looks at them.
-        // (One barrier here, one per unit below: every wave executes the same number.)
-        if (threadIdx.x == 0) {
-            S.ctl[0].ready = 0; S.ctl[1].ready = 0; S.drawn = 0;
-            if (hb == 0) for (uint32_t z = 0; z < 8u; ++z) __hip_atomic_store(&tk.clear[z * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
-
-    for (uint32_t it = 0;; ++it) {
-    F2ArgsConst am = args_mem;
-    if (kPersist) asm volatile("" : "+s"(am));       // (see above: the parameters are loaded afresh for every unit)
-    if (kPersist) { lane = lane_id; asm volatile("" : "+v"(lane)); }   // (likewise per-lane constants: LDS addresses, tags, lane / 6)
-    const SceneDev sc = kPersist ? ld_const(&am->sc) : args_direct.sc;
-    const uint32_t R = kPersist ? am->R : args_direct.R;
-    unsigned long long* __restrict__ const chain = kPersist ? am->chain : args_direct.chain;
-    const unsigned long long limit = kPersist ? am->limit : args_direct.limit;
-    float4* __restrict__ const out = kPersist ? am->out : args_direct.out;
-    unsigned long long* __restrict__ const total_out = kPersist ? am->total_out : args_direct.total_out;
-    uint32_t* __restrict__ const status = kPersist ? am->status : args_direct.status;
-    BigItem* __restrict__ const biglist = kPersist ? am->biglist : args_direct.biglist;
-    uint32_t* __restrict__ const bigmeta = kPersist ? am->bigmeta : args_direct.bigmeta;
-    F2Ctl& C = S.ctl[kPersist ? (it & 1u) : 0u];
-    uint32_t lb;
-    bool band_first;
     [[maybe_unused]] const unsigned long long tk0 = F2_NOW();     // phase timers: live only in -DM2S_TIMING builds
 #ifdef M2S_TIMING
     const unsigned long long tk_real0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz, the same on every XCD: s_memtime is per XCD)
 #endif
-    [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0, tk_bar = 0, tk_tick = 0, tk_tri = 0;
-    if (!kPersist) {
-        if (it) return;
-        const uint32_t round = hb >> 3;
-        lb = hb;
-        if (in_runs) lb = ((((round >> runs.shift) << 3) + xcd) << runs.shift) + (round & rmask);
-        band_first = in_runs && (round & rmask) == 0u;     // first unit of its run: its base is the run's, known
-        if (lb * (uint32_t)kTeam >= n_batches) return;
-        // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
-        // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed.
-        // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
-        // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
-        if (lane == 0) { C.counted[wave] = 0; C.expanded[wave] = 0; }
-        if (wave == 0 && lane == 0) {
-            C.claimed = 0; C.irregular = 0; C.error = 0;
-            C.base_state = (lb == 0 || band_first) ? 2u : 0u;
-            C.base = band_first ? runs.base[lb >> runs.shift] : 0ull;   // scalar load from device memory
-        }
-        __syncthreads();
-    } else {
-        // The unit of this iteration is drawn by the FIRST wave that gets here — when the workgroup is about to start it, not
-        // earlier: units must START in ticket order, or the look-back of every later unit waits for one that was drawn early by a
-        // workgroup still busy with its previous unit.  (First version: wave 0 drew the next ticket a whole unit ahead, to hide
-        // the atomic's round trip; the waves then spent 13 k cycles per unit at the barrier below, behind their last wave's
-        // look-back: 0.150 ms instead of k_fused2's 0.120, profiles/r04/timeline_persistent_tickets_drawn_one_unit_ahead.log.)
-        // The other set of control words is free: everybody left the unit before the previous one at that unit's barrier.
-        {
-            uint32_t mine = 0;
-            if (lane == 0) {
-                uint32_t expect = it;
-                mine = __hip_atomic_compare_exchange_strong(&S.drawn, &expect, it + 1u, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-                if (mine) {
-                    [[maybe_unused]] const unsigned long long ttk0 = F2_NOW();
-                    const Unit u = ticket_resolve(tk, queues, xcd, ticket_issue(tk, xcd));
-                    C.unit = u.lb; C.first_of_queue = u.first_of_queue;
-                    C.claimed = 0; C.irregular = 0; C.error = 0;
-                    C.base_state = (u.lb == 0u || u.first_of_queue) ? 2u : 0u;
-                    C.base = (u.first_of_queue && u.lb != kNoUnit) ? runs.base[u.lb >> runs.shift] : 0ull;
-#pragma unroll
-                    for (int k = 0; k < kTeam; ++k) { C.counted[k] = 0; C.expanded[k] = 0; }
-                    tk_tick = F2_NOW() - ttk0;
-                    __hip_atomic_store(&C.ready, it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-        uint32_t spins = 0;
-        bool lost = false;
-        while (lds_load(&C.ready) != it + 1u) {
-            if (++spins > kWaitLimit) { lost = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        lb = lost ? kNoUnit : C.unit;
-        lb = __builtin_amdgcn_readfirstlane(lb);
-        if (lost && lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lb == kNoUnit) return;
-        band_first = C.first_of_queue != 0u;
+    [[maybe_unused]] unsigned long long tk_cnt = 0, tk_ent = 0, tk_base = 0, n_strips = 0, tk_tri = 0;
+    uint32_t lb = hb;
+    if (in_runs) {
+        uint32_t rr = ((round >> runs.shift) << 3) + xcd;      // dispatch slot of the run ...
+        if (runs.order) rr = ((const __attribute__((address_space(4))) uint32_t*)runs.order)[rr];   // ... heaviest runs first (launch_run_order)
+        lb = (rr << runs.shift) + (round & rmask);
     }
+    const bool band_first = in_runs && (round & rmask) == 0u;     // first unit of its run: its base is the run's, known
+    if (lb * (uint32_t)kTeam >= n_batches) return;
+    // control words: each wave initialises its own; the shared ones are set by wave 0 BEFORE it publishes `counted`,
+    // and every other wave reads them only after it has seen counted[0] (acquire) — no barrier needed.
+    // LDS is not zero on entry: counted[]/expanded[] of OTHER waves may hold garbage until those waves get here.
+    // One barrier at the very start (all four waves arrive immediately) makes the flags trustworthy.
+    if (lane == 0) { C.counted[wave] = 0; C.expanded[wave] = 0; }
+    if (wave == 0 && lane == 0) {
+        C.claimed = 0; C.irregular = 0; C.error = 0;
+        C.base_state = (lb == 0 || band_first) ? 2u : 0u;
+        C.base = band_first ? runs.base[lb >> runs.shift] : 0ull;   // scalar load from device memory
+    }
+    __syncthreads();
     const uint32_t b0 = lb * kTeam;                    // the workgroup's first batch
     const uint32_t nb_here = min((uint32_t)kTeam, n_batches - b0);
     const uint32_t b = b0 + wave;                      // this wave's batch (may not exist in the last workgroup)
@@ -337,18 +181,6 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
 #pragma unroll
     for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
-    if (kPersist) {
-        // Every per-unit variable gets a value on EVERY path, once per unit.  A variable that lanes without a triangle leave
-        // unset is "undefined" to the compiler, and in a loop the cheapest undefined value is the one the register held in
-        // the previous iteration: positions, frame and window coordinates of unit i were carried — live — through all strips
-        // into unit i + 1 (16 register pairs copied at the loop latch; with the per-lane constants hoisted in front of the loop
-        // 194 VGPRs instead of 157).
-#pragma unroll
-        for (int i = 0; i < 9; i++) p[i] = 0.0f;
-        g.xx = g.xy = g.xz = g.nx = g.ny = g.nz = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; i++) g.ou[i] = g.ov[i] = 0.0f;
-    }
     bool ok = false;
     uint32_t m = 0;
     float4 uvb0 = make_float4(0, 0, 0, 0);
@@ -491,17 +323,6 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         tk_base += F2_NOW() - tb0;
     }
 
-    if (kPersist) {
-        // Everything above touched registers, global memory and THIS unit's control words only.  From here on the unit writes the
-        // single-buffered arrays (TriShade table, entry stream, staging) which the previous unit's strips may still be reading: all
-        // four waves meet here, i.e. after the slowest one has left the previous unit.  (k_fused2 has this rendezvous implicitly,
-        // and earlier: a workgroup starts when the previous one on its slot has exited — a wave that finishes its strips early
-        // idles until the slowest has finished; here it has done a triangle phase meanwhile.)
-        [[maybe_unused]] const unsigned long long tbar0 = F2_NOW();
-        __syncthreads();
-        tk_bar = F2_NOW() - tbar0;
-    }
-
     // ======================= my TriShade, tskip and entries =======================
 #if defined(M2S_PROBE_STOP) && M2S_PROBE_STOP >= 2      // instruction-count probes (wrong output): tools/r4_valu.sh
     if (false) {
@@ -608,10 +429,6 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
         for (int k = 1; k < kTeam; ++k) ow += (pos0 + (uint32_t)lane >= cum[k]) ? 1u : 0u;
         const uint32_t tl = (en >> 24) & 63u;
         float4 rec[6];
-        if (kPersist) {     // (a value on every path: see the triangle phase)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rec[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
         uint32_t skip = 0;
         // do all fragments of the strip belong to one mesh?
         uint32_t my_mesh = 0;
@@ -682,71 +499,20 @@ __device__ __forceinline__ void f2_body(F2Lds& S, const F2Args& args_direct, F2A
     { const uint32_t e = lds_load(&C.error); if (e && lane == 0) __hip_atomic_store(&status[1], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     F2_T(0, F2_NOW() - tk0); F2_T(1, tk_cnt); F2_T(2, tk_ent); F2_T(3, tk_base); F2_T(4, n_strips); F2_T(5, (unsigned long long)stream_total);
     F2_T(6, tk_real0); F2_T(7, __builtin_amdgcn_s_memrealtime()); F2_T(8, (unsigned long long)(blockIdx.x & 7u));
-    F2_T(9, tk_bar); F2_T(10, tk_tick); F2_T(11, tk_tri); F2_T(12, (unsigned long long)it);
+    F2_T(11, tk_tri);
     F2_T(13, tsl1 - tsl0); F2_TW(3, 14, tsl1 - tsl0); F2_TW(3, 15, n_strips);
-    }   // units
-}
-
-__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
-                                                      unsigned long long limit, float4* __restrict__ out,
-                                                      unsigned long long* __restrict__ total_out,
-                                                      uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                      BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta,
-                                                      uint32_t tpw /* triangles per wave: 64, 32 or 16 (fused_tpw) */,
-                                                      RunInfo runs, BatchTable bt) {
-    __shared__ F2Lds S;
-    const F2Args a{ sc, chain, limit, out, total_out, status, biglist, bigmeta, R, epoch, tpw, runs, bt, TicketSets{ nullptr, nullptr } };
-    f2_body<false>(S, a, nullptr);
-}
-
-// the persistent form (see "tickets" above): at most as many workgroups as the GPU holds at once, units by ticket.  Its one
-// parameter is never touched by name: the body reads it from the kernel-argument segment (f2_body, args_mem).
-__global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2p(F2Args a) {
-    __shared__ F2Lds S;
-    f2_body<true>(S, *reinterpret_cast<const F2Args*>(&S) /* never read */, (F2ArgsConst)__builtin_amdgcn_kernarg_segment_ptr());
-}
-
-// workgroups of k_fused2p the GPU holds at once (its grid)
-static uint32_t persistent_grid() {
-    static const uint32_t n = [] {
-        int dev = 0, per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0u;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused2p, kTeamThreads, 0) != hipSuccess || per_cu <= 0) return 0u;
-        return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
-    }();
-    return n;
 }
 
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const RunInfo& runs, const BatchTable& bt, const TicketSets& tk, hipStream_t st) {
+                   const RunInfo& runs, const BatchTable& bt, hipStream_t st) {
     const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
     const uint32_t n_batches = bt.first ? bt.n : n_fused_waves(sc.n_tri);
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     RunInfo r = runs;
-    if (tpw != 64u || kTeam != 4 || bt.first) r = RunInfo{ nullptr, nullptr, 0u };
+    if (tpw != 64u || kTeam != 4 || bt.first) r = RunInfo{ nullptr, nullptr, 0u, nullptr };
     if (r.base) r.out = nullptr;
-    // The persistent form (units by ticket) is built, bit-identical (tests/test_gpu_persistent.py) and NOT the default: on config 3
-    // it is 11 % slower than one unit per workgroup (0.133 vs 0.118 ms, profiles/r04/ab_persistent_tickets_at_unit_start.log).  It
-    // does what it was built for — 757 of 768 slots busy until the last sixth of the launch instead of ~700 — but (1) a strip
-    // then takes 8.8 k cycles instead of 7.9 k: the memory system, not the number of workgroups in flight, sets the steady-state
-    // rate; (2) the four waves of a team have to meet once per unit before they overwrite the shared tables, and they meet after
-    // the slowest wave's triangle phase: 7.5 k cycles of waiting per unit against the ~4 k the hardware needs to replace an
-    // exited workgroup; (3) the tail is the same 1.3 unit lifetimes.  (profiles/r04/timeline_persistent_*.log.)  Debug switch
-    // M2S_PERSIST=1 selects it for scenes of more than one generation of workgroups.
-    uint32_t pg = persistent_grid();
-    if (const char* v = debug_env("M2S_PERSIST_GRID")) {     // debug: A/B of the grid size
-        static bool said = false;
-        if (!said) { said = true; fprintf(stderr, "[m2s] k_fused2p: occupancy query says %u workgroups, M2S_PERSIST_GRID=%s\n", pg, v); }
-        pg = (uint32_t)strtoul(v, nullptr, 10);
-    }
-    if (tk.use && pg && nb > pg && tpw == 64u && kTeam == 4 && !bt.first && debug_on("M2S_PERSIST")) {
-        const F2Args a{ sc, chain, (unsigned long long)limit, out, total, status, biglist, bigmeta, R, epoch & 0xFFFFu, 64u, r, BatchTable{ nullptr, 0u }, tk };
-        hipLaunchKernelGGL(k_fused2p, dim3(pg), dim3(kTeamThreads), 0, st, a);
-        return;
-    }
     if (r.base) nb = ((nb + (8u << r.shift) - 1u) / (8u << r.shift)) * (8u << r.shift);   // whole groups of eight runs; surplus workgroups exit at once
     else nb = (nb + 7u) & ~7u;
     hipLaunchKernelGGL(k_fused2, dim3(nb), dim3(kTeamThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,

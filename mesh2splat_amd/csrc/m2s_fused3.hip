@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
     const uint32_t rmask = (1u << runs.shift) - 1u;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     uint32_t lb = hb;
-    if (in_runs) lb = ((((round >> runs.shift) << 3) + xcd) << runs.shift) + (round & rmask);
+    if (in_runs) {
+        uint32_t rr = ((round >> runs.shift) << 3) + xcd;          // dispatch slot of the run ...
+        if (runs.order) rr = ((const __attribute__((address_space(4))) uint32_t*)runs.order)[rr];   // ... heaviest runs first
+        lb = (rr << runs.shift) + (round & rmask);
+    }
     const bool band_first = in_runs && (round & rmask) == 0u;     // first unit of its run: its base is the run's, known
     if (lb * (uint32_t)kL3Team >= n_batches) return;
     // LDS is not zero on entry: one barrier at the very start makes the flags trustworthy (see k_fused2)
@@ -362,6 +366,9 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
             }
             if (!alive) break;
         }
+#ifdef M2S_FUSED3_PRIO
+        __builtin_amdgcn_s_setprio(M2S_FUSED3_PRIO);       // A/B: the front of a strip (up to its texel requests) ahead of other waves' arithmetic
+#endif
         const uint32_t pos = pos0 + (uint32_t)lane;
         const bool have = (uint32_t)lane < n;
         uint32_t en = 0;
@@ -382,7 +389,9 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
                 const uint32_t tt = C.t0[ow] + tl;
                 const uint32_t org = ts.org;
                 const int x = (int)(org & 0xFFFu) + (int)(bit & 7u), y = (int)(org >> 12) + (int)(bit >> 3);
-                shade_from_tri<ConstMeshPtr, TriShadeS, true>(sc.tri, tt, x, y, kConstMesh(sc.meshes + m_now), ts, rec);
+                // (readfirstlane, not m_now: inside this branch the optimiser knows my_mesh == m_now and substitutes the per-lane
+                //  value — the descriptor loads then become vector loads through a per-lane pointer, the texel reads 64-bit addresses)
+                shade_from_tri<ConstMeshPtr, TriShadeS, true>(sc.tri, tt, x, y, kConstMesh(sc.meshes + __builtin_amdgcn_readfirstlane(my_mesh)), ts, rec);
             }
             todo &= ~__ballot(mine);
         }
@@ -453,7 +462,7 @@ void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
     if (!n_batches) return;
     uint32_t nb = (n_batches + kL3Team - 1) / kL3Team;
     RunInfo r = runs;
-    if (tpw != 64u || bt.first) r = RunInfo{ nullptr, nullptr, 0u };
+    if (tpw != 64u || bt.first) r = RunInfo{ nullptr, nullptr, 0u, nullptr };
     if (r.base) r.out = nullptr;
     if (r.base) nb = ((nb + (8u << r.shift) - 1u) / (8u << r.shift)) * (8u << r.shift);   // whole groups of eight runs; surplus workgroups exit at once
     else nb = (nb + 7u) & ~7u;

@@ -245,6 +245,29 @@ void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n
 }
 
 // ============================================================================================
+// K_run_order: rank sort of the runs by fragment count, descending (ties: lower run first).  n_runs <= a few thousand.
+// ============================================================================================
+__global__ void __launch_bounds__(kBlock) k_run_order(const unsigned long long* __restrict__ run_base, uint32_t n_runs,
+                                                      const unsigned long long* __restrict__ total, uint32_t* __restrict__ order, uint32_t n_slots) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_slots) return;
+    if (i >= n_runs) { order[i] = i; return; }
+    const unsigned long long end = *total;
+    auto cost = [&](uint32_t j) { return (j + 1u < n_runs ? run_base[j + 1u] : end) - run_base[j]; };
+    const unsigned long long mine = cost(i);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n_runs; ++j) {
+        const unsigned long long cj = cost(j);
+        rank += (cj > mine || (cj == mine && j < i)) ? 1u : 0u;
+    }
+    order[rank] = i;
+}
+void launch_run_order(const unsigned long long* run_base, uint32_t n_runs, const unsigned long long* total, uint32_t* order, uint32_t n_slots, hipStream_t st) {
+    if (!n_slots) return;
+    hipLaunchKernelGGL(k_run_order, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, st, run_base, n_runs, total, order, n_slots);
+}
+
+// ============================================================================================
 // K_offsets: off[t] = exclusive prefix of cnt; start[m] = triangle that owns output index m*kEmitF
 // ============================================================================================
 __global__ void __launch_bounds__(kBlock) k_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ partials,

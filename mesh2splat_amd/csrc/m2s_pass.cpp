@@ -51,7 +51,7 @@ bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
            sparse_supported(c->scene.n_tri);
 }
 RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes) {
-    RunInfo r{ nullptr, nullptr, 0u };
+    RunInfo r{ nullptr, nullptr, 0u, nullptr };
     if (writes) *writes = false;
     const uint32_t n_wg = band_workgroups(c, unit);
     const uint32_t shift = run_shift_for(n_wg);
@@ -59,23 +59,17 @@ RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, boo
     if ((size_t)n_runs(n_wg, shift) > c->run_table_words) return r;
     unsigned long long* table = c->d_bands + (size_t)ri.band_slot * c->run_table_words;
     r.shift = shift;
-    if (ri.bands_ready && ri.bands_unit == unit) r.base = table;
+    if (ri.bands_ready && ri.bands_unit == unit) {
+        r.base = table;
+        // heaviest runs first (built by warm_scene from the exact counts at ITS R: the ranking of the runs is a property of the mesh)
+        if (c->run_order_unit == unit && c->run_order_shift == shift && !debug_on("M2S_NO_RUN_ORDER")) r.order = c->d_run_order;
+    }
     else if (may_write) { r.out = table; if (writes) *writes = true; }
     return r;
 }
 
 BatchTable batches_for(const m2s_ctx* c) {
     return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab } : BatchTable{ nullptr, 0u };
-}
-
-// Persistent launches (k_fused2p) draw their units from ticket counters that must be zero when the launch starts: every lane
-// has two sets and alternates — a launch zeroes the set of the NEXT launch on its chain, which is idle because launches that
-// share a chain run in order.
-TicketSets tickets_for(m2s_ctx* c, int lane) {
-    if (!c->d_tickets) return TicketSets{ nullptr, nullptr };
-    const uint32_t turn = c->ticket_turn[lane]++ & 1u;
-    uint32_t* base = c->d_tickets + (size_t)lane * 2 * 8 * kTicketStride;
-    return TicketSets{ base + (size_t)turn * 8 * kTicketStride, base + (size_t)(turn ^ 1u) * 8 * kTicketStride };
 }
 
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
@@ -179,6 +173,9 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
         const RunInfo table = bands_for(c, ri, unit, true, &writes);
         if (writes) {
             launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, table.shift, table.out, st);
+            const uint32_t n_units = band_workgroups(c, unit);
+            launch_run_order(table.out, n_runs(n_units, table.shift), c->d_total, c->d_run_order, run_order_slots(n_units, table.shift), st);
+            c->run_order_unit = unit; c->run_order_shift = table.shift;
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));
             ri.bands_ready = true; ri.bands_unit = unit;
@@ -304,7 +301,7 @@ static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t 
     { const m2s_status s = ensure_multipass_buffers(c, limit); if (s != M2S_OK) return s; }
     c->h_total[0] = 0; c->h_total[1] = 0;
     { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
-    HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+    HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
     if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
     if (prof) {
         if (multipass_v1()) { for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
@@ -398,12 +395,12 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), tickets_for(c, 0), st);
+                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
+            HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);

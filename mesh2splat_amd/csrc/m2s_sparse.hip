@@ -198,7 +198,11 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
     const bool in_runs = runs.base != nullptr;
     const uint32_t rmask = (1u << runs.shift) - 1u;
     uint32_t lb = hb;
-    if (in_runs) lb = ((((rnd >> runs.shift) << 3) + xcd) << runs.shift) + (rnd & rmask);
+    if (in_runs) {
+        uint32_t rr = ((rnd >> runs.shift) << 3) + xcd;            // dispatch slot of the run ...
+        if (runs.order) rr = ((const __attribute__((address_space(4))) uint32_t*)runs.order)[rr];   // ... heaviest runs first (launch_run_order)
+        lb = (rr << runs.shift) + (rnd & rmask);
+    }
     const bool band_first = in_runs && (rnd & rmask) == 0u;
     if (lb >= n_wg) return;
     const uint32_t t_wg = lb * kSpCand;

@@ -192,8 +192,8 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     const uint32_t units = fused2_band_workgroups(n_tri);
     const size_t run_words = run_shift_for(units) ? (size_t)n_runs(units, run_shift_for(units)) + 1 : 0;
     const size_t o_bands = take(std::max<size_t>((size_t)kBandSlots * run_words, 1) * sizeof(unsigned long long));
+    const size_t o_run_order = take(std::max<size_t>(run_shift_for(units) ? run_order_slots(units, run_shift_for(units)) : 0, 1) * sizeof(uint32_t));
     const size_t o_batch = take(std::max<size_t>(batch_table_capacity(n_tri), 1) * sizeof(uint32_t));
-    const size_t o_tickets = take(4 * kTicketSetBytes);
     HIPCHK(c, hipMalloc(&c->scene_arena, arena));
     { const m2s_status s = ensure_stage(c); if (s != M2S_OK) return s; }
     c->last_upload_ms[3] = ms_since(t_alloc);
@@ -278,11 +278,10 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->d_bigmeta = (uint32_t*)(A + o_bigmeta);
     c->d_bands = (unsigned long long*)(A + o_bands);
     c->run_table_words = run_words;
+    c->d_run_order = (uint32_t*)(A + o_run_order);
+    c->run_order_unit = 0; c->run_order_shift = 0;
     c->d_batch_first = (uint32_t*)(A + o_batch);
     c->n_batch_tab = 0;
-    c->d_tickets = (uint32_t*)(A + o_tickets);
-    c->ticket_turn[0] = c->ticket_turn[1] = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 4 * kTicketSetBytes, c->stream));
     c->chain_words = chain_words;
     HIPCHK(c, hipMemsetAsync(c->d_chain, 0, chain_words * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));

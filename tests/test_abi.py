@@ -117,3 +117,30 @@ def test_rccl_stand_in_exports_what_load_rccl_resolves():
     assert len(wanted) == 9
     have = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     assert all(re.search(rf"\bT {w}\b", have) for w in wanted), wanted
+
+
+def test_unloadable_rccl_path_is_an_error_string_not_a_crash(hiplib):
+    """with M2S_RCCL_PATH naming a file that cannot be loaded, m2s_dist_unique_id must fail with a message
+    (it used to build the message from a second dlerror() call, which returns NULL: undefined behaviour, a segfault in practice).
+    No GPU needed: the library is loaded, librccl is not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from mesh2splat_amd import _lib\n"
+        "L = _lib.load()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "L.m2s_dist_unique_id.restype = ctypes.c_int\n"
+        "rc = L.m2s_dist_unique_id(buf)\n"
+        "L.m2s_dist_last_error.restype = ctypes.c_char_p\n"
+        "L.m2s_dist_last_error.argtypes = [ctypes.c_void_p]\n"
+        "msg = L.m2s_dist_last_error(None).decode()\n"
+        "print(rc, '|', msg)\n"
+    )
+    env = dict(os.environ, M2S_RCCL_PATH="/nonexistent/librccl_nowhere.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    rc, msg = r.stdout.strip().splitlines()[-1].split(" | ", 1)
+    assert int(rc) != 0 and "M2S_RCCL_PATH" in msg and "librccl_nowhere" in msg, r.stdout

@@ -30,7 +30,7 @@ def test_new_densities_and_band_bases(hiplib, oracle):
         want = ref.download()
         for rep in range(3):
             assert c.convert(R) == want_total
-            assert c.last_pipeline == "team"
+            assert c.last_pipeline == "lean"              # (k_fused3 and k_fused2 share units and run tables)
             assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32)), (R, rep)
     ototal, orec, _ = oracle.convert(scene, 640, cap=reference_cap(640, 1))
     assert ototal == ref.convert(640)

@@ -23,8 +23,7 @@ def st(x): return f"median {np.median(x):9.0f} mean {x.mean():9.0f} p90 {np.perc
 print("workgroups", nb, "(wave 0 of each)")
 for i, name in enumerate(["total", "wait counts", "wait entries", "wait base", "strips", "entries / workgroup"]):
     print(f"{name:22s}", st(t[i]))
-for i, name in ((9, "at the unit barrier"), (10, "next ticket"), (11, "until counts published"), (12, "units per workgroup"),
-                (13, "wave 0 in strip loop"), (14, "wave 3 in strip loop"), (15, "wave 3 strips")):
+for i, name in ((11, "until counts published"), (13, "wave 0 in strip loop"), (14, "wave 3 in strip loop"), (15, "wave 3 strips")):
     print(f"{name:22s}", st(t[i]))
 print("cycles per strip: wave 0 %.0f, wave 3 %.0f" % (t[13].sum() / max(t[4].sum(), 1), t[14].sum() / max(t[15].sum(), 1)))
 
