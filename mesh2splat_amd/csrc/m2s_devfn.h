@@ -195,19 +195,41 @@ struct Raster {
 
 constexpr float kGuardPx = 16384.0f;
 
-__device__ __forceinline__ bool raster_setup(const Geo& g, uint32_t R, Raster& s) {
+// First half of the raster setup: viewport transform, 24.8 snap, pixel box.  false: a coordinate beyond the guard band (or NaN),
+// or no pixel centre inside the box (the zero-area test is the caller's: raster_setup / raster_small).
+struct RasterHead {
+    int X[3], Y[3];      // snapped window coordinates (24.8)
+    int x0, x1, y0, y1;  // inclusive pixel box, clamped to the viewport
+    int ext;             // max sub-pixel extent of the (unclamped) triangle box
+};
+__device__ __forceinline__ bool raster_head(const Geo& g, uint32_t R, RasterHead& h) {
     const float half = (float)R * 0.5f;
-    int X[3], Y[3];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float ndx = g.ou[i] * 2.0f - 1.0f, ndy = g.ov[i] * 2.0f - 1.0f;  // GS:439
         float xw = half * ndx + half, yw = half * ndy + half;            // glViewport(0,0,R,R)
         ok = ok && (fabsf(xw) < kGuardPx) && (fabsf(yw) < kGuardPx);     // false for NaN
-        X[i] = (int)rintf(xw * 256.0f);
-        Y[i] = (int)rintf(yw * 256.0f);
+        h.X[i] = (int)rintf(xw * 256.0f);
+        h.Y[i] = (int)rintf(yw * 256.0f);
     }
     if (!ok) return false;
+    const int xmin = min(h.X[0], min(h.X[1], h.X[2])), xmax = max(h.X[0], max(h.X[1], h.X[2]));
+    const int ymin = min(h.Y[0], min(h.Y[1], h.Y[2])), ymax = max(h.Y[0], max(h.Y[1], h.Y[2]));
+    h.ext = max(xmax - xmin, ymax - ymin);
+    h.x0 = max((xmin - 128 + 255) >> 8, 0);
+    h.x1 = min((xmax - 128) >> 8, (int)R - 1);
+    h.y0 = max((ymin - 128 + 255) >> 8, 0);
+    h.y1 = min((ymax - 128) >> 8, (int)R - 1);
+    return h.x0 <= h.x1 && h.y0 <= h.y1;
+}
+
+__device__ __forceinline__ bool raster_setup(const Geo& g, uint32_t R, Raster& s) {
+    RasterHead h;
+    const bool box = raster_head(g, R, h);
+    const int* X = h.X;
+    const int* Y = h.Y;
+    if (!box) return false;
     long long area2 = (long long)(X[1] - X[0]) * (Y[2] - Y[0]) - (long long)(Y[1] - Y[0]) * (X[2] - X[0]);
     if (area2 == 0) return false;
     const int sgn = area2 < 0 ? -1 : 1;  // no culling (ConversionPass.cpp:48)
@@ -222,14 +244,74 @@ __device__ __forceinline__ bool raster_setup(const Geo& g, uint32_t R, Raster& s
         s.c[i] = ((long long)dy * X[ia] - (long long)dx * Y[ia]) * sgn;
         if (s.a[i] > 0 || (s.a[i] == 0 && s.b[i] > 0)) s.bias |= 1 << i;
     }
-    int xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
-    int ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
-    s.ext = max(xmax - xmin, ymax - ymin);
-    s.x0 = max((xmin - 128 + 255) >> 8, 0);
-    s.x1 = min((xmax - 128) >> 8, (int)R - 1);
-    s.y0 = max((ymin - 128 + 255) >> 8, 0);
-    s.y1 = min((ymax - 128) >> 8, (int)R - 1);
-    return s.x0 <= s.x1 && s.y0 <= s.y1;
+    s.ext = h.ext;
+    s.x0 = h.x0; s.x1 = h.x1; s.y0 = h.y0; s.y1 = h.y1;
+    return true;
+}
+
+// The same setup for a triangle whose sub-pixel extent is at most 2304 (so |a|, |b| <= 2304) in a pixel box of at most 8 x 8
+// (k_fused3): every quantity fits 32 bits and every product 24 x 24 bits.  E_i(P) = a_i (Px - X_ia) + b_i (Py - Y_ia) — the edge
+// function written from the edge's first vertex, equal to a_i Px + b_i Py + c_i of raster_setup — and the centre of the box-origin
+// pixel lies inside the triangle's own box (x0 is the first centre >= xmin and x0 <= x1 puts it <= xmax), so both factors are at
+// most 2304 and each product below 2^23.  No 64-bit and no full-rate-quarter 32 x 32 multiplies (v_mul_lo_u32, v_mad_i64_i32:
+// 16 cycles each; raster_setup has twenty of them), same integers.
+struct RasterSmall {
+    int a[3], b[3];
+    int e[3];            // E_i at the centre of pixel (x0, y0), exact
+    int area2;           // > 0
+    int bias;
+};
+__device__ __forceinline__ bool raster_small(const RasterHead& h, RasterSmall& s) {
+    const int area = __mul24(h.X[1] - h.X[0], h.Y[2] - h.Y[0]) - __mul24(h.Y[1] - h.Y[0], h.X[2] - h.X[0]);
+    if (area == 0) return false;
+    const bool neg = area < 0;
+    s.area2 = neg ? -area : area;
+    const int Px0 = 256 * h.x0 + 128, Py0 = 256 * h.y0 + 128;
+    s.bias = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int ia = (i + 1) % 3, ib = (i + 2) % 3;
+        const int dy = h.Y[ib] - h.Y[ia], dx = h.X[ib] - h.X[ia];
+        s.a[i] = neg ? dy : -dy;
+        s.b[i] = neg ? -dx : dx;
+        s.e[i] = __mul24(s.a[i], Px0 - h.X[ia]) + __mul24(s.b[i], Py0 - h.Y[ia]);
+        if (s.a[i] > 0 || (s.a[i] == 0 && s.b[i] > 0)) s.bias |= 1 << i;
+    }
+    return true;
+}
+
+// Coverage of the wave's SMALL triangles (one per lane; lanes without one pass small = false): bit 8 dy + dx of mhi:mlo = pixel
+// (x0 + dx, y0 + dy) is covered (top-left rule through the bias, as everywhere).  The wave walks rows and columns TOGETHER
+// (wave-uniform trip counts: the tallest and the widest box among its triangles), every lane shifting the sign of its own three
+// edge functions into a row of bits: v_or3 + v_alignbit + three adds per pixel, loop control in scalar registers.  (The per-lane
+// loop with a 64-bit mask this replaces took thirteen vector instructions per pixel and ran as long as the largest box as well.)
+__device__ __forceinline__ void small_coverage(bool small, int w, int rows, const RasterSmall& rs, uint32_t& mlo, uint32_t& mhi) {
+    const int ws = small ? w : 0, rws = small ? rows : 0;
+    int wmax = 0, rmax = 0;
+    while (__ballot(ws > wmax) != 0ull) ++wmax;
+    while (__ballot(rws > rmax) != 0ull) ++rmax;
+    mlo = 0; mhi = 0;
+    if (!wmax) return;
+    int e0 = 0, e1 = 0, e2 = 0, ax0 = 0, ax1 = 0, ax2 = 0, by0 = 0, by1 = 0, by2 = 0;
+    if (small) {
+        e0 = rs.e[0] + ((rs.bias >> 0) & 1) - 1; e1 = rs.e[1] + ((rs.bias >> 1) & 1) - 1; e2 = rs.e[2] + ((rs.bias >> 2) & 1) - 1;
+        ax0 = rs.a[0] * 256; ax1 = rs.a[1] * 256; ax2 = rs.a[2] * 256;
+        by0 = rs.b[0] * 256; by1 = rs.b[1] * 256; by2 = rs.b[2] * 256;
+    }
+    const uint32_t wmask = (1u << ws) - 1u;     // (0 for a lane without a small triangle)
+    for (int dy = 0; dy < rmax; ++dy) {
+        int r0 = e0, r1 = e1, r2 = e2;
+        uint32_t outside = 0;                    // column dx at bit wmax - 1 - dx; 1 = some edge function negative
+        for (int dx = 0; dx < wmax; ++dx) {
+            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)(r0 | r1 | r2), 31);   // (outside << 1) | sign bit
+            r0 += ax0; r1 += ax1; r2 += ax2;
+        }
+        uint32_t row = (__brev(~outside) >> (32 - wmax)) & wmask;   // column dx at bit dx; 1 = covered
+        if (dy >= rws) row = 0;
+        if (dy < 4) mlo |= row << (8 * dy);
+        else mhi |= row << (8 * dy - 32);
+        e0 += by0; e1 += by1; e2 += by2;
+    }
 }
 
 // covered pixels of row y form one interval [xa, xb] (empty if xa > xb): exact closed form
@@ -448,25 +530,14 @@ __device__ __forceinline__ float lod_from_grad(float fw, float fh, float dudx, f
     return 0.5f * fast_log2(r2);   // log2(sqrt(r2))
 }
 
-// p: positions; b0/b1: uv planes of the triangle.  Needs a valid Raster.
-template <class MP>   // const MeshParams* in the generic or the constant address space (kConstMesh)
-__device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, MP mp,
-                                                float4 b0, float2 b1, TriShade& ts) {
-    // The barycentrics feed the texture coordinates, where any rounding difference is amplified by the
-    // texture size and contrast: they follow the oracle's exact operation sequence
-    // lambda_i = float(E_i) * (1 / float(area2)) with exact integer E_i (DECISION-class arithmetic).
-    {
-#pragma clang fp contract(off)
-        ts.inva = 1.0f / (float)rs.area2;
-    }
-    const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
-    ts.a1 = rs.a[1]; ts.b1 = rs.b[1]; ts.a2 = rs.a[2]; ts.b2 = rs.b[2];
-    ts.e1 = (long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1];
-    ts.e2 = (long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2];
-    ts.org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;
+// Everything of the per-triangle fragment constants that does not depend on how the edge functions are stored: Scale, Quaternion,
+// the levels of detail.  Needs ts.inva; a1 .. b2 = the coefficients of edges 1 and 2.
+template <class MP, class TS>   // MP: const MeshParams* in the generic or the constant address space (kConstMesh); TS: TriShade / TriShadeS
+__device__ __forceinline__ void tri_shade_rest(const float p[9], const Geo& g, int a1, int b1, int a2, int b2, MP mp,
+                                               float4 b0, float2 b1uv, TS& ts) {
     ts.mesh = 0;
-    const float A1 = (float)rs.a[1] * 256.0f * ts.inva, B1 = (float)rs.b[1] * 256.0f * ts.inva;
-    const float A2 = (float)rs.a[2] * 256.0f * ts.inva, B2 = (float)rs.b[2] * 256.0f * ts.inva;
+    const float A1 = (float)a1 * 256.0f * ts.inva, B1 = (float)b1 * 256.0f * ts.inva;
+    const float A2 = (float)a2 * 256.0f * ts.inva, B2 = (float)b2 * 256.0f * ts.inva;
     geo_flat(p, g, ts.sx, ts.sy, ts.rot);
     ts.lod0 = ts.lod1 = ts.lod2 = 0.0f;
     const auto ta = &mp->tex[0];
@@ -475,7 +546,7 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
     const bool hasA = ta->texels != nullptr, hasN = tn->texels != nullptr, hasM = tm->texels != nullptr;
     if (hasA || hasN || hasM) {
         // UV is affine in window space (all w = 1, GS:439): d(lambda_i)/dx = A_i, d/dy = B_i per pixel
-        const float du1 = b0.z - b0.x, du2 = b1.x - b0.x, dv1 = b0.w - b0.y, dv2 = b1.y - b0.y;
+        const float du1 = b0.z - b0.x, du2 = b1uv.x - b0.x, dv1 = b0.w - b0.y, dv2 = b1uv.y - b0.y;
         const float dudx = fma_(A2, du2, A1 * du1), dvdx = fma_(A2, dv2, A1 * dv1);
         const float dudy = fma_(B2, du2, B1 * du1), dvdy = fma_(B2, dv2, B1 * dv1);
         if (hasA) ts.lod0 = lod_from_grad((float)ta->w, (float)ta->h, dudx, dvdx, dudy, dvdy);
@@ -509,6 +580,41 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
     }
 }
 
+// p: positions; b0/b1: uv planes of the triangle.  Needs a valid Raster.
+template <class MP>   // const MeshParams* in the generic or the constant address space (kConstMesh)
+__device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, const Raster& rs, MP mp,
+                                                float4 b0, float2 b1, TriShade& ts) {
+    // The barycentrics feed the texture coordinates, where any rounding difference is amplified by the
+    // texture size and contrast: they follow the oracle's exact operation sequence
+    // lambda_i = float(E_i) * (1 / float(area2)) with exact integer E_i (DECISION-class arithmetic).
+    {
+#pragma clang fp contract(off)
+        ts.inva = 1.0f / (float)rs.area2;
+    }
+    const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+    ts.a1 = rs.a[1]; ts.b1 = rs.b[1]; ts.a2 = rs.a[2]; ts.b2 = rs.b[2];
+    ts.e1 = (long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1];
+    ts.e2 = (long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2];
+    ts.org = ((uint32_t)rs.y0 << 12) | (uint32_t)rs.x0;
+    tri_shade_rest(p, g, rs.a[1], rs.b[1], rs.a[2], rs.b[2], mp, b0, b1, ts);
+}
+
+// TriShadeS of one small triangle, straight from its 32-bit raster setup (raster_small; the same values tri_shade_setup computes
+// in 64 bits and the sparse kernel narrows: m2s_devfn.h, TriShadeS)
+template <class MP>
+__device__ __forceinline__ void tri_shade_small(const float p[9], const Geo& g, const RasterHead& h, const RasterSmall& rs, MP mp, float4 b0, float2 b1,
+                                                uint32_t m, TriShadeS& c) {
+    {
+#pragma clang fp contract(off)
+        c.inva = 1.0f / (float)rs.area2;     // area2 <= 2304^2 < 2^24: the conversion is exact, like (float)(long long) of the same value
+    }
+    c.a1 = (short)rs.a[1]; c.b1 = (short)rs.b[1]; c.a2 = (short)rs.a[2]; c.b2 = (short)rs.b[2];
+    c.e1 = rs.e[1]; c.e2 = rs.e[2];
+    c.org = ((uint32_t)h.y0 << 12) | (uint32_t)h.x0;
+    tri_shade_rest(p, g, rs.a[1], rs.b[1], rs.a[2], rs.b[2], mp, b0, b1, c);
+    c.mesh |= m;
+}
+
 // Texel addresses (in texels from the start of the mip chain) and bilinear weights of one level.
 struct TexTap {
     uint32_t o00, o10, o01, o11;
@@ -531,7 +637,8 @@ __device__ __forceinline__ void tex_tap(uint32_t W, uint32_t H, uint32_t level_o
     j0 = j0 < 0 ? j0 + (int)H : j0;
     i1 = i1 >= (int)W ? i1 - (int)W : i1;
     j1 = j1 >= (int)H ? j1 - (int)H : j1;
-    const uint32_t r0 = level_off + (uint32_t)j0 * W, r1 = level_off + (uint32_t)j1 * W;
+    // (rows and widths are below 2^24: the full-rate 24-bit multiply, not the quarter-rate v_mul_lo_u32)
+    const uint32_t r0 = level_off + __umul24((uint32_t)j0, W), r1 = level_off + __umul24((uint32_t)j1, W);
     t.o00 = r0 + (uint32_t)i0; t.o10 = r0 + (uint32_t)i1;
     t.o01 = r1 + (uint32_t)i0; t.o11 = r1 + (uint32_t)i1;
     const float na = 1.0f - a, nb = 1.0f - b;
@@ -623,8 +730,9 @@ __device__ __forceinline__ void combo_tap(uint32_t level_off, uint32_t W, uint32
     j0 = j0 < 0 ? j0 + (int)H : j0;
     j1 = j1 >= (int)H ? j1 - (int)H : j1;
     const uint32_t stride = W + 1;
-    t.o0 = level_off + ((uint32_t)j0 * stride + (uint32_t)i0) * 3u;
-    t.o1 = level_off + ((uint32_t)j1 * stride + (uint32_t)i0) * 3u;
+    // (rows and strides are below 2^24: the full-rate 24-bit multiply, not the quarter-rate v_mul_lo_u32)
+    t.o0 = level_off + (__umul24((uint32_t)j0, stride) + (uint32_t)i0) * 3u;
+    t.o1 = level_off + (__umul24((uint32_t)j1, stride) + (uint32_t)i0) * 3u;
     const float na = 1.0f - a, nb = 1.0f - b;
     t.w00 = na * nb; t.w10 = a * nb; t.w01 = na * b; t.w11 = a * b;
 }

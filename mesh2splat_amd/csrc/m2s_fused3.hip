@@ -109,19 +109,6 @@ __device__ __forceinline__ bool f3_get_base(F3Ctl& C, unsigned long long* chain,
     return true;
 }
 
-// TriShadeS of one small triangle (see tri_shade_setup; the narrowing is exact for boxes of at most 8 x 8 pixels with a sub-pixel
-// extent of at most 2304: m2s_devfn.h, TriShadeS)
-template <class MP>
-__device__ __forceinline__ void tri_shade_small(const float p[9], const Geo& g, const Raster& rs, MP mp, float4 b0, float2 b1, uint32_t m, TriShadeS& c) {
-    TriShade ts;
-    tri_shade_setup(p, g, rs, mp, b0, b1, ts);
-    c.a1 = (short)ts.a1; c.b1 = (short)ts.b1; c.a2 = (short)ts.a2; c.b2 = (short)ts.b2;
-    c.e1 = (int)ts.e1; c.e2 = (int)ts.e2;
-    c.inva = ts.inva; c.sx = ts.sx; c.sy = ts.sy; c.lod0 = ts.lod0;
-    c.rot = ts.rot;
-    c.lod1 = ts.lod1; c.lod2 = ts.lod2; c.org = ts.org; c.mesh = ts.mesh | m;
-}
-
 __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                       unsigned long long limit, float4* __restrict__ out,
                                                       unsigned long long* __restrict__ total_out,
@@ -177,11 +164,9 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
     {
         float p[9];
         Geo g;
-        Raster rs;
-        rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
-#pragma unroll
-        for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
-        bool ok = false;
+        RasterHead h;
+        h.x0 = h.y0 = 0; h.x1 = h.y1 = -1; h.ext = 0;
+        bool box = false;
         uint32_t m = 0;
         float4 uvb0 = make_float4(0, 0, 0, 0);
         float2 uvb1 = make_float2(0, 0);
@@ -197,56 +182,35 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
                 uvb1 = sc.tri.B1[t];
                 if (uniform_mesh) geo_setup_mp(p, kConstMesh(sc.meshes + m0), g);
                 else { m = find_mesh(sc, sc.tri_first + t); geo_setup_mp(p, sc.meshes + m, g); }
-                ok = raster_setup(g, R, rs);
+                box = raster_head(g, R, h);
             }
         }
-        const int w = rs.x1 - rs.x0 + 1, rows = rs.y1 - rs.y0 + 1;
-        if (ok) {
-            if (w <= 8 && rows <= 8 && rs.ext <= 2304) {
-                kind = kSmall;
-                const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
-                int e0 = (int)((long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0]) + ((rs.bias >> 0) & 1) - 1;
-                int e1 = (int)((long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1]) + ((rs.bias >> 1) & 1) - 1;
-                int e2 = (int)((long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2]) + ((rs.bias >> 2) & 1) - 1;
-                const int ax0 = rs.a[0] * 256, ax1 = rs.a[1] * 256, ax2 = rs.a[2] * 256;
-                const int by0 = rs.b[0] * 256, by1 = rs.b[1] * 256, by2 = rs.b[2] * 256;
-                for (int dy = 0; dy < rows; ++dy) {
-                    int r0 = e0, r1 = e1, r2 = e2;
-                    for (int dx = 0; dx < w; ++dx) {
-                        if ((r0 | r1 | r2) >= 0) mask |= 1ull << (dy * 8 + dx);
-                        r0 += ax0; r1 += ax1; r2 += ax2;
-                    }
-                    e0 += by0; e1 += by1; e2 += by2;
-                }
-                cnt = (uint32_t)__popcll(mask);
-            } else {
-                kind = kBig;           // counted below, emitted by k_emit_big
-            }
+        const int w = h.x1 - h.x0 + 1, rows = h.y1 - h.y0 + 1;
+        // small: shaded in this workgroup, all of its integer setup in 32 bits (raster_small)
+        RasterSmall rs;
+        bool small = box && w <= 8 && rows <= 8 && h.ext <= 2304;
+        if (small) small = raster_small(h, rs);
+        else if (box) kind = kBig;         // (unless it has no area: decided where the wave counts it, below)
+        {   // coverage of the small triangles, the wave walking rows and columns together (small_coverage, m2s_devfn.h)
+            uint32_t mlo = 0, mhi = 0;
+            small_coverage(small, w, rows, rs, mlo, mhi);
+            mask = (unsigned long long)mlo | ((unsigned long long)mhi << 32);
+            cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+            if (small) kind = kSmall;
         }
         // fragment constants of the triangles this workgroup shades itself: in place before any wait (see the file header)
         if (cnt != 0 && kind == kSmall) {
             TriShadeS c;
-            if (uniform_mesh) tri_shade_small(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, m, c);
-            else tri_shade_small(p, g, rs, sc.meshes + m, uvb0, uvb1, m, c);
+            if (uniform_mesh) tri_shade_small(p, g, h, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, m, c);
+            else tri_shade_small(p, g, h, rs, sc.meshes + m, uvb0, uvb1, m, c);
             const float4* src = reinterpret_cast<const float4*>(&c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) S.tri[wave][lane * 4 + k] = src[k];
         }
-        {   // larger triangles (rare): the whole wave counts one of them, a pixel row per lane
-            unsigned long long bigm = __ballot(kind == kBig);
-            while (bigm) {
-                const int src = __ffsll((long long)bigm) - 1;
-                bigm &= bigm - 1;
-                const Raster br = shfl_raster(rs, src);
-                uint32_t part = 0;
-                for (int y = br.y0 + lane; y <= br.y1; y += 64) {
-                    int xa, xb;
-                    row_span(br, y, xa, xb);
-                    part += (uint32_t)max(xb - xa + 1, 0);
-                }
-                part = wave_sum(part);
-                if (lane == src) cnt = part;
-            }
+        if (__ballot(kind == kBig) != 0ull) {   // larger triangles (rare): the whole wave counts one of them, a pixel row per lane
+            const Geo gc = g;   // (a copy: only IT lives in memory, for the call)
+            const uint32_t cb = count_larger(&gc, R, kind == kBig, 0, lane);
+            if (kind == kBig) cnt = cb;
         }
     }
     if (cnt == 0) kind = kNone;

@@ -211,3 +211,119 @@ def random_soup(n_tri: int, seed: int = 1, extent: float = 1.0, tri_size: float 
     v[..., 10:12] = rng.uniform(-0.5, 2.5, (n_tri, 3, 2))
     m = Mesh(name=name, vertices=v.reshape(-1, stride), base_color=(0.8, 0.6, 0.4, 0.9), textures=dict(textures or {}))
     return Scene([m])
+
+
+# ---- heterogeneous scene (round 5): what a real asset looks like to the converter ----------------------------------
+
+def _surface_mesh(P, dPds, dPdt, uv, stride: int = 12) -> np.ndarray:
+    """De-indexed triangles of a parametric grid: P, dPds, dPdt (nv+1, nu+1, 3) float64, uv (nv+1, nu+1, 2);
+    normal = normalize(dPds x dPdt), tangent = normalize(dPds) (w = +1).  Two triangles per cell: (00, 10, 11), (00, 11, 01)."""
+    n = np.cross(dPds, dPdt)
+    n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-30)
+    t = dPds / np.maximum(np.linalg.norm(dPds, axis=-1, keepdims=True), 1e-30)
+    att = np.concatenate([P, n, t, np.ones(P.shape[:2] + (1,)), uv], axis=-1)   # (nv+1, nu+1, 12)
+    a00, a10, a01, a11 = att[:-1, :-1], att[:-1, 1:], att[1:, :-1], att[1:, 1:]
+    tri = np.stack([a00, a10, a11, a00, a11, a01], axis=2)                        # (nv, nu, 6, 12)
+    v = np.zeros((tri.shape[0] * tri.shape[1] * 6, stride), np.float32)
+    v[:, :12] = tri.reshape(-1, 12)
+    return v
+
+
+def patch_vertices(nu: int, nv: int, origin, U, V, amp: float = 0.0, waves=(3.0, 2.0), uv_tile: float = 1.0,
+                   stride: int = 12) -> np.ndarray:
+    """nu x nv cells on the parallelogram origin + s U + t V (s, t in [0, 1]), displaced along its normal by
+    amp sin(2 pi w0 s) sin(2 pi w1 t): planes (amp = 0), cloth."""
+    origin, U, V = (np.asarray(x, np.float64) for x in (origin, U, V))
+    N = np.cross(U, V)
+    N /= np.linalg.norm(N)
+    s, t = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="xy")
+    w0, w1 = (2.0 * np.pi * w for w in waves)
+    d = amp * np.sin(w0 * s) * np.sin(w1 * t)
+    P = origin + s[..., None] * U + t[..., None] * V + d[..., None] * N
+    dPds = U + (amp * w0 * np.cos(w0 * s) * np.sin(w1 * t))[..., None] * N
+    dPdt = V + (amp * w1 * np.sin(w0 * s) * np.cos(w1 * t))[..., None] * N
+    uv = np.stack([s * uv_tile, t * uv_tile], -1)
+    return _surface_mesh(P, dPds, dPdt, uv, stride)
+
+
+def cylinder_vertices(seg: int, rings: int, base, radius: float, height: float, uv_tile: float = 1.0, stride: int = 12) -> np.ndarray:
+    """Open cylinder along +y: seg x rings cells."""
+    base = np.asarray(base, np.float64)
+    th, t = np.meshgrid(np.linspace(0.0, 2.0 * np.pi, seg + 1), np.linspace(0.0, 1.0, rings + 1), indexing="xy")
+    c, s_ = np.cos(th), np.sin(th)
+    P = base + np.stack([radius * c, height * t, radius * s_], -1)
+    dPds = np.stack([-radius * s_, np.zeros_like(th), radius * c], -1)
+    dPdt = np.broadcast_to(np.array([0.0, height, 0.0]), P.shape).copy()
+    uv = np.stack([th / (2.0 * np.pi) * uv_tile, t * uv_tile], -1)
+    return _surface_mesh(P, dPdt, dPds, uv, stride)   # (t, theta) order: outward normals
+
+
+def sponza_like(seed: int = SEED, combo_only: bool = False, tex_scale: float = 1.0, stride: int = 12) -> Scene:
+    """A Sponza-shaped workload (BASELINE config 4 names the real file, which no box here has): 64 meshes, ~267 k triangles whose
+    pixel areas at R = 1024 spread over six decades inside ONE scene — a 2-triangle floor across the whole bounding box (half a
+    million fragments per triangle), three 2-triangle walls, sixteen columns (~50-150 px per triangle), ten mid-size patches,
+    twenty-four props, eight sheets of dense cloth (a few pixels per triangle) and two of sub-pixel foliage (a fragment every
+    dozen triangles) — in shuffled mesh order behind the floor, materials with maps of 256^2 ... 2048^2, some with an albedo
+    map only, some with none (`combo_only`: every textured material carries all three maps, so the lean kernel is allowed).
+    The floor spans [0,1]^2 in x/z, so every cumulative bounding box has range 1 in each projection plane and a triangle's pixel
+    area is its projected world area times R^2.  ~3.5 M Gaussians at R = 1024 (under the reference's 7 M cap)."""
+    rng = np.random.default_rng(seed & 0xFFFFFFFF)
+    axes = np.eye(3)
+
+    def oriented(k):   # two in-plane unit vectors whose normal is axis k
+        return axes[(k + 1) % 3], axes[(k + 2) % 3]
+
+    meshes = []   # (name, vertices, tex size or 0, maps)
+    meshes.append(("floor", patch_vertices(1, 1, (0, 0, 1), (1, 0, 0), (0, 0, -1), uv_tile=8.0, stride=stride), 2048, 3))
+    rest = []
+    for i in range(3):
+        k = i % 3
+        U, V = oriented(k)
+        o = rng.uniform(0.05, 0.55, 3)
+        o[k] = rng.uniform(0.1, 0.5)
+        rest.append((f"wall_{i}", patch_vertices(1, 1, o, 0.4 * U, 0.4 * V, uv_tile=4.0, stride=stride), 1024, 3))
+    for i in range(16):
+        r, hgt = rng.uniform(0.015, 0.04), rng.uniform(0.3, 0.6)
+        b = (rng.uniform(0.05, 0.95), 0.0, rng.uniform(0.05, 0.95))
+        rest.append((f"column_{i}", cylinder_vertices(32, 16, b, r, hgt, stride=stride), 512 if i % 4 else 0, 3))
+    for i in range(10):
+        size = rng.uniform(0.1, 0.4)
+        U, V = oriented(int(rng.integers(0, 3)))
+        tilt = rng.normal(scale=0.15, size=3)
+        o = rng.uniform(0.0, 1.0 - size, 3) * (1.0, 0.5, 1.0)
+        rest.append((f"panel_{i}", patch_vertices(30, 30, o, size * (U + tilt * 0.5), size * (V - tilt * 0.5), amp=0.01 * size, stride=stride),
+                     (1024, 512)[i % 2], 3 if i % 3 else 1))
+    for i in range(24):
+        size = float(np.exp(rng.uniform(np.log(0.02), np.log(0.3))))
+        U, V = oriented(int(rng.integers(0, 3)))
+        o = rng.uniform(0.0, 1.0 - size, 3) * (1.0, 0.5, 1.0)
+        rest.append((f"prop_{i}", patch_vertices(12, 12, o, size * U, size * V, amp=0.05 * size, waves=(1.0, 1.0), stride=stride),
+                     (256, 512, 256, 0)[i % 4], 3 if i % 5 else 1))
+    for i in range(8):
+        size = rng.uniform(0.1, 0.4)
+        U, V = oriented(int(rng.integers(0, 3)))
+        o = rng.uniform(0.0, 1.0 - size, 3) * (1.0, 0.5, 1.0)
+        rest.append((f"cloth_{i}", patch_vertices(100, 100, o, size * U, size * V, amp=0.02, waves=(5.0, 3.0), uv_tile=2.0, stride=stride),
+                     (2048, 1024, 1024, 512)[i % 4], 3))
+    for i in range(2):
+        U, V = oriented(i)
+        o = rng.uniform(0.1, 0.8, 3) * (1.0, 0.5, 1.0)
+        rest.append((f"foliage_{i}", patch_vertices(128, 128, o, 0.05 * U, 0.05 * V, amp=0.004, waves=(9.0, 7.0), stride=stride), 512, 3))
+    order = rng.permutation(len(rest))
+    meshes += [rest[j] for j in order]
+    out = []
+    tex_cache = {}
+    for k, (name, v, tsize, maps) in enumerate(meshes):
+        tex = {}
+        if tsize:
+            ts = max(16, int(tsize * tex_scale))
+            if (ts, k % 7) not in tex_cache:
+                tex_cache[(ts, k % 7)] = procedural_textures(ts, seed + (k % 7))
+            full = tex_cache[(ts, k % 7)]
+            if maps == 3 or combo_only:
+                tex = dict(full)
+            else:
+                tex = {"baseColorTexture": full["baseColorTexture"]}
+        col = (0.6 + 0.4 * ((k * 37) % 11) / 10.0, 0.6 + 0.4 * ((k * 17) % 7) / 6.0, 0.9, 1.0)
+        out.append(Mesh(name=name, vertices=v, base_color=col, textures=tex))
+    return Scene(out)

@@ -153,10 +153,17 @@ def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, or
     c = Converter(0)
     c.upload_scene(scene)
     c.set_max_gaussians(0)
+    # AUTO takes the lean form for a scene of this size (round 5): ITS workgroups only keep triangles of at most 8 x 8 pixels, the
+    # cluster is deferred to k_emit_big and nothing overflows
+    assert c.convert(R) == ototal
+    assert c.last_pipeline == "lean"
+    assert_records_match(c.download(), orec, "lean form, cluster deferred")
+    c.set_pipeline("team")                                    # k_fused2 expands the cluster in the workgroup: that overflows
     for _ in range(2):
         assert c.convert(R) == ototal
         assert c.last_pipeline == "wave"                      # the team form gave up, the wave form answered
     assert_records_match(c.download(), orec, "fallback to k_fused")
+    c.set_pipeline("auto")
     # an ordinary scene runs the team form, several meshes included
     grid = synth.colocated_spheres(3, 150, 64)
     c.upload_scene(grid)
