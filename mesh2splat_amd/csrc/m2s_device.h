@@ -112,7 +112,8 @@ void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint
 // second-generation multi-pass pipeline (m2s_emit2.hip): count + scan + offsets in one kernel, wave-granular emit
 uint32_t emit2_slices(uint64_t limit);       // entries of start[] needed for `limit` output records
 uint32_t count_scan_blocks(uint32_t n_tri);  // chain words k_count_scan uses
-size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array
+size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array + the tall-triangle table behind it
+size_t setup_tall_offset(uint32_t n_tri);    // where that table's 16-byte header starts (zero when the buffer is allocated)
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
                        uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, hipStream_t st);
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,

@@ -50,9 +50,22 @@ struct TriSetup {
     int a0, b0;          // edge function opposite vertex 0 ...
     long long e0;        // ... and its value at the centre of pixel (x0, y0)
     uint32_t ext;        // x1 | y1 << 12 | bias << 24
-    uint32_t pad[3];
+    uint32_t tall;       // triangles of more than kRowsCount pixel rows: 1 + their slot in the tall-triangle table (0: none)
+    uint32_t pad[2];
 };
 static_assert(sizeof(TriSetup) == 112, "TriSetup must be seven float4");
+
+// Tall-triangle table (round 5), behind the TriSetup array in the same allocation: a 16-byte header (word 0: slots handed out in
+// this conversion) and kTallCap slots of 64 words.  Word j of a slot = fragments of its triangle in the pixel rows BEFORE row
+// y0 + 64 j.  k_count_scan counts such a triangle 64 rows at a time anyway and writes the running sums down; a slice of k_emit2
+// that starts deep inside the triangle (the floor of a Sponza-like scene: half a million fragments, a thousand slices, a
+// thousand rows) then begins at the 64-row chunk that holds its first record instead of walking every chunk above it.  A
+// conversion with more tall triangles than slots leaves the rest without one: they are walked from the top, as before.
+constexpr uint32_t kTallCap = 4096;
+constexpr uint32_t kTallChunks = 64;          // 4096 rows / 64
+__device__ __forceinline__ uint32_t* tall_header(const float4* setup, uint32_t n_tri) {
+    return reinterpret_cast<uint32_t*>(const_cast<float4*>(setup) + (size_t)max(n_tri, 1u) * 7);
+}
 
 __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
     Raster r;
@@ -113,20 +126,29 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
             c += (uint32_t)max(xb - xa + 1, 0);
         }
     }
-    {   // triangles spanning more rows: the whole wave counts one triangle, one row per lane
+    uint32_t tall_slot = 0;
+    {   // triangles spanning more rows: the whole wave counts one triangle, 64 rows at a time, one row per lane — and leaves the
+        // running sums in the tall-triangle table (see kTallCap) for k_emit2
         unsigned long long big = __ballot(ok && rows > kRowsCount);
+        uint32_t* const hdr = tall_header(setup, sc.n_tri);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
             const Raster b = shfl_raster(rs, src);
-            uint32_t part = 0;
-            for (int y = b.y0 + lane; y <= b.y1; y += 64) {
-                int xa, xb;
-                row_span(b, y, xa, xb);
-                part += (uint32_t)max(xb - xa + 1, 0);
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(&hdr[0], 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            const bool listed = slot < kTallCap;
+            uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
+            uint32_t run = 0, ci = 0;
+            for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
+                const int y = yc + lane;
+                int xa = 0, xb = -1;
+                if (y <= b.y1) row_span(b, y, xa, xb);
+                if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
+                run += wave_sum((uint32_t)max(xb - xa + 1, 0));
             }
-            part = wave_sum(part);
-            if (lane == src) c = part;
+            if (lane == src) { c = run; tall_slot = listed ? slot + 1u : 0u; }
         }
     }
     // ---- counts -> offsets: workgroup scan + decoupled look-back (chain word = one per workgroup) ----
@@ -155,7 +177,8 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         s.a0 = rs.a[0]; s.b0 = rs.b[0];
         s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
         s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
-        s.pad[0] = s.pad[1] = s.pad[2] = 0;
+        s.tall = tall_slot;
+        s.pad[0] = s.pad[1] = 0;
         const float4* src4 = reinterpret_cast<const float4*>(&s);
         float4* dst4 = setup + (size_t)t * 7;
 #pragma unroll
@@ -202,11 +225,9 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
 struct Emit2Lds {
     float4 tri[64 * 5];          // TriShade of the current batch of (up to) 64 triangles
     uint32_t entries[kSlice];    // slot << 24 | y << 12 | x, indexed by (record index - slice base)
-    float4 stage[32 * 6];        // half-wave record staging; during the expansion its first 512 bytes hold, for the
-                                 // wave-cooperative expansion of tall triangles, the row-length prefix and the first covered
-                                 // column of 64 consecutive rows (row_off / row_xa below) — the two uses never overlap in time
-    __device__ __forceinline__ uint32_t* row_off() { return reinterpret_cast<uint32_t*>(stage); }
-    __device__ __forceinline__ int* row_xa() { return reinterpret_cast<int*>(stage) + 64; }
+    float4 stage[32 * 6];        // half-wave record staging; during the expansion its first 64 bytes hold the row-start mask
+                                 // of the slice (one bit per record, row_mask below) — the two uses never overlap in time
+    __device__ __forceinline__ uint32_t* row_mask() { return reinterpret_cast<uint32_t*>(stage); }
 };
 static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of four waves per CU");
 
@@ -227,6 +248,8 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     // everywhere (triangles per slice, magnified or minified maps): on the C4 stand-in the kernel ran 7 % faster with NO mapping
     // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
     // inter-workgroup dependency, so any mapping is correct.
+    // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
+    if (blockIdx.x == 0 && threadIdx.x == 0) tall_header(setup, sc.n_tri)[0] = 0;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
     const uint32_t xcd = blockIdx.x & 7u, turn = (blockIdx.x >> 3) / run, in_run = (blockIdx.x >> 3) % run;
@@ -254,6 +277,7 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
         rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.bias = 0; rs.area2 = 1; rs.ext = 0;
 #pragma unroll
         for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
+        uint32_t tall_slot = 0;
         if (active) {
             TriSetup s;
             const float4* src4 = setup + (size_t)t * 7;
@@ -263,10 +287,28 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
 #pragma unroll
             for (int k = 0; k < 5; ++k) L.tri[lane * 5 + k] = dst4[k];
             rs = raster_from_setup(s);
+            tall_slot = s.tall;
         }
         // ---- expansion: (triangle slot, pixel) entries of [pos, bend), in canonical order ----
+        // Two steps (round 5).  (1) Row starts: whoever walks a triangle's rows — its own lane, or the whole wave for a tall one —
+        // writes ONE entry per covered row, at the row's first record inside [pos, bend), and sets that record's bit in a 512-bit
+        // mask.  (2) Fill: all 64 lanes sweep the range; a record's entry is the nearest row start at or before it plus the distance
+        // (in x).  Until round 5 the lane that owned a triangle wrote every one of its pixels itself: a slice inside triangles of
+        // 100-300 fragments (columns, panels of a Sponza-like scene) kept 2-5 lanes busy for hundreds of iterations while the other
+        // sixty waited — as long as the eight strips of shading that followed.
         const uint32_t tag = (uint32_t)lane << 24;
         const int rows = active ? rs.y1 - rs.y0 + 1 : 0;
+        uint32_t* const smask = L.row_mask();
+        if (lane < kSlice / 32) smask[lane] = 0;
+        wave_lds_sync();
+        auto mark_row = [&](uint32_t k_row, uint32_t len, uint32_t tag_y, int xa) {   // row = records [k_row, k_row + len), first pixel xa
+            if (len != 0 && k_row < bend && k_row + len > pos) {
+                const uint32_t st = max(k_row, pos);
+                const uint32_t i = st - wbase;
+                L.entries[i] = tag_y | (uint32_t)(xa + (int)(st - k_row));
+                atomicOr(&smask[i >> 5], 1u << (i & 31u));
+            }
+        };
         if (active && rows <= kRowsThread) {
             uint32_t k = o0;
             RowWalker rw;
@@ -275,10 +317,8 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
                 int xa, xb;
                 row_walker_next(rw, xa, xb);
                 const uint32_t len = (uint32_t)max(xb - xa + 1, 0);
-                if (k + len > pos) {
-                    for (int x = xa; x <= xb; ++x, ++k)
-                        if (k >= pos && k < bend) L.entries[k - wbase] = tag | ((uint32_t)y << 12) | (uint32_t)x;
-                } else k += len;
+                mark_row(k, len, tag | ((uint32_t)y << 12), xa);
+                k += len;
             }
         }
         unsigned long long big = __ballot(active && rows > kRowsThread);
@@ -288,30 +328,45 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
             const Raster b = shfl_raster(rs, src);
             const uint32_t btag = (uint32_t)src << 24;
             uint32_t acc = __shfl(o0, src);
-            for (int yc = b.y0; yc <= b.y1 && acc < bend; yc += 64) {
+            int yc0 = b.y0;
+            const uint32_t ts_ = (uint32_t)__shfl((int)tall_slot, src);
+            if (ts_ != 0 && pos > acc) {
+                // start at the 64-row chunk that holds record `pos`: the last chunk whose running sum does not exceed pos - acc
+                // (running sums never decrease; a chunk without fragments shares its sum with the next one and is skipped)
+                const uint32_t rel = pos - acc;
+                const int nch = min((b.y1 - b.y0) / 64 + 1, (int)kTallChunks);
+                const uint32_t* row = tall_header(setup, T) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
+                const uint32_t pre = lane < nch ? row[lane] : 0xFFFFFFFFu;
+                const unsigned long long le = __ballot(pre <= rel);
+                const int c0 = le ? 63 - __clzll((long long)le) : 0;
+                acc += (uint32_t)__shfl((int)pre, c0);
+                yc0 += 64 * c0;
+            }
+            for (int yc = yc0; yc <= b.y1 && acc < bend; yc += 64) {
                 const int y = yc + lane;
                 int xa = 0, xb = -1;
                 if (y <= b.y1) row_span(b, y, xa, xb);
                 const uint32_t len = (uint32_t)max(xb - xa + 1, 0);
                 const uint32_t incl = wave_incl_scan(len, lane);
                 const uint32_t chunk = __shfl(incl, 63);
-                if (acc + chunk > pos) {
-                    wave_lds_sync();
-                    L.row_off()[lane] = incl - len;
-                    L.row_xa()[lane] = xa;
-                    wave_lds_sync();
-                    const uint32_t lo = acc < pos ? pos - acc : 0;
-                    const uint32_t hi = acc + chunk > bend ? bend - acc : chunk;
-                    for (uint32_t k = lo + lane; k < hi; k += 64) {
-                        int r = 0;  // largest r with row_off[r] <= k
-#pragma unroll
-                        for (int step = 32; step >= 1; step >>= 1)
-                            if (L.row_off()[r + step] <= k) r += step;
-                        const int x = L.row_xa()[r] + (int)(k - L.row_off()[r]);
-                        L.entries[acc + k - wbase] = btag | ((uint32_t)(yc + r) << 12) | (uint32_t)x;
-                    }
-                }
+                if (acc + chunk > pos) mark_row(acc + (incl - len), len, btag | ((uint32_t)y << 12), xa);
                 acc += chunk;
+            }
+        }
+        wave_lds_sync();
+        {   // fill: every record of [pos, bend) lies in a marked row (the row that holds `pos` was clipped to start AT pos)
+            const uint32_t i0 = pos - wbase, i1 = bend - wbase;
+            uint32_t carry = 0;
+            for (uint32_t blk = i0 >> 6; blk <= (i1 - 1u) >> 6; ++blk) {
+                const uint32_t i = blk * 64u + (uint32_t)lane;
+                const uint32_t raw = L.entries[i];
+                const unsigned long long m = (unsigned long long)smask[2u * blk] | ((unsigned long long)smask[2u * blk + 1u] << 32);
+                const unsigned long long me = m & (~0ull >> (63 - lane));        // row starts at or before my record, in this block
+                const int srcl = me ? 63 - __clzll((long long)me) : lane;
+                const uint32_t from = (uint32_t)__shfl((int)raw, srcl);
+                const uint32_t e = me ? from + (uint32_t)(lane - srcl) : carry + (uint32_t)lane + 1u;
+                if (i >= i0 && i < i1) L.entries[i] = e;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)e, 63);
             }
         }
         wave_lds_sync();
@@ -359,7 +414,8 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 uint32_t emit2_slices(uint64_t limit) { return (uint32_t)((limit + kSlice - 1) / kSlice); }
 uint32_t count_scan_blocks(uint32_t n_tri) { return (n_tri + kCountBlock - 1) / kCountBlock; }
-size_t setup_bytes(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
+size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (size_t)kTallCap * kTallChunks * sizeof(uint32_t); }
+size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
 
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
                        uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, hipStream_t st) {

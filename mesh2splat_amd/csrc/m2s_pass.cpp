@@ -208,7 +208,11 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
         HIPCHK(c, hipMalloc((void**)&c->d_start, want * sizeof(uint32_t)));
         c->start_cap = want;
     }
-    if (!multipass_v1() && !c->d_setup) HIPCHK(c, hipMalloc(&c->d_setup, setup_bytes(c->scene.n_tri)));
+    if (!multipass_v1() && !c->d_setup) {
+        HIPCHK(c, hipMalloc(&c->d_setup, setup_bytes(c->scene.n_tri)));
+        HIPCHK(c, hipMemsetAsync((char*)c->d_setup + setup_tall_offset(c->scene.n_tri), 0, 16, c->stream));   // the tall-triangle table's slot counter
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return M2S_OK;
 }
 
@@ -240,7 +244,11 @@ m2s_status ensure_second_lane(m2s_ctx* c) {
 m2s_status ensure_second_lane_multipass(m2s_ctx* c, uint32_t n_start) {
     const size_t np = std::max<size_t>(c->scene.n_tri, 1);
     if (!c->d_off_b) HIPCHK(c, hipMalloc((void**)&c->d_off_b, (np + 1) * sizeof(uint32_t)));
-    if (!c->d_setup_b) HIPCHK(c, hipMalloc(&c->d_setup_b, setup_bytes(c->scene.n_tri)));
+    if (!c->d_setup_b) {
+        HIPCHK(c, hipMalloc(&c->d_setup_b, setup_bytes(c->scene.n_tri)));
+        HIPCHK(c, hipMemsetAsync((char*)c->d_setup_b + setup_tall_offset(c->scene.n_tri), 0, 16, c->stream_b));
+        HIPCHK(c, hipStreamSynchronize(c->stream_b));
+    }
     if (!c->d_total_b) HIPCHK(c, hipMalloc((void**)&c->d_total_b, sizeof(unsigned long long)));
     if (c->start_b_cap < n_start) {
         for (uint32_t q = 0; q < c->slot_count; ++q) {   // (a second-lane conversion in flight reads the old table)
