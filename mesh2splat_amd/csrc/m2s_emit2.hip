@@ -20,7 +20,17 @@
 //                 TriSetup of the (typically 5-60) triangles overlapping its slice, expands them into an LDS entry list
 //                 (row walker; triangles of more than 32 rows wave-cooperatively), and shades strips of 64 entries
 //                 exactly like the single-pass kernel does: record staged half a wave at a time, 16 B/lane non-temporal
-//                 stores.  10.5 KB of LDS per wave.  Output-partitioned, so balanced for ANY triangle size.
+//                 stores.  10 KB of LDS per wave.  Output-partitioned, so balanced for ANY triangle size.
+//   fine blocks   (round 5) Output partitioning has a bad case of its own: where triangles are much SMALLER than a pixel (foliage,
+//                 distant cloth: a fragment every dozen triangles) a slice of 512 records spans thousands of triangles, i.e. dozens of
+//                 64-triangle batches — each a dependent chain of global round trips (offsets, TriSetup, attributes, texels) —
+//                 walked by ONE wave: the heterogeneous scene's k_emit2 took 0.26 ms for 4.3 M fragments, 2.2 times the time per
+//                 fragment of the C4 stand-in, waiting for the ~30 waves inside its two foliage meshes.  k_count_scan therefore
+//                 classes every block of 256 triangles: FINE if the whole block yields at most 2048 fragments (and none of its
+//                 triangles is taller than 32 pixel rows).  Fine blocks are emitted triangle-partitioned — one workgroup per block,
+//                 one thread per triangle, the block's whole entry list in LDS, no inter-workgroup dependency because the offsets are
+//                 known — by extra workgroups of the SAME launch (emit_fine_block); the output-partitioned slices step over them
+//                 (one scalar load per block).  The pipeline choice has become a per-256-triangle decision taken on the device.
 // Output: bit-identical to every other pipeline (same device functions, same operation order).
 #include <cstdlib>
 #include "m2s_fused_common.h"
@@ -66,6 +76,11 @@ constexpr uint32_t kTallChunks = 64;          // 4096 rows / 64
 __device__ __forceinline__ uint32_t* tall_header(const float4* setup, uint32_t n_tri) {
     return reinterpret_cast<uint32_t*>(const_cast<float4*>(setup) + (size_t)max(n_tri, 1u) * 7);
 }
+// ... and behind that table one byte per block of kCountBlock triangles: 1 = fine block (see the file header)
+constexpr uint32_t kFineMax = 2048;           // fragments of a fine block: its entry list fits the workgroup's LDS
+__device__ __forceinline__ uint8_t* block_class(const float4* setup, uint32_t n_tri) {
+    return reinterpret_cast<uint8_t*>(tall_header(setup, n_tri) + 4 + (size_t)kTallCap * kTallChunks);
+}
 
 __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
     Raster r;
@@ -90,6 +105,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
                                                             unsigned long long* __restrict__ total_out,
                                                             float4* __restrict__ setup, uint32_t* __restrict__ status) {
     __shared__ uint32_t wsum[kCountBlock / 64];
+    __shared__ uint32_t wtall[kCountBlock / 64];
     __shared__ unsigned long long base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = blockIdx.x * kCountBlock;
@@ -153,14 +169,18 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     }
     // ---- counts -> offsets: workgroup scan + decoupled look-back (chain word = one per workgroup) ----
     const uint32_t incl = wave_incl_scan(c, lane);
-    if (lane == 63) wsum[wave] = incl;
+    const bool wave_tall = __ballot(ok && rows > kRowsThread) != 0ull;
+    if (lane == 63) { wsum[wave] = incl; wtall[wave] = wave_tall ? 1u : 0u; }
     __syncthreads();
-    uint32_t woff = 0, tot = 0;
+    uint32_t woff = 0, tot = 0, any_tall = 0;
 #pragma unroll
     for (int w = 0; w < kCountBlock / 64; ++w) {
         if (w < wave) woff += wsum[w];
         tot += wsum[w];
+        any_tall |= wtall[w];
     }
+    // the block's class: who emits its fragments (see the file header)
+    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[blockIdx.x] = (tot <= kFineMax && !any_tall) ? 1 : 0;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     // The workgroup's aggregate is published as soon as it is known — BEFORE the per-triangle setup records are computed and
     // stored: successors can resolve their bases while this workgroup is still busy, and this workgroup's own look-back
@@ -230,18 +250,111 @@ struct Emit2Lds {
     __device__ __forceinline__ uint32_t* row_mask() { return reinterpret_cast<uint32_t*>(stage); }
 };
 static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of four waves per CU");
+// a fine block's workgroup: the TriShade of its 256 triangles, its whole entry list, one staging area per wave — the same 40 KB
+struct FineLds {
+    float4 tri[kCountBlock * 5];
+    uint32_t entries[kFineMax];  // thread << 24 | y << 12 | x, indexed by (record index - block base)
+    float4 stage[kBlock / 64][32 * 6];
+};
+static_assert(sizeof(FineLds) == sizeof(Emit2Lds) * (kBlock / 64), "both kinds of workgroup of k_emit2 use the same LDS");
+static_assert(kCountBlock == kBlock, "a fine block is emitted by one thread per triangle");
+
+// One strip: the fragments whose entries are strip[0 .. n) (slot << 24 | y << 12 | x; slot = index into `tri`, triangle t_base +
+// slot) are shaded and written to dst[0 .. n) — staged half a wave at a time, 16 B per lane, non-temporal.
+__device__ __forceinline__ void shade_and_store_strip(const SceneDev& sc, const float4* tri, const uint32_t* strip, uint32_t n, uint32_t t_base,
+                                                      float4* stage, float4* __restrict__ dst, int lane) {
+    const bool have = (uint32_t)lane < n;
+    uint32_t en = 0;
+    if (have) en = strip[lane];
+    const uint32_t tl = en >> 24;
+    uint32_t my_mesh = 0;
+    if (have) my_mesh = reinterpret_cast<const uint32_t*>(&tri[tl * 5 + 4])[3] & 0xFFFFFFu;
+    const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
+    const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
+    float4 rec[6];
+    if (have) {
+        const TriShade& ts = *reinterpret_cast<const TriShade*>(&tri[tl * 5]);
+        const uint32_t tt = t_base + tl;
+        if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
+        else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (have && (lane >> 5) == half) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) stage[(lane & 31) * 6 + k] = rec[k];
+        }
+        wave_lds_sync();
+        float4* __restrict__ dsto = dst + 32u * half * 6u;
+        const uint32_t nv = n > 32u * half ? min(32u, n - 32u * half) : 0u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t q = (uint32_t)lane + 64u * j;
+            const uint32_t r = q / 6u;
+            if (r < nv) nt_store(&dsto[q], stage[q]);
+        }
+        wave_lds_sync();
+    }
+}
+
+// A fine block (at most kFineMax fragments from kCountBlock triangles of at most kRowsThread rows each): one thread per triangle
+// writes its pixels into the block's entry list, then the four waves take the strips in turn.
+__device__ __forceinline__ void emit_fine_block(const SceneDev& sc, const uint32_t* __restrict__ off, unsigned long long nw,
+                                                const float4* __restrict__ setup, float4* __restrict__ out, uint32_t blk, FineLds& F) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t T = sc.n_tri, t0 = blk * (uint32_t)kCountBlock, t1 = min(t0 + (uint32_t)kCountBlock, T);
+    const uint32_t base = off[t0], end = off[t1];
+    if (end <= base || (unsigned long long)base >= nw) return;
+    const uint32_t n_store = (uint32_t)min((unsigned long long)(end - base), nw - base);
+    const uint32_t t = t0 + threadIdx.x;
+    if (t < t1) {
+        const uint32_t o0 = off[t], o1 = off[t + 1];
+        if (o1 > o0 && o0 - base < n_store) {
+            TriSetup s;
+            const float4* src4 = setup + (size_t)t * 7;
+            float4* dst4 = reinterpret_cast<float4*>(&s);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) F.tri[threadIdx.x * 5 + k] = dst4[k];
+            const Raster rs = raster_from_setup(s);
+            const uint32_t tag = (uint32_t)threadIdx.x << 24;
+            uint32_t k = o0 - base;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
+            for (int y = rs.y0; y <= rs.y1 && k < n_store; ++y) {
+                int xa, xb;
+                row_walker_next(rw, xa, xb);
+                for (int x = xa; x <= xb && k < n_store; ++x, ++k) F.entries[k] = tag | ((uint32_t)y << 12) | (uint32_t)x;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s0 = wave * 64u; s0 < n_store; s0 += (uint32_t)kBlock)
+        shade_and_store_strip(sc, F.tri, &F.entries[s0], min(64u, n_store - s0), t0, F.stage[wave], out + ((size_t)base + s0) * 6, lane);
+}
 
 __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ start,
                                                      const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                      const float4* __restrict__ setup, float4* __restrict__ out,
                                                      uint32_t run /* consecutive workgroups per XCD turn */) {
-    __shared__ Emit2Lds lds_all[kBlock / 64];
+    __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Emit2Lds& L = lds_all[wave];
     const unsigned long long total = *total_p;
     const unsigned long long nw = total < limit ? total : limit;  // records actually stored
+    const uint32_t T = sc.n_tri;
+    const uint8_t* __restrict__ cls = block_class(setup, T);
+    // the first workgroups of the launch (one per block of triangles, rounded up to whole groups of eight) take the FINE blocks
+    const uint32_t n_tb = (T + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock, n_fine_wg = (n_tb + 7u) & ~7u;
+    if (blockIdx.x < n_fine_wg) {
+        if (blockIdx.x < n_tb && cls[blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
+        return;
+    }
+    const uint32_t bid = blockIdx.x - n_fine_wg;
+    Emit2Lds& L = reinterpret_cast<Emit2Lds*>(lds_raw)[wave];
     // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): the XCDs take turns of `run` consecutive
     // workgroups — runs of the output, of the mesh surface, of texture space meet in ONE L2 —, block-cyclically.  Until round 3
     // every XCD had one contiguous EIGHTH of the output: fine for one uniform mesh, but a record does not cost the same
@@ -249,10 +362,10 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
     // inter-workgroup dependency, so any mapping is correct.
     // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
-    if (blockIdx.x == 0 && threadIdx.x == 0) tall_header(setup, sc.n_tri)[0] = 0;
+    if (bid == 0 && threadIdx.x == 0) tall_header(setup, T)[0] = 0;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
-    const uint32_t xcd = blockIdx.x & 7u, turn = (blockIdx.x >> 3) / run, in_run = (blockIdx.x >> 3) % run;
+    const uint32_t xcd = bid & 7u, turn = (bid >> 3) / run, in_run = (bid >> 3) % run;
     const uint32_t lblock = (turn * 8u + xcd) * run + in_run;
     if (lblock >= nblk) return;
     const uint32_t slice = lblock * (kBlock / 64) + wave;
@@ -260,19 +373,26 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     if (wbase64 >= nw) return;
     const uint32_t wbase = (uint32_t)wbase64;
     const uint32_t wend = (uint32_t)(nw - wbase64 < (unsigned long long)kSlice ? nw : wbase64 + kSlice);
-    const uint32_t T = sc.n_tri;
 
     uint32_t pos = wbase;                 // next record to produce
-    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; t_cur += 64) {
-        // ---- the batch: 64 consecutive triangles, one per lane ----
+    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; ) {
+        // ---- the batch: up to 64 consecutive triangles, one per lane.  A fine block is stepped over; a batch that would run from a
+        // dense block into a fine one ends at the block boundary.  Everything the decision needs is requested at once (the classes of
+        // this block and the next, the offsets at both possible ends, the lanes' own offsets): one round trip, as before round 5 ----
+        const uint32_t blk = t_cur / (uint32_t)kCountBlock;
+        const uint32_t blk_end = min((blk + 1u) * (uint32_t)kCountBlock, T);
+        const uint32_t t_full = min(t_cur + 64u, T);
         const uint32_t t = t_cur + lane;
         uint32_t o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
-        if (t < T) { o0 = off[t]; o1 = off[t + 1]; }
-        // records of this batch: [pos, bend)
-        const uint32_t t_next = min(t_cur + 64u, T);
-        const uint32_t o_next = off[t_next];                 // (scalar) first record of the next batch
-        const uint32_t bend = min(wend, o_next);
-        const bool active = (o1 > o0) && (o0 < bend) && (o1 > pos);
+        if (t < t_full) { o0 = off[t]; o1 = off[t + 1]; }
+        const uint32_t c_here = cls[blk], c_next = t_full > blk_end ? cls[blk + 1u] : 0u;
+        const uint32_t o_full = off[t_full], o_blk = off[blk_end];
+        const bool fine_blk = c_here != 0;
+        const uint32_t t_next = (fine_blk || c_next != 0) ? blk_end : t_full;
+        const uint32_t o_next = t_next == t_full ? o_full : o_blk;   // first record of the next batch
+        const uint32_t bend = min(wend, o_next);             // records of this batch: [pos, bend)
+        if (fine_blk) { pos = bend; t_cur = t_next; continue; }   // (those records are emit_fine_block's)
+        const bool active = (t < t_next) && (o1 > o0) && (o0 < bend) && (o1 > pos);
         Raster rs;
         rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.bias = 0; rs.area2 = 1; rs.ext = 0;
 #pragma unroll
@@ -371,50 +491,17 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
         }
         wave_lds_sync();
         // ---- fragment phase: strips of 64 entries ----
-        uint32_t s_begin = pos;
-        for (uint32_t s0 = s_begin; s0 < bend; s0 += 64) {
-            const uint32_t n = min(64u, bend - s0);
-            const bool have = (uint32_t)lane < n;
-            uint32_t en = 0;
-            if (have) en = L.entries[s0 - wbase + lane];
-            const uint32_t tl = (en >> 24) & 63u;
-            uint32_t my_mesh = 0;
-            if (have) my_mesh = reinterpret_cast<const uint32_t*>(&L.tri[tl * 5 + 4])[3] & 0xFFFFFFu;
-            const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
-            const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
-            float4 rec[6];
-            if (have) {
-                const TriShade& ts = *reinterpret_cast<const TriShade*>(&L.tri[tl * 5]);
-                const uint32_t tt = t_cur + tl;
-                if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
-                else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
-            }
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                if (have && (lane >> 5) == half) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) L.stage[(lane & 31) * 6 + k] = rec[k];
-                }
-                wave_lds_sync();
-                float4* __restrict__ dsto = out + ((size_t)s0 + 32u * half) * 6;
-                const uint32_t nv = n > 32u * half ? min(32u, n - 32u * half) : 0u;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const uint32_t q = (uint32_t)lane + 64u * j;
-                    const uint32_t r = q / 6u;
-                    if (r < nv) nt_store(&dsto[q], L.stage[q]);
-                }
-                wave_lds_sync();
-            }
-        }
+        for (uint32_t s0 = pos; s0 < bend; s0 += 64)
+            shade_and_store_strip(sc, L.tri, &L.entries[s0 - wbase], min(64u, bend - s0), t_cur, L.stage, out + (size_t)s0 * 6, lane);
         pos = bend;
+        t_cur = t_next;
     }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 uint32_t emit2_slices(uint64_t limit) { return (uint32_t)((limit + kSlice - 1) / kSlice); }
 uint32_t count_scan_blocks(uint32_t n_tri) { return (n_tri + kCountBlock - 1) / kCountBlock; }
-size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (size_t)kTallCap * kTallChunks * sizeof(uint32_t); }
+size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (size_t)kTallCap * kTallChunks * sizeof(uint32_t) + ((count_scan_blocks(n_tri) + 63u) & ~63u); }
 size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
 
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
@@ -432,6 +519,7 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
     uint32_t run = 16;                          // workgroups per XCD turn (profiles/r03/ab_emit2_xcd_turns.log)
     if (const char* v = debug_env("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
     n_blocks = (n_blocks + 8u * run - 1u) / (8u * run) * (8u * run);   // whole rounds of turns; surplus workgroups leave at once
+    n_blocks += (count_scan_blocks(sc.n_tri) + 7u) & ~7u;              // in front of them: one workgroup per block of triangles (the fine blocks)
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
                        (const float4*)setup, out, run);
 }
