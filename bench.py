@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
     ap.add_argument("--one-device", action="store_true",
                     help="tests: every rank on device 0 (several processes share one GPU; needs an RCCL stand-in that allows it: M2S_RCCL_PATH)")
+    ap.add_argument("--pipeline", default=None, choices=["auto", "multipass", "wave", "team", "sparse", "lean"],
+                    help="A/B: force a pipeline setting for the headline workload (default: the library's AUTO)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()
@@ -259,10 +261,12 @@ def self_launch(a) -> int:
 class Rig:
     """One rank's converter on one scene + the step loops (pipelined or blocking), shared by the headline and the extras."""
 
-    def __init__(self, torch, local_rank, scene, R, tri_range=None, cap=-1, out_rows=None, exchange=None):
+    def __init__(self, torch, local_rank, scene, R, tri_range=None, cap=-1, out_rows=None, exchange=None, pipeline=None):
         from mesh2splat_amd.converter import Converter
         self.torch, self.R, self.exchange = torch, R, exchange
         self.conv = Converter(local_rank)
+        if pipeline:
+            self.conv.set_pipeline(pipeline)
         if tri_range is not None:
             self.conv.set_triangle_range(*tri_range)
         self.conv.upload_scene(scene)
@@ -400,8 +404,9 @@ def whole_conversion_roofline(total_stored, tri, ms, traffic_key=None):
 def cold_path(torch, local_rank, scene, R, steady_sync_ms):
     """What a conversion costs when nothing is warm (the reference converts on load and on every move of the density
     slider, guiRendererConcreteMediator.cpp:51-57 — always a NEW (scene, R)):
-      first_call_ms  fresh context, scene uploaded, first m2s_convert (includes the exact count that decides the pipeline
-                     and the allocation of the record pool);
+      first_call_ms  fresh context, resolution hinted, scene uploaded, first m2s_convert.  (Since round 4 the exact count that decides
+                     the pipeline, the run table and the record pool are prepared by m2s_upload_scene at the hinted R — its "warm"
+                     share is upload_ms["warm"]; first_call_plus_warm_ms adds it back for comparison with round 3);
       new_R_ms       blocking conversions at densities this context has never seen (R, R-8, R-16, ...): no cached decision,
                      no cached band bases, cap changes every time;
       cold_inputs    three independent copies of the scene (> 700 MB of inputs: more than the 256 MiB Infinity Cache) converted
@@ -410,12 +415,16 @@ def cold_path(torch, local_rank, scene, R, steady_sync_ms):
     from mesh2splat_amd.converter import Converter
     out = {}
     conv = Converter(local_rank)
+    conv.set_resolution_hint(R)      # the reference knows its resolutionTarget when it loads a model (guiRendererConcreteMediator.cpp:11-29)
     conv.upload_scene(scene)
     out["upload_ms"] = conv.last_upload_ms()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     total = conv.convert(R)
     out["first_call_ms"] = (time.perf_counter() - t0) * 1e3
+    # since round 4 the exact count, the pipeline decision, the run table and the record pool are prepared inside m2s_upload_scene
+    # (warm_scene: upload_ms["warm"]), at the hinted R: the cost of a first conversion as round 3 measured it is the sum
+    out["first_call_plus_warm_ms"] = out["first_call_ms"] + out["upload_ms"]["warm"]
     t0 = time.perf_counter()
     conv.convert(R)
     out["second_call_ms"] = (time.perf_counter() - t0) * 1e3
@@ -722,7 +731,7 @@ def main():
     # N == 1: the reference's own cap formula.  N > 1: the merged scene exceeds the reference's 7 M envelope,
     # so the cap is lifted and each rank writes into its own buffer; the counters are exchanged every step (RCCL, C ABI).
     rig = Rig(torch, local_rank, scene, R, tri_range=(rank * tri_per_mesh, tri_per_mesh), cap=0 if multi else -1,
-              out_rows=0 if multi else None, exchange=exchange)
+              out_rows=0 if multi else None, exchange=exchange, pipeline=a.pipeline)
     T_local = rig.conv.num_triangles
     dt, total = timed_loop(torch, dist, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
     ntot = torch.tensor([total], dtype=torch.int64, device=CTL)
@@ -998,6 +1007,7 @@ def main():
                                 "against the north star's 40 % is made on frac_step and frac_blocking (whole steps, host included).")
             if "first_call_ms" in cp:
                 rf["frac_first_call"] = b / (cp["first_call_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rf["frac_first_call_including_warm"] = b / (cp["first_call_plus_warm_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                 # (the other densities move (R'/R)^2 of the records: scale the bytes of the record part accordingly)
                 rs = cp["new_R_ms"]["densities"]
                 scale = float(np.mean([(r / R) ** 2 for r in rs])) if rs else 1.0

@@ -269,7 +269,11 @@ m2s_status m2s_upload_records(m2s_ctx* ctx, const m2s_gaussian* records, uint64_
 
 /* Records that already live in device memory (e.g. the merged buffer of m2s_dist_gather_records) become the context's current
  * records without a copy: m2s_num_stored / m2s_download / m2s_export_ply (scale multiplier = std / R) / m2s_prepass /
- * m2s_sort_by_depth then refer to them.  The memory stays the caller's and must outlive those calls. */
+ * m2s_sort_by_depth then refer to them.  The memory stays the caller's and must outlive those calls.
+ * The context caches what it derives from the current records (m2s_sort_by_depth: the plane of positions its keys are built from)
+ * under (pointer, n, a counter bumped by every conversion / m2s_upload_records / m2s_set_records).  A caller that REWRITES a buffer
+ * in place — the one adopted here, or one handed to m2s_convert_into by a kernel of its own — must call m2s_set_records again
+ * afterwards: without it later sorts would order the new records by the old positions. */
 m2s_status m2s_set_records(m2s_ctx* ctx, const void* d_records, uint64_t n, uint32_t R);
 /* Room for n records in the context-owned pool (grow-only, like the conversion's own allocation); *out_ptr = device address. */
 m2s_status m2s_reserve_records(m2s_ctx* ctx, uint64_t n, void** out_ptr);

@@ -40,7 +40,7 @@ void free_scene(m2s_ctx* c) {
     c->rinfo.clear();
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
-    c->warm_R = 0;
+    c->warm_R = 0; c->warm_total = 0; c->warm_mismatch_seen = false;
     c->sparse_off_R = c->team_off_R = c->lean_off_R = UINT32_MAX;
     c->lean_ok = false;
     c->scene = SceneDev{};

@@ -70,6 +70,8 @@ struct m2s_ctx {
     uint32_t rinfo_gen = 0;
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene: from the exact count m2s_upload_scene takes (warm_scene), refreshed by every conversion
+    uint64_t warm_total = 0;                // fragments of the scene at warm_R (exact: warm_scene's count)
+    bool warm_mismatch_seen = false;        // a launch in runs disagreed with that count once (run_pass): not retried again
     uint32_t hint_R = 0;                    // m2s_set_resolution_hint: the R the next upload prepares for (0: the last R converted at, else 1024)
     uint32_t warm_R = 0;                    // the R the resident scene was prepared for
     unsigned long long* d_bands = nullptr;  // kBandSlots run tables of run_table_words words each (RunInfo, m2s_device.h)

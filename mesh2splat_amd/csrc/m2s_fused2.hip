@@ -209,22 +209,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     uint32_t cnt = 0;
     if (ok) {
         if (w <= 8 && rows <= 8 && rs.ext <= 2304) {
-            kind = kSmall;
-            const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
-            int e0 = (int)((long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0]) + ((rs.bias >> 0) & 1) - 1;
-            int e1 = (int)((long long)rs.a[1] * Px0 + (long long)rs.b[1] * Py0 + rs.c[1]) + ((rs.bias >> 1) & 1) - 1;
-            int e2 = (int)((long long)rs.a[2] * Px0 + (long long)rs.b[2] * Py0 + rs.c[2]) + ((rs.bias >> 2) & 1) - 1;
-            const int ax0 = rs.a[0] * 256, ax1 = rs.a[1] * 256, ax2 = rs.a[2] * 256;
-            const int by0 = rs.b[0] * 256, by1 = rs.b[1] * 256, by2 = rs.b[2] * 256;
-            for (int dy = 0; dy < rows; ++dy) {
-                int r0 = e0, r1 = e1, r2 = e2;
-                for (int dx = 0; dx < w; ++dx) {
-                    if ((r0 | r1 | r2) >= 0) mask |= 1ull << (dy * 8 + dx);
-                    r0 += ax0; r1 += ax1; r2 += ax2;
-                }
-                e0 += by0; e1 += by1; e2 += by2;
-            }
-            cnt = (uint32_t)__popcll(mask);
+            kind = kSmall;       // (its coverage: below, by the whole wave at once)
         } else if (rows <= kRowsCount) {
             kind = rows <= kFusedRows ? kMedium : kBig;
             RowWalker rw;
@@ -237,6 +222,26 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
             if (cnt > kBigCount) kind = kBig;
         } else {
             kind = kBig;
+        }
+    }
+    {   // coverage of the small triangles, the wave walking rows and columns together (small_coverage, m2s_devfn.h)
+        RasterSmall rsm;
+        if (kind == kSmall) {
+            // (edge values at the centre of the box-origin pixel: below 2^31 for such boxes, so the low words of raster_setup's 64-bit
+            //  constants give them)
+            const uint32_t Px0 = 256u * (uint32_t)rs.x0 + 128u, Py0 = 256u * (uint32_t)rs.y0 + 128u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rsm.a[i] = rs.a[i]; rsm.b[i] = rs.b[i];
+                rsm.e[i] = (int)((uint32_t)rs.a[i] * Px0 + (uint32_t)rs.b[i] * Py0 + (uint32_t)rs.c[i]);
+            }
+            rsm.bias = rs.bias; rsm.area2 = 0;
+        }
+        uint32_t mlo = 0, mhi = 0;
+        small_coverage(kind == kSmall, w, rows, rsm, mlo, mhi);
+        if (kind == kSmall) {
+            mask = (unsigned long long)mlo | ((unsigned long long)mhi << 32);
+            cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
         }
     }
     {

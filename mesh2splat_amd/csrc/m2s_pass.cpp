@@ -117,6 +117,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     const uint64_t total = c->h_total[0];
     c->frag_per_R2 = (double)total / ((double)R * (double)R);
     c->warm_R = R;
+    c->warm_total = total;
     // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
     // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
     // cube-sphere face).  Work = 214 per triangle + 140 per fragment (cycles of the triangle phase per 64 triangles and of a strip
@@ -181,12 +182,17 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
             ri.bands_ready = true; ri.bands_unit = unit;
         }
     }
-    // allocations a first conversion would otherwise make inside its own call; best effort (the conversion reports a failure)
+    // allocations a first conversion would otherwise make inside its own call; best effort (the conversion reports a failure).
+    // Only for a caller that has said at which R it is about to convert (m2s_set_resolution_hint: the command line, the drop-in
+    // ConversionPass, the reference's load-then-convert flow) or whose context already owns a record pool: a context that only ever
+    // converts into its caller's buffers (m2s_convert_into: the ranks of a multi-GPU job) does not carry 600 MB it never uses.
     const uint64_t want = cap ? cap : std::max<uint64_t>(total, 1);
-    if (!single || total >= 8ull * sc.n_tri) (void)ensure_multipass_buffers(c, std::min<uint64_t>(cap ? cap : want, 0xFFFFFFFFull));
-    // (touching the pool here does not pay: a hipMemset of the part the first conversion writes made that conversion 0.014 ms
-    //  SLOWER on config 3, 0.185 vs 0.171 ms — profiles/r04/first_call_probe.jsonl)
-    (void)ensure_records(c, want);
+    if (c->hint_R != 0 || c->d_records != nullptr) {
+        if (!single || total >= 8ull * sc.n_tri) (void)ensure_multipass_buffers(c, std::min<uint64_t>(cap ? cap : want, 0xFFFFFFFFull));
+        // (touching the pool here does not pay: a hipMemset of the part the first conversion writes made that conversion 0.014 ms
+        //  SLOWER on config 3, 0.185 vs 0.171 ms — profiles/r04/first_call_probe.jsonl)
+        (void)ensure_records(c, want);
+    }
     c->err.clear();
     return M2S_OK;
 }
@@ -398,12 +404,13 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
             const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
+            const RunInfo runs = (sparse || team) ? bands_for(c, ri, unit, true, &wrote_bands) : RunInfo{ nullptr, nullptr, 0u, nullptr };
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                      c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), st);
+                                      c->d_biglist, c->d_bigmeta, runs, st);
             else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, bands_for(c, ri, unit, true, &wrote_bands), batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -414,6 +421,17 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             err = (uint32_t)(c->h_total[1] >> 32);
             c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
             if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
+            // A launch in runs trusts the run table: at the R the scene was counted at (warm_scene), that table comes from k_count's
+            // counts, not from a launch of this kernel.  The two must agree on every triangle; if the totals ever differ, the table is
+            // dropped and the conversion repeated in plain order (until now only the parity tests guarded this)
+            if (runs.base && !err && R == c->warm_R && c->h_total[0] != c->warm_total && !c->warm_mismatch_seen) {
+                c->warm_mismatch_seen = true;
+                ri.bands_ready = false;
+                if (debug_on("M2S_DEBUG")) fprintf(stderr, "[m2s] run table of R = %u disagrees with the launch (%llu vs %llu fragments): repeated without runs\n",
+                                                   R, (unsigned long long)c->warm_total, (unsigned long long)c->h_total[0]);
+                HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
+                continue;
+            }
             if (err && debug_on("M2S_DEBUG"))
                 fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : lean ? "lean" : team ? "team" : "wave", err, R);
             if (lean && !err && any_big && c->pipeline == M2S_PIPELINE_AUTO) {
