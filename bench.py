@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK /
-WORLD_SIZE in the environment) or typed as is — bench.py then starts the N ranks itself (one process per GPU).
+N > 1 works both ways: started by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* for one process per GPU (the
+driver's torchrun does), or typed as is — bench.py then starts the N ranks itself.  The ranks meet in a directory for the 128-byte
+RCCL id (mesh2splat_amd/ctl.py); every collective after that — data path, barriers, timing reductions — is the C-ABI communicator's
+(m2s_dist_*: RCCL behind libm2s_hip.so).  No second process group next to it.
+`--gpus N --dry-scale` runs that whole schedule on ONE GPU through the RCCL stand-in of tests/stub_rccl (CI; not a transport measurement).
 
 A "step" is one execution of the conversion pass (== ConversionPass::execute) on geometry and textures already resident
 in HBM.  Headline workload (BASELINE.json configs[2], the one the metric is quoted on): I-3 = cube-sphere n=289
@@ -36,7 +39,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-CTL = "cpu"   # where the control-plane tensors of torch.distributed live: "cpu" on the gloo process group (default), "cuda" on nccl
 
 WORKLOADS = {
     # name: (cube-sphere n, texture size, R)
@@ -45,6 +47,7 @@ WORKLOADS = {
     "small": (24, 256, 256),   # CI-sized
     "c4": ("grid", 1024, 1024),  # Sponza stand-in (I-4): 64 meshes x cube-sphere n=18 (radius 0.12 s: 6.6 M Gaussians, under the 7 M cap), 64 materials
     "mid": (94, 2048, 1024),   # one mesh, 106 032 triangles, ~26 fragments per triangle (Sponza-like triangle sizes)
+    "band": (140, 2048, 1024),  # one mesh, 235 200 triangles, 11.6 fragments per triangle: the band where AUTO runs the team kernel in batches of 40 triangles
     "hetero": ("sponza_like", 0, 1024),  # synth.sponza_like: 64 meshes, 266 840 triangles from 0.1 to 500 000 px each, maps of 256^2 ... 2048^2, some materials without
 }
 
@@ -66,7 +69,12 @@ def parse():
     ap.add_argument("--sync-steps", action="store_true", help="one blocking m2s_convert per step instead of the two-deep pipeline")
     ap.add_argument("--no-extra-workloads", action="store_true", help="skip the C2 / mid-size / C4 lines (and the C4 strong-scaling run at N > 1)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="N > 1: seconds after which the multi-GPU extras are abandoned and the headline line is printed")
+    ap.add_argument("--no-strong-scaling", action="store_true", help="N > 1: skip the strong-scaling section (one scene cut into N ranges)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path measurements (first call, new R, rotating scene copies)")
+    ap.add_argument("--dry-scale", action="store_true",
+                    help="with --gpus N: the whole N-process schedule (bring-up, weak-scaling loop, record exchange, strong scaling) on ONE "
+                         "GPU through the RCCL stand-in of tests/stub_rccl: what a CI box can run; the line has the shape of a real "
+                         "SCALE record (scale_record) and says dry_scale: true.  Not a measurement of a transport")
     ap.add_argument("--one-device", action="store_true",
                     help="tests: every rank on device 0 (several processes share one GPU; needs an RCCL stand-in that allows it: M2S_RCCL_PATH)")
     ap.add_argument("--pipeline", default=None, choices=["auto", "multipass", "wave", "team", "sparse", "lean"],
@@ -244,18 +252,37 @@ def viewer_extra(conv, R, total):
 
 
 def self_launch(a) -> int:
-    """`python bench.py --gpus N` typed by hand (no torchrun): start N ranks ourselves, one per GPU, and relay their output."""
+    """`python bench.py --gpus N` typed by hand: start N ranks ourselves, one per GPU — plain processes with the launcher
+    environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT); the ranks meet through mesh2splat_amd/ctl.py."""
     import socket
     import subprocess
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
+    port = s.getsockname()[1]      # (only names the rendezvous directory)
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = p_.wait() or rc
+    return rc
+
+
+def dry_scale_env(a):
+    """--dry-scale: the RCCL stand-in of the tests (shared memory on one device) selected through M2S_RCCL_PATH, every rank on device 0."""
+    import tempfile
+    stub = os.path.join(ROOT, "tests", "stub_rccl", "_build", "librccl_stub.so")
+    if not os.path.exists(stub):
+        raise SystemExit("--dry-scale needs tests/stub_rccl/_build/librccl_stub.so: python -c 'import __graft_entry__ as g; g.build()'")
+    tmp = tempfile.mkdtemp(prefix="m2s_dry_scale_")
+    os.makedirs(os.path.join(tmp, "objs"), exist_ok=True)
+    os.environ.update(M2S_RCCL_PATH=stub, M2S_STUB_RCCL_DIR=os.path.join(tmp, "objs"), M2S_STUB_RCCL_LOG=os.path.join(tmp, "rccl_log"))
+    os.environ.setdefault("M2S_STUB_RCCL_TIMEOUT", "120")
+    if "--one-device" not in sys.argv:
+        sys.argv.append("--one-device")
 
 
 class Rig:
@@ -353,12 +380,12 @@ class Rig:
         self.conv.close()
 
 
-def timed_loop(torch, dist, multi, rig, steps, warmup, sync_steps=False):
+def timed_loop(torch, ctl, multi, rig, steps, warmup, sync_steps=False):
     """warmup, barrier + sync, `steps` conversions, barrier + sync; returns (seconds (max over ranks), last counter)"""
     def sync():
         torch.cuda.synchronize()
         if multi:
-            dist.barrier()
+            ctl.barrier()
         torch.cuda.synchronize()
     if warmup:
         rig.run(warmup, sync_steps=sync_steps)
@@ -371,9 +398,7 @@ def timed_loop(torch, dist, multi, rig, steps, warmup, sync_steps=False):
     sync()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=CTL)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = ctl.max_float(dt)
     return dt, total
 
 
@@ -473,7 +498,7 @@ def cold_path(torch, local_rank, scene, R, steady_sync_ms):
     return out
 
 
-def extra_workload(torch, dist, local_rank, name, steps=24, warmup=3):
+def extra_workload(torch, ctl, local_rank, name, steps=24, warmup=3):
     """One more BASELINE config on this GPU: whole-conversion ms, Gaussians/s, roofline fraction by algorithmic bytes."""
     from mesh2splat_amd import synth
     if name == "c5":
@@ -481,7 +506,7 @@ def extra_workload(torch, dist, local_rank, name, steps=24, warmup=3):
     n, tex, R = WORKLOADS[name]
     scene = synth.sponza_like() if n == "sponza_like" else synth.sponza_standin(tex) if n == "grid" else synth.colocated_spheres(1, n, tex)
     rig = Rig(torch, local_rank, scene, R)
-    dt, total = timed_loop(torch, dist, False, rig, steps, warmup)
+    dt, total = timed_loop(torch, ctl, False, rig, steps, warmup)
     ms = dt / steps * 1e3
     k = rig.kernel_ms()
     kern = sum(k.values())
@@ -614,6 +639,8 @@ class stdout_to_stderr:
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if a.dry_scale:
+            dry_scale_env(a)
         raise SystemExit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -624,58 +651,46 @@ def main():
         local_rank = 0
 
     import torch  # first, so that the HIP runtime torch ships is the one the process uses
-    import torch.distributed as dist
     import numpy as np
     from mesh2splat_amd import synth
     from mesh2splat_amd import dist as m2d
+    from mesh2splat_amd.ctl import Ctl
 
     torch.cuda.set_device(local_rank)
     multi = world > 1 or a.force_dist
     exchange = None
     phases = {}          # multi-GPU: how long each bring-up step took on this rank, and every error met on the way (-> the JSON line)
     dist_errors = []
-    global CTL
+    ctl = Ctl(rank, world)
     if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own account of a failure goes to stderr
-        # ONE user of RCCL per process: the C-ABI communicator (m2s_dist_*), which carries the data path.  torch.distributed only
-        # bootstraps (the 128-byte id), barriers and reduces the timings, on CPU tensors over gloo — it does not bring up a second
-        # set of RCCL communicators next to ours (M2S_BENCH_PG=nccl restores that).
-        backend = os.environ.get("M2S_BENCH_PG", "gloo")
+        # ONE user of RCCL per process — the C-ABI communicator (m2s_dist_*), which carries the data path — and ONE rendezvous: the
+        # ranks meet in a directory (mesh2splat_amd/ctl.py) for the 128-byte id and the agreement that every rank has a communicator;
+        # from then on the barriers and reductions of this run are 8-byte all-gathers of that communicator.
         t_pg = time.perf_counter()
-        with stdout_to_stderr():
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-                CTL = "cuda"
-            else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                CTL = "cpu"
-            dist.barrier()
-        phases["control_plane"] = backend
+        ctl.barrier()
+        phases["control_plane"] = "directory rendezvous (mesh2splat_amd/ctl.py) until m2s_dist_create, then the communicator's own 8-byte all-gather"
         phases["control_plane_init_s"] = time.perf_counter() - t_pg
-        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
-        # rank 0's RCCL id reaches the other ranks through the process group that torchrun set up — together with a flag: if rank 0
-        # cannot get one (no librccl), EVERY rank learns it here, before anybody enters a collective of the C-ABI communicator.
-        # From here on the data path talks to RCCL through the C ABI (m2s_dist_*), not through torch.distributed.
-        idt = torch.zeros(129, dtype=torch.uint8, device=CTL)
+        # rank 0's RCCL id reaches the other ranks together with a flag: if rank 0 cannot get one (no librccl), EVERY rank learns it
+        # here, before anybody enters a collective of the communicator
+        payload = None
         if rank == 0:
             try:
                 if os.environ.get("M2S_BENCH_FAIL_COMM"):      # (test hook: the exit path below)
                     raise RuntimeError("forced by M2S_BENCH_FAIL_COMM")
-                ident0 = m2d.RcclExchange.unique_id()
-                idt[1:].copy_(torch.frombuffer(bytearray(ident0), dtype=torch.uint8))
-                idt[0] = 1
+                payload = b"\x01" + m2d.RcclExchange.unique_id()
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
                 dist_errors.append(f"rank 0: m2s_dist_unique_id: {e!r}")
-        dist.broadcast(idt, src=0)
-        idh = idt.cpu().numpy()
+                payload = b"\x00"
+        payload = ctl.broadcast_bytes("rccl_id", payload)
         exchange, ok = None, 0
-        if int(idh[0]) == 1:
+        if payload[:1] == b"\x01":
+            ident = bytes(payload[1:129])
+
             def bootstrap(_):
-                return bytes(idh[1:].tobytes())
+                return ident
             bootstrap.provides_id = True
             t_comm = time.perf_counter()
             try:
@@ -687,22 +702,19 @@ def main():
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
                 dist_errors.append(f"rank {rank}: m2s_dist_create: {e!r}")
                 exchange, ok = None, 0
-        okt = torch.tensor([ok], dtype=torch.int32, device=CTL)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        if int(okt.item()) == 0:
+        reports = ctl.gather_obj("comm_ok", {"ok": ok, "errors": dist_errors})
+        if min(r_["ok"] for r_ in reports) == 0:
             # NO fallback: the exchange under test is the product's (m2s_dist_* behind the C ABI: RCCL).  A run whose ranks cannot
             # create that communicator must not report a number measured on something else: every rank leaves, rank 0 says why.
-            errs = [None] * world
-            dist.all_gather_object(errs, dist_errors)
             if exchange is not None:
                 exchange.close()
             if rank == 0:
                 print(json.dumps({"error": "the C-ABI communicator (m2s_dist_create) could not be created on every rank; no measurement was taken",
-                                  "n_gpus": world, "exchange_transport": None, "errors": [e for per in errs for e in (per or [])],
+                                  "n_gpus": world, "exchange_transport": None, "errors": [e for r_ in reports for e in r_["errors"]],
                                   "multi_gpu_bringup": phases}), file=sys.stderr, flush=True)
-            dist.barrier()
-            dist.destroy_process_group()
+            ctl.close()
             raise SystemExit(3)
+        ctl.use(exchange)
         if exchange is not None:           # the first exchange of all: 8 bytes per rank, timed on its own
             t_x = time.perf_counter()
             try:
@@ -733,11 +745,9 @@ def main():
     rig = Rig(torch, local_rank, scene, R, tri_range=(rank * tri_per_mesh, tri_per_mesh), cap=0 if multi else -1,
               out_rows=0 if multi else None, exchange=exchange, pipeline=a.pipeline)
     T_local = rig.conv.num_triangles
-    dt, total = timed_loop(torch, dist, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
-    ntot = torch.tensor([total], dtype=torch.int64, device=CTL)
-    if multi:
-        dist.all_reduce(ntot, op=dist.ReduceOp.SUM)
-    n_all = int(ntot.item())
+    dt, total = timed_loop(torch, ctl, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
+    per_rank_total = ctl.gather_u64(total) if multi else [int(total)]
+    n_all = int(sum(per_rank_total))
     ms_per_step = dt / a.steps * 1e3
     value = n_all / (dt / a.steps)
     kms = rig.kernel_ms()
@@ -810,7 +820,7 @@ def main():
                                     f"3 procedural {tex}^2 RGBA8 maps, R={R}"),
                        "gaussians_per_step": n_all, "triangles_per_gpu": T_local, "parallelism": f"tri-range x{world}",
                        "pipeline": last_pipeline,
-                       "rccl_ranks": (dist.get_world_size() if multi else 1),
+                       "rccl_ranks": (exchange.world if multi else 1),
                        "exchange": ("per step: 8-byte counter all-gather, two in flight; transport: " + exchange.transport) if multi else "none (single GPU)",
                        "cap": "unlimited (merged scene exceeds the 7M envelope)" if multi else "reference formula",
                        "submission": "one blocking call per step" if a.sync_steps else
@@ -844,7 +854,21 @@ def main():
                                                          "rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)")
             except Exception:
                 pass
+    xch_ms = None
+    if multi:       # one 8-byte all-gather (publish + collect, blocking): what a rank pays to learn its offset in the merged buffer
+        ctl.barrier()
+        x0 = time.perf_counter()
+        for _ in range(20):
+            exchange.all_gather_counts(total)
+        xch_ms = ctl.max_float((time.perf_counter() - x0) / 20) * 1e3
     if rank == 0 and multi:
+        # the record the driver's SCALE run is read for, in one flat place
+        res["scale_record"] = {"rccl_ranks": exchange.world, "per_rank_gaussians": [int(x) for x in per_rank_total], "value": value,
+                               "ms_per_step": ms_per_step, "exchange_ms": xch_ms,
+                               "bringup_ms": (phases.get("control_plane_init_s", 0.0) + phases.get("rccl_comm_init_s", 0.0)) * 1e3,
+                               "transport": exchange.transport, "dry_scale": bool(a.dry_scale),
+                               "what": "exchange_ms: one blocking 8-byte counter all-gather; bringup_ms: rendezvous + m2s_dist_create (ncclCommInitRank)"}
+        res["dry_scale"] = bool(a.dry_scale)
         res["multi_gpu_bringup"] = {**phases, "exchange": getattr(exchange, "transport", None), "errors": dist_errors,
                                     "what": "rank 0's timings of the bring-up steps; errors: every m2s_dist_* failure met so far (text of m2s_dist_last_error)"}
     # The multi-GPU extras below contain collectives that have never run on more than one GPU by the builder.  Should one of
@@ -871,16 +895,15 @@ def main():
             merged = torch.empty((max(offs[-1], 1), 24), dtype=torch.float32, device="cuda")
             for _ in range(2):
                 exchange.gather_records_t(rig.out, counts, merged, -1, rig.stream)
-            torch.cuda.synchronize(); dist.barrier()
+            torch.cuda.synchronize(); ctl.barrier()
             g0 = time.perf_counter()
             for _ in range(reps):
                 rig.step_sync()
                 exchange.gather_records_t(rig.out, counts, merged, -1, rig.stream)
             rig.drain_counts()
-            torch.cuda.synchronize(); dist.barrier()
-            gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=CTL)
-            dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-            gather = {"ms_per_step": float(gdt.item()) * 1e3, "value": n_all / float(gdt.item()), "unit": "Gaussians/s",
+            torch.cuda.synchronize(); ctl.barrier()
+            gdt = ctl.max_float((time.perf_counter() - g0) / reps)
+            gather = {"ms_per_step": gdt * 1e3, "value": n_all / gdt, "unit": "Gaussians/s",
                       "bytes_received_per_rank": 96 * (offs[-1] - counts[rank]),
                       "what": "convert + exact-size all-pairs exchange of every rank's block to every rank (m2s_dist_gather_records: one "
                               "RCCL group of ncclSend/ncclRecv at the final offsets of the merged buffer)"}
@@ -891,7 +914,7 @@ def main():
         strong = {}
         if rank == 0:
             res["strong_scaling"] = strong
-        strong_scenes = ["c3"] + ([] if a.no_extra_workloads else ["c4"]) + (["c5p"] if ((world == 8 or os.environ.get("M2S_BENCH_FORCE_C5P")) and not a.no_extra_workloads) else [])
+        strong_scenes = ([] if a.no_strong_scaling else ["c3"]) + ([] if (a.no_extra_workloads or a.no_strong_scaling) else ["c4"]) + (["c5p"] if ((world == 8 or os.environ.get("M2S_BENCH_FORCE_C5P")) and not a.no_extra_workloads) else [])
         for sname in strong_scenes:
             # every rank takes the same path through this block (collectives inside): an exception is recorded, not raised
             try:
@@ -905,7 +928,7 @@ def main():
                     one = synth.sponza_standin(stex) if sn == "grid" else synth.colocated_spheres(1, sn, stex)
                 plan = m2d.shard_ranges_native(one, sR, world)
                 srig = Rig(torch, local_rank, one, sR, tri_range=plan[rank], cap=0, out_rows=0, exchange=exchange)
-                sdt, stotal = timed_loop(torch, dist, True, srig, a.steps, a.warmup)
+                sdt, stotal = timed_loop(torch, ctl, True, srig, a.steps, a.warmup)
                 scounts, soffs = exchange.all_gather_counts(stotal)
                 entry = {"scene": sname, "R": sR, "triangles": one.n_triangles, "gaussians": soffs[-1], "per_rank_gaussians": scounts,
                          "per_rank_triangles": [c_ for _, c_ in plan],
@@ -915,22 +938,20 @@ def main():
                 if not a.no_gather:
                     merged = torch.empty((max(soffs[-1], 1), 24), dtype=torch.float32, device="cuda")
                     exchange.gather_records_t(srig.out, scounts, merged, -1, srig.stream)
-                    torch.cuda.synchronize(); dist.barrier()
+                    torch.cuda.synchronize(); ctl.barrier()
                     g0 = time.perf_counter()
                     for _ in range(reps):
                         srig.step_sync()
                         exchange.gather_records_t(srig.out, scounts, merged, -1, srig.stream)
                     srig.drain_counts()
-                    torch.cuda.synchronize(); dist.barrier()
-                    gdt = torch.tensor([(time.perf_counter() - g0) / reps], dtype=torch.float64, device=CTL)
-                    dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-                    entry["gather"] = {"ms_per_step": float(gdt.item()) * 1e3, "value": soffs[-1] / float(gdt.item()),
+                    torch.cuda.synchronize(); ctl.barrier()
+                    gdt = ctl.max_float((time.perf_counter() - g0) / reps)
+                    entry["gather"] = {"ms_per_step": gdt * 1e3, "value": soffs[-1] / gdt,
                                        "what": "convert + all-pairs record exchange into the merged buffer on every rank"}
                     # the merged buffer must be the single-GPU output: checksum of checksums across ranks
-                    chk = torch.tensor([int(merged.view(torch.int32).to(torch.int64).sum().item())], dtype=torch.int64, device=CTL)
-                    allchk = [torch.zeros_like(chk) for _ in range(world)]
-                    dist.all_gather(allchk, chk)
-                    entry["gather"]["merged_identical_on_all_ranks"] = bool(all(int(x.item()) == int(chk.item()) for x in allchk))
+                    chk = int(merged.view(torch.int32).to(torch.int64).sum().item())
+                    allchk = ctl.gather_u64(chk)
+                    entry["gather"]["merged_identical_on_all_ranks"] = bool(all(x == (chk & 0xFFFFFFFFFFFFFFFF) for x in allchk))
                     if sname == "c5p":
                         from mesh2splat_amd.converter import Converter
                         sink = Converter(local_rank)
@@ -951,23 +972,20 @@ def main():
                         if True:
                             try:
                                 srig.drain_counts()
-                                torch.cuda.synchronize(); dist.barrier()
+                                torch.cuda.synchronize(); ctl.barrier()
                                 d0 = time.perf_counter()
                                 dn, doff = exchange.sort_by_depth(srig.conv, view)
-                                ddt = torch.tensor([time.perf_counter() - d0], dtype=torch.float64, device=CTL)
-                                dist.all_reduce(ddt, op=dist.ReduceOp.MAX)
+                                ddt = ctl.max_float(time.perf_counter() - d0)
                                 sl = torch.from_numpy(srig.conv.download_sorted()).cuda() if dn else torch.zeros((0, 24), dtype=torch.float32, device="cuda")
                                 z = (sl[:, 2] + torch.tensor(-6.0, device="cuda")).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF   # key = bits of view-space z
-                                edge = torch.tensor([int(z[0].item()) if dn else -1, int(z[-1].item()) if dn else -1,
-                                                     int(sl.view(torch.int32).to(torch.int64).sum().item()), dn,
-                                                     int(bool((z[1:] >= z[:-1]).all().item())) if dn > 1 else 1], dtype=torch.int64, device=CTL)
-                                edges = [torch.zeros_like(edge) for _ in range(world)]
-                                dist.all_gather(edges, edge)
-                                E = [[int(v) for v in e.tolist()] for e in edges]
+                                edge = [int(z[0].item()) if dn else -1, int(z[-1].item()) if dn else -1,
+                                        int(sl.view(torch.int32).to(torch.int64).sum().item()), int(dn),
+                                        int(bool((z[1:] >= z[:-1]).all().item())) if dn > 1 else 1]
+                                E = ctl.gather_obj("sort_edges_" + sname, edge)
                                 nonempty = [e for e in E if e[3] > 0]
                                 entry["distributed_depth_sort"] = {
-                                    "ms": float(ddt.item()) * 1e3, "per_rank_records": [e[3] for e in E],
-                                    "same_multiset_as_merged": sum(e[2] for e in E) == int(chk.item()),
+                                    "ms": ddt * 1e3, "per_rank_records": [e[3] for e in E],
+                                    "same_multiset_as_merged": sum(e[2] for e in E) == chk,
                                     "sorted_inside_slices": all(e[4] == 1 for e in E),
                                     "slices_ordered": all(nonempty[i][1] <= nonempty[i + 1][0] for i in range(len(nonempty) - 1)),
                                     "what": "m2s_dist_sort_by_depth: local sort, 256 samples per rank, splitters, one all-pairs exchange of exact sizes, "
@@ -1017,9 +1035,9 @@ def main():
                 res["traffic_note"] = "roofline.traffic is a COMMITTED constant of the same command (see roofline.traffic_source), not a measurement of this run"
             if not a.no_extra_workloads and a.workload == "c3":
                 res["extra_workloads"] = {}
-                for w in ("c2", "mid", "c4", "hetero") + (() if a.no_c5 else ("c5",)):
+                for w in ("c2", "band", "mid", "c4", "hetero") + (() if a.no_c5 else ("c5",)):
                     try:
-                        res["extra_workloads"][w] = extra_workload(torch, dist, local_rank, w)
+                        res["extra_workloads"][w] = extra_workload(torch, ctl, local_rank, w)
                     except Exception as e:  # noqa: BLE001
                         res["extra_workloads"][w] = {"error": str(e)}
             # every fraction of this line in one flat place: algorithmic bytes of ONE conversion / its time / 8 TB/s;
@@ -1041,8 +1059,10 @@ def main():
         print(json.dumps(res), flush=True)
 
     if multi:
+        ctl.barrier()
+        ctl.use(None)
         exchange.close()
-        dist.destroy_process_group()
+        ctl.close()
 
 
 if __name__ == "__main__":

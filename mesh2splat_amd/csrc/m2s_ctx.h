@@ -56,6 +56,7 @@ struct m2s_ctx {
         bool sparse = false;       // AUTO: fewer fragments than triangles, the sparse form of the single-pass kernel (k_sparse)
         bool sparse_off = false;   // k_sparse reported a workgroup that did not fit its LDS stream: use k_fused2
         bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
+        uint32_t tpw = 0;          // AUTO: k_fused2 in batches of this many triangles (0: fused_tpw) — the 11-18 fragments-per-triangle band
         bool lean_off = false;     // k_fused3 overflowed its LDS stream or deferred many triangles at this R: use k_fused2
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
@@ -71,6 +72,7 @@ struct m2s_ctx {
     std::map<uint32_t, RInfo> rinfo;
     double frag_per_R2 = -1.0;              // fragments / R^2 of this scene: from the exact count m2s_upload_scene takes (warm_scene), refreshed by every conversion
     uint64_t warm_total = 0;                // fragments of the scene at warm_R (exact: warm_scene's count)
+    uint64_t warm_big = 0;                  // ... of which in triangles of more than 96 fragments (what a single-pass kernel would defer)
     bool warm_mismatch_seen = false;        // a launch in runs disagreed with that count once (run_pass): not retried again
     uint32_t hint_R = 0;                    // m2s_set_resolution_hint: the R the next upload prepares for (0: the last R converted at, else 1024)
     uint32_t warm_R = 0;                    // the R the resident scene was prepared for
@@ -204,7 +206,7 @@ bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 bool use_lean(const m2s_ctx* c, const m2s_ctx::RInfo& ri);   // the team kernel in its lean form (k_fused3)
 bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
-m2s::BatchTable batches_for(const m2s_ctx* c);
+m2s::BatchTable batches_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
 bool multipass_v1();
 m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident

@@ -94,6 +94,8 @@ void launch_combo_level(const uint32_t* a, const uint32_t* n, const uint32_t* m,
                         hipStream_t st);
 void launch_count(const SceneDev& sc, uint32_t R, uint32_t* cnt, uint32_t* partials, hipStream_t st);
 void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long long* total, hipStream_t st);
+// *out (zero before) += fragments of the triangles with more than `threshold` fragments (cnt: launch_count's counts)
+void launch_big_share(const uint32_t* cnt, uint32_t n_tri, uint32_t threshold, unsigned long long* out, hipStream_t st);
 // where the output of every RUN (1 << shift units of `unit` = 256 / 512 triangles) starts, from launch_count's counts and the
 // scanned partial sums: the table a launch in runs reads (RunInfo::base)
 void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t unit, uint32_t shift, unsigned long long* run_base, hipStream_t st);
@@ -155,6 +157,8 @@ inline uint32_t n_runs(uint32_t n_units, uint32_t shift) { return (n_units + (1u
 struct BatchTable {
     const uint32_t* first;   // device, n + 1 entries
     uint32_t n;
+    uint32_t tpw;            // k_fused2 only, first == nullptr: uniform batches of this many triangles instead of fused_tpw (0: fused_tpw);
+                             // a multiple of 8, at most 64 — AUTO's choice for scenes of 11-18 fragments per triangle (run_pass: decide)
 };
 // units (workgroups of 256 triangles) of k_fused2 for a scene of n_tri triangles that can be converted in runs (0: too small for
 // 64-triangle batches)

@@ -157,10 +157,12 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
             const bool listed = slot < kTallCap;
             uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
             uint32_t run = 0, ci = 0;
+            RowWalkerS rw;       // lane l: rows y0 + l, y0 + l + 64, ... (one closed-form setup per lane, then division-free steps)
+            if (b.y0 + lane <= b.y1) row_walker_init_strided(b, b.y0 + lane, 64, rw);
             for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
                 const int y = yc + lane;
                 int xa = 0, xb = -1;
-                if (y <= b.y1) row_span(b, y, xa, xb);
+                if (y <= b.y1) row_walker_next(rw, xa, xb);
                 if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
                 run += wave_sum((uint32_t)max(xb - xa + 1, 0));
             }

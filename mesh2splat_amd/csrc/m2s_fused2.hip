@@ -511,8 +511,10 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
 void launch_fused2(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const RunInfo& runs, const BatchTable& bt, hipStream_t st) {
-    const uint32_t tpw = fused_tpw(sc.n_tri);   // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h)
-    const uint32_t n_batches = bt.first ? bt.n : n_fused_waves(sc.n_tri);
+    // small scenes: fewer triangles per wave, more workgroups (see m2s_device.h); bt.tpw: the caller's batch size (scenes of 11-18
+    // fragments per triangle: smaller batches keep a workgroup's entries inside its LDS stream)
+    const uint32_t tpw = (!bt.first && bt.tpw) ? bt.tpw : fused_tpw(sc.n_tri);
+    const uint32_t n_batches = bt.first ? bt.n : (sc.n_tri + tpw - 1u) / tpw;
     if (!n_batches) return;
     uint32_t nb = (n_batches + kTeam - 1) / kTeam;
     RunInfo r = runs;

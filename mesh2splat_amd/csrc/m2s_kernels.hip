@@ -211,6 +211,22 @@ void launch_scan_partials(uint32_t* partials, uint32_t n_partials, unsigned long
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, st, partials, n_partials, total);
 }
 
+// fragments held by the triangles of more than `threshold` fragments: what a single-pass kernel would have to defer (warm_scene)
+__global__ void __launch_bounds__(kBlock) k_big_share(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t threshold, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t c = cnt[i];
+        if (c > threshold) acc += c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+void launch_big_share(const uint32_t* cnt, uint32_t n_tri, uint32_t threshold, unsigned long long* out, hipStream_t st) {
+    if (!n_tri) return;
+    hipLaunchKernelGGL(k_big_share, dim3(std::min<uint32_t>((n_tri + kBlock - 1) / kBlock, 1024u)), dim3(kBlock), 0, st, cnt, n_tri, threshold, out);
+}
+
 // ============================================================================================
 // K_unit_bases: where the output of every RUN of units starts (unit = 256 or 512 triangles, run = 1 << shift units), from the
 // exact counts and the scanned partial sums — what a launch of the single-pass kernels without runs records as a by-product

@@ -42,7 +42,7 @@ bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
 // workgroup per CU does nothing for a launch that fits the GPU once — C2 stand-in 0.0354 (k_fused2) vs 0.0362 ms, config 3 0.1170 vs
 // 0.1138, profiles/r05/ab_lean_team_kernel.log) and while few triangles are deferred
 bool use_lean(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
-    if (!(use_team(c, ri) && c->lean_ok && !ri.lean_off) || debug_on("M2S_NO_LEAN")) return false;
+    if (!(use_team(c, ri) && c->lean_ok && !ri.lean_off) || ri.tpw || debug_on("M2S_NO_LEAN")) return false;
     return c->pipeline == M2S_PIPELINE_LEAN || (c->pipeline == M2S_PIPELINE_AUTO && fused_tpw(c->scene.n_tri) == 64u);
 }
 // ... or its sparse form (m2s_sparse.hip): meshes with fewer fragments than triangles, large enough for 64-triangle batches
@@ -55,7 +55,7 @@ RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, boo
     if (writes) *writes = false;
     const uint32_t n_wg = band_workgroups(c, unit);
     const uint32_t shift = run_shift_for(n_wg);
-    if (!n_wg || !shift || !c->d_bands || !c->run_table_words || (unit == 256u && c->n_batch_tab) || debug_on("M2S_NO_BANDS")) return r;
+    if (!n_wg || !shift || !c->d_bands || !c->run_table_words || (unit == 256u && (c->n_batch_tab || ri.tpw)) || debug_on("M2S_NO_BANDS")) return r;
     if ((size_t)n_runs(n_wg, shift) > c->run_table_words) return r;
     unsigned long long* table = c->d_bands + (size_t)ri.band_slot * c->run_table_words;
     r.shift = shift;
@@ -68,8 +68,8 @@ RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, boo
     return r;
 }
 
-BatchTable batches_for(const m2s_ctx* c) {
-    return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab } : BatchTable{ nullptr, 0u };
+BatchTable batches_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
+    return c->n_batch_tab ? BatchTable{ c->d_batch_first, c->n_batch_tab, 0u } : BatchTable{ nullptr, 0u, ri.tpw };
 }
 
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
@@ -87,9 +87,23 @@ uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
 // sweep); with more than ~11 fragments per triangle on average the output-partitioned multi-pass pipeline is
 // faster and soon much faster (2.74 M fragments at R = 1024 from 1 M / 250 k / 125 k / 62 k triangles: fused 0.167 /
 // 0.138 / 0.323 / 0.626 ms, multi-pass 0.214 / 0.137 / 0.136 / 0.154 ms; tools/auto_probe.py).
-static void decide(const m2s_ctx* c, m2s_ctx::RInfo& ri, double frags) {
+// Round 5, the lower edge of the multi-pass range: from 11 to 13 fragments per triangle the team kernel in SMALLER batches (40 triangles
+// per wave, so that a workgroup's 160 triangles still fit its 4096-entry LDS stream) beats the multi-pass pipeline — 235 200 triangles
+// at 11.6 fragments each: kernels 0.113 against 0.118 ms, one blocking call 0.127 against 0.146 (one launch instead of two;
+// profiles/r05/band_probe.jsonl); at 14 fragments per triangle a cube-sphere's densest workgroups overflow the stream even at 40
+// (the launch is then repeated by the multi-pass pipeline, which wins from there on anyway: 0.110 ms).  Taken only at the R the
+// scene was counted at (R == warm_R: the first conversion after an upload, the reference's case) and only if triangles of more than
+// 96 fragments — which a single-pass kernel defers — hold less than an eighth of the fragments: a scene whose MEAN falls in the band
+// because it mixes planes with foliage (synth.sponza_like: 16 per triangle) belongs to the multi-pass pipeline and its fine blocks.
+static void decide(const m2s_ctx* c, m2s_ctx::RInfo& ri, double frags, uint32_t R) {
     ri.decided = true;
     ri.multipass = frags >= 11.0 * (double)c->scene.n_tri;
+    ri.tpw = 0;
+    if (ri.multipass && frags < 13.0 * (double)c->scene.n_tri && R == c->warm_R && c->warm_total > 0 && c->warm_big * 8ull < c->warm_total &&
+        fused_tpw(c->scene.n_tri) == 64u && !c->n_batch_tab && c->team_off_R > R && !debug_on("M2S_NO_BAND_TPW")) {
+        ri.multipass = false;
+        ri.tpw = 40;
+    }
     // about as many fragments as triangles, or fewer: many triangles cover no pixel centre, the sparse form drops them cheaply
     // (crossover measured with tools/sparse_probe.py: see DESIGN.md)
     ri.sparse = !ri.multipass && frags < sparse_frags_per_triangle(c->scene.n_tri) * (double)c->scene.n_tri && !debug_on("M2S_NO_SPARSE");
@@ -118,6 +132,16 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     c->frag_per_R2 = (double)total / ((double)R * (double)R);
     c->warm_R = R;
     c->warm_total = total;
+    c->warm_big = 0;
+    if (total >= 11ull * sc.n_tri && total < 13ull * sc.n_tri) {   // (the only case decide() asks for it)
+        HIPCHK(c, hipMemsetAsync(c->d_total, 0, 8, st));
+        launch_big_share(c->d_cnt, sc.n_tri, 96u, c->d_total, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&c->h_total[1], c->d_total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->warm_big = c->h_total[1];
+        c->h_total[1] = 0;
+    }
     // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
     // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
     // cube-sphere face).  Work = 214 per triangle + 140 per fragment (cycles of the triangle phase per 64 triangles and of a strip
@@ -155,7 +179,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
         } catch (...) { /* no table: uniform batches */ }
     }
     m2s_ctx::RInfo& ri = rinfo_for(c, R);
-    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total);
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total, R);
     const uint64_t cap = resolve_cap(c, R);
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
     // the code object of the pipeline this scene is about to run: loaded here, not inside the first conversion of the process
@@ -367,7 +391,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         if (s != M2S_OK) return s;
     }
     const double predicted = c->frag_per_R2 * (double)R * (double)R;
-    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, predicted);
+    if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, predicted, R);
 
     // ---- where do the records go, and how many may be stored? ------------------------------------
     uint64_t limit;
@@ -408,9 +432,9 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                       c->d_biglist, c->d_bigmeta, runs, st);
             else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c), st);
+                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
             else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                               c->d_biglist, c->d_bigmeta, st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -449,6 +473,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
                 }
             }
             if (!(err && (team || sparse))) break;
+            if (team && ri.tpw) { ri.tpw = 0; break; }   // a scene of the 11-18 band whose workgroups overflow even in small batches: multi-pass (below)
             // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
             // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
             // launch listed, try again.

@@ -178,7 +178,8 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
         combo_plan.push_back(cp);
     }
     const size_t n_mp = std::max<uint32_t>(n_meshes, 1);
-    const size_t chain_words = std::max<size_t>(std::max<size_t>(n_fused_waves(n_tri), batch_table_capacity(n_tri)), 1);
+    // (n_tri / 32: room for AUTO's smaller batches of the 11-18 fragments-per-triangle band, BatchTable::tpw >= 32)
+    const size_t chain_words = std::max<size_t>(std::max<size_t>(std::max<size_t>(n_fused_waves(n_tri), batch_table_capacity(n_tri)), (size_t)n_tri / 32 + 1), 1);
     const size_t o_meshes = take(n_mp * sizeof(MeshParams));
     const size_t o_mesh_first = take(mesh_first.size() * sizeof(uint32_t));
     const size_t o_mesh_of8 = take(((np + 7) / 8 + 1) * sizeof(uint2));

@@ -1,0 +1,57 @@
+"""The control plane of a multi-rank run (mesh2splat_amd/ctl.py): directory rendezvous between PROCESSES, world size 3, on the CPU —
+what bench.py and the rank scripts use until the C-ABI communicator exists (and, for JSON-sized objects, afterwards)."""
+import multiprocessing as mp
+import os
+
+import pytest
+
+
+def _rank(rank, world, directory, q, die):
+    os.environ["M2S_RDZV_DIR"] = directory
+    from mesh2splat_amd.ctl import Ctl, RendezvousTimeout
+    c = Ctl(rank, world, timeout=3.0 if die else 30.0)
+    try:
+        ident = c.broadcast_bytes("id", bytes(range(128)) if rank == 0 else None)
+        if die and rank == 1:
+            os._exit(7)                                     # a rank that dies before a collective: the others time out, they do not hang
+        vals = c.gather_u64(10 * rank + 1)
+        objs = c.gather_obj("report", {"rank": rank, "ok": 1})
+        out = (rank, ident == bytes(range(128)), vals, [o["rank"] for o in objs], c.max_float(0.001 * (rank + 1)), c.sum_int(rank), c.min_int(5 - rank))
+        c.barrier()
+        c.close()
+        q.put(out)
+    except RendezvousTimeout as e:
+        q.put((rank, "timeout", str(e)))
+
+
+@pytest.mark.parametrize("die", [False, True])
+def test_directory_rendezvous_world_3(tmp_path, die):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_rank, args=(r, world, str(tmp_path / "rdzv"), q, die)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=60) for _ in range(world - (1 if die else 0)))
+    for p in ps:
+        p.join(timeout=30)
+    if die:
+        assert all(g[1] == "timeout" for g in got) and ps[1].exitcode == 7
+        return
+    for rank, ok, vals, ranks, mx, sm, mn in got:
+        assert ok and vals == [1, 11, 21] and ranks == [0, 1, 2] and abs(mx - 0.003) < 1e-9 and sm == 3 and mn == 3
+    assert not os.path.exists(tmp_path / "rdzv")             # rank 0 removed the directory after the last collective
+
+
+def test_sequence_numbers_keep_rounds_apart(tmp_path):
+    """A fast rank may be two collectives ahead of a slow one: names carry the round."""
+    os.environ["M2S_RDZV_DIR"] = str(tmp_path / "one")
+    try:
+        from mesh2splat_amd.ctl import FileRendezvous
+        a, b = FileRendezvous(0, 2), FileRendezvous(1, 2)
+        a._put(0, "u64", b"A0"); a._put(1, "u64", b"A1")    # rank 0 has published two rounds
+        b._seq = 0
+        assert b.allgather("u64", b"B0") == [b"A0", b"B0"]
+        assert b.allgather("u64", b"B1") == [b"A1", b"B1"]
+    finally:
+        os.environ.pop("M2S_RDZV_DIR", None)

@@ -165,7 +165,7 @@ def test_command_line_with_a_rank_that_dies(hiplib, tmp_path):
 
 @needs_stub
 def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank; here both on device 0): the line
+    """bench.py --gpus 2, one process per rank (the launcher environment RANK / WORLD_SIZE / MASTER_*; here both on device 0): the line
     says which transport moved the bytes — the C ABI's RCCL, here the stand-in — and carries gather / strong-scaling sections;
     and when the communicator cannot be created the run exits non-zero WITHOUT a line (no silent fall-back)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--workload", "c2", "--steps", "4", "--warmup", "1",
@@ -181,3 +181,32 @@ def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
     assert bad.returncode != 0
     assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")], "a measurement line was printed although the communicator failed"
     assert "could not be created" in bad.stderr
+
+
+@needs_stub
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_dry_scale_prints_the_scale_record(hiplib, tmp_path, world):
+    """bench.py --gpus N --dry-scale: the N-process schedule of a SCALE run on the one GPU of a CI box (the stand-in is selected by
+    bench.py itself), no torch.distributed anywhere: the line carries the record the driver reads — ranks, per-rank Gaussians,
+    whole-job value, the counter exchange's and the bring-up's time — and says that it is a dry run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-scale", "--workload", "small", "--steps", "3", "--warmup", "1",
+           "--no-extra-workloads", "--no-strong-scaling", "--extras-timeout", "200"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("M2S_RCCL_PATH", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["dry_scale"] is True and line["scaling"] == "weak"
+    rec = line["scale_record"]
+    assert set(rec) >= {"rccl_ranks", "per_rank_gaussians", "value", "ms_per_step", "exchange_ms", "bringup_ms", "transport", "dry_scale"}
+    assert rec["rccl_ranks"] == world and len(rec["per_rank_gaussians"]) == world and rec["transport"].startswith("rccl:")
+    assert len(set(rec["per_rank_gaussians"])) == 1 and sum(rec["per_rank_gaussians"]) == line["config"]["gaussians_per_step"]
+    assert rec["exchange_ms"] > 0 and rec["bringup_ms"] > 0 and line["value"] > 0
+    assert not line["multi_gpu_bringup"]["errors"]
+    assert line["gather"]["ms_per_step"] > 0                       # the all-pairs record exchange ran as well
+
+
+def test_bench_has_no_torch_distributed():
+    """The control plane of bench.py is mesh2splat_amd/ctl.py + the C-ABI communicator."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch.distributed" not in src and "dist.barrier" not in src and "init_process_group" not in src

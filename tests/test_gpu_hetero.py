@@ -82,3 +82,38 @@ def test_sponza_like_with_three_maps_everywhere_runs_lean_kernels_too(hiplib, or
         else:
             assert np.array_equal(rec.view(np.uint32), ref.view(np.uint32)), (name, c.last_pipeline)
         c.close()
+
+
+def test_auto_runs_the_team_kernel_in_small_batches_at_the_lower_edge_of_the_multipass_range(hiplib, oracle):
+    """AUTO between 11 and 13 fragments per triangle (run_pass: decide): a uniform mesh is converted by k_fused2 in batches of 40
+    triangles (a workgroup's 160 triangles fit its LDS stream) instead of the multi-pass pipeline; same bytes either way.  A scene
+    whose mean lies there only because it mixes planes with foliage is not, and neither is a mesh of 14 fragments per triangle."""
+    scene = synth.cube_sphere(140, tex_size=256)           # 235 200 triangles, 11.6 fragments each at R = 1024
+    R = 1024
+    ototal, orec, _ = oracle.convert(scene, R, n_threads=os.cpu_count() or 1)
+    assert 11 * scene.n_triangles <= ototal < 13 * scene.n_triangles
+    c = Converter(0)
+    c.set_resolution_hint(R)
+    c.upload_scene(scene)
+    for _ in range(2):
+        assert c.convert(R) == ototal
+        assert c.last_pipeline == "team"
+    rec = c.download()
+    assert_records_match(rec, orec, "11.6 fragments per triangle, team kernel in batches of 40")
+    for _ in range(3):                                      # the asynchronous path takes the same kernel
+        c.submit(R)
+    for _ in range(3):
+        assert c.wait() == ototal
+    assert np.array_equal(c.download().view(np.uint32), rec.view(np.uint32))
+    c.set_pipeline("multipass")
+    assert c.convert(R) == ototal
+    assert np.array_equal(c.download().view(np.uint32), rec.view(np.uint32))
+    c.close()
+    for other in (synth.cube_sphere(127, tex_size=64), synth.sponza_like(tex_scale=0.125)):   # 14.1 per triangle; mixed sizes
+        h = Converter(0)
+        h.set_resolution_hint(R)
+        h.upload_scene(other)
+        t = h.convert(R)
+        assert h.last_pipeline == "multipass"
+        assert t == oracle.convert(other, R, count_only=True)[0]
+        h.close()
