@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     }
 
     // ======================= my TriShade, tskip and entries =======================
-#if defined(M2S_PROBE_STOP) && M2S_PROBE_STOP >= 2      // instruction-count probes (wrong output): tools/r4_valu.sh
+#if defined(M2S_PROBE_STOP) && M2S_PROBE_STOP >= 2      // instruction-count probes (wrong output): tools/ab/r4_valu.sh
     if (false) {
 #else
     if (alive) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B two builds of the library on the bench workload: tools/ab.sh <libA> <libB> [bench args]
+# A/B two builds of the library on the bench workload: tools/ab/ab.sh <libA> <libB> [bench args]
 A=$1; B=$2; shift 2
 for i in 1 2; do
 for L in $A $B; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# generic PMC runner: tools/pmc_sets.sh TAG "set1 counters" "set2 counters" ...   (hard timeout per pass)
+# generic PMC runner: tools/ab/pmc_sets.sh TAG "set1 counters" "set2 counters" ...   (hard timeout per pass)
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 i=0

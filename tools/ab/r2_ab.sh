@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 A/B: bench workloads under env variants.  usage: tools/r2_ab.sh TAG "ENV=.. ENV2=.." "..." -- workloads...
+# round-2 A/B: bench workloads under env variants.  usage: tools/ab/r2_ab.sh TAG "ENV=.. ENV2=.." "..." -- workloads...
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=$1; shift
 VARS=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do VARS+=("$1"); shift; done; shift
 for w in "$@"; do for rep in 1 2; do for v in "${VARS[@]}"; do

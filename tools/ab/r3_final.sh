@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${1:-r3fin}
 cd $R
 sha256sum mesh2splat_amd/_build/libm2s_hip.so | cut -c1-16 > $O/${TAG}_binary_sha.txt; cat $O/${TAG}_binary_sha.txt
-bash tools/r3_check.sh ${TAG}
+bash tools/ab/r3_check.sh ${TAG}
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_bench -o k -- python $R/bench.py > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace_bench.err || echo "trace of bench failed"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_c3 -o k -- python $R/bench.py --no-overlap-extra --no-c5 --no-cpu-baseline --no-viewer-extra --no-cold --no-extra-workloads > $O/${TAG}_trace_c3.json 2> $O/${TAG}_trace_c3.err || echo "trace of c3 failed"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""After tools/r4_final.sh (r3_final.sh): fold the PMC summaries of the closing run into profiles/pmc_traffic.json (HBM bytes per launch =
+"""After tools/ab/r5_final.sh (r4_final.sh, r3_final.sh): fold the PMC summaries of the closing run into profiles/pmc_traffic.json (HBM bytes per launch =
 2 x FETCH_SIZE KB (gfx950 tallies 128-byte requests at 64) + WRITE_SIZE KB x the k_repack calibration) together with the sha of
 the library they were measured on, and copy the evidence files to profiles/<round>/.   usage: python tools/pmc_update.py [tag] [round dir, default r04]"""
 import json
@@ -9,8 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r4fin"
-RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r5fin"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r05"
 P = os.path.join(ROOT, "profiles", RND)
 os.makedirs(P, exist_ok=True)
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -23,14 +23,17 @@ def traffic(d):
     return 2 * d["FETCH_SIZE"] * 1024.0, d["WRITE_SIZE"] * 1024.0 * WCAL
 
 
-c3 = json.load(open(os.path.join(O, TAG + "_pmc_c3_summary.json")))["m2s::k_fused2"]
+c3all = json.load(open(os.path.join(O, TAG + "_pmc_c3_summary.json")))
+k3 = "k_fused3" if "m2s::k_fused3" in c3all else "k_fused2"      # the kernel AUTO runs on config 3 (round 5: the lean team kernel)
+c3 = c3all["m2s::" + k3]
 c5 = json.load(open(os.path.join(O, TAG + "_pmc_c5_summary.json")))["m2s::k_sparse"]
 c2 = json.load(open(os.path.join(O, TAG + "_pmc_c2_summary.json")))["m2s::k_fused2"]
 r, w = traffic(c3)
-t.update({"FETCH_SIZE_KB": c3["FETCH_SIZE"], "WRITE_SIZE_KB": c3["WRITE_SIZE"], "k_fused2_read_bytes": r, "k_fused2_write_bytes": w,
-          "k_fused2_hbm_bytes_per_launch": r + w, "binary_sha": {"k_fused2": sha, "k_sparse": sha}})
-t["source_round" + RND[-1]] = ("profiles/" + RND + "/final_pmc_c3_summary.json, final_pmc_c5_summary.json, final_pmc_c2_summary.json (tools/" + RND.replace("0", "") + "_final.sh: separate --pmc "
-                      "passes FETCH_SIZE / WRITE_SIZE / two SQ sets, 23 blocking launches each for c3 and c2, 8 for c5; mean per launch); library sha256[:16] " + sha)
+t.update({"FETCH_SIZE_KB": c3["FETCH_SIZE"], "WRITE_SIZE_KB": c3["WRITE_SIZE"], k3 + "_read_bytes": r, k3 + "_write_bytes": w,
+          k3 + "_hbm_bytes_per_launch": r + w, "kernel": k3})
+t.setdefault("binary_sha", {}).update({k3: sha, "k_sparse": sha, "k_fused2_c2": sha})
+t["source_round" + RND[-1]] = ("profiles/" + RND + "/final_pmc_{c3,c2,c5,hetero}_summary.json (tools/ab/" + RND.replace("0", "") + "_final.sh <tag> pmc: separate --pmc "
+                      "passes FETCH_SIZE / WRITE_SIZE / two SQ sets, 23 blocking launches each; mean per launch); library sha256[:16] " + sha)
 r5, w5 = traffic(c5)
 t["c5"] = {"workload": "c5 at full size (50 037 168 triangles, 24 267 048 Gaussians)", "kernel": "k_sparse", "algorithmic_bytes": 9534988800.0,
            "k_sparse_read_bytes": r5, "k_sparse_write_bytes": w5, "k_sparse_hbm_bytes_per_launch": r5 + w5,
@@ -39,9 +42,19 @@ r2, w2 = traffic(c2)
 t["c2"] = {"workload": "c2 stand-in (69 312 triangles, R = 512, 684 624 Gaussians)", "kernel": "k_fused2", "algorithmic_bytes": 75704832.0,
            "k_fused2_read_bytes": r2, "k_fused2_write_bytes": w2, "k_fused2_hbm_bytes_per_launch": r2 + w2,
            "traffic_over_algorithmic": (r2 + w2) / 75704832.0}
+het = os.path.join(O, TAG + "_pmc_hetero_summary.json")
+if os.path.exists(het):
+    h = json.load(open(het))
+    hb = 96.0 * 4282886 + 144.0 * 266840
+    parts = {k.replace("m2s::", ""): traffic(v) for k, v in h.items() if k in ("m2s::k_count_scan", "m2s::k_emit2") and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    tot = sum(a + b for a, b in parts.values())
+    t["hetero"] = {"workload": "synth.sponza_like (266 840 triangles, 4 282 886 Gaussians, R = 1024)", "kernel": "k_emit2", "algorithmic_bytes": hb,
+                   "k_emit2_hbm_bytes_per_launch": tot, "what": "k_count_scan + k_emit2 of one conversion (the pair is the launch unit of the multi-pass pipeline)",
+                   "per_kernel": {k: {"read": a, "write": b} for k, (a, b) in parts.items()}, "traffic_over_algorithmic": tot / hb}
 json.dump(t, open(path, "w"), indent=1)
-for w_ in ("c3", "c2", "c5"):
-    shutil.copy(os.path.join(O, f"{TAG}_pmc_{w_}_summary.json"), os.path.join(P, f"final_pmc_{w_}_summary.json"))
+for w_ in ("c3", "c2", "c5", "hetero"):
+    if os.path.exists(os.path.join(O, f"{TAG}_pmc_{w_}_summary.json")):
+        shutil.copy(os.path.join(O, f"{TAG}_pmc_{w_}_summary.json"), os.path.join(P, f"final_pmc_{w_}_summary.json"))
 for src, dst in ((f"{TAG}_trace_bench/k_kernel_stats.csv", "final_bench_kernel_stats.csv"), (f"{TAG}_trace_c3/k_kernel_stats.csv", "final_c3_only_kernel_stats.csv"),
                  (f"{TAG}_bench.json", "final_bench.json"), (f"{TAG}_trace_bench.json", "final_bench_under_rocprofv3.json"), (f"{TAG}_tests.log", "final_gpu_tests.log")):
     if os.path.exists(os.path.join(O, src)):
