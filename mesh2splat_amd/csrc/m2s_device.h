@@ -224,6 +224,7 @@ hipError_t preload_fused3();
 hipError_t preload_sparse();
 hipError_t preload_fused();
 hipError_t preload_multipass();
+void launch_scratch_warm(hipStream_t st);   // the queue's scratch memory set up now, not inside the first multi-pass conversion (m2s_emit2.hip)
 hipError_t preload_export();
 hipError_t preload_prepass();
 hipError_t preload_sort();

@@ -526,6 +526,17 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
                        (const float4*)setup, out, run);
 }
 
+// The multi-pass kernels keep a few spilled registers in scratch memory (12-32 bytes per lane), and the runtime sets a queue's scratch
+// up inside the FIRST dispatch that needs it (~0.1 ms, seen on k_fused3 when a stack crept into it).  warm_scene pays that at upload for
+// scenes AUTO sends here: one workgroup of a kernel that uses 64 bytes per lane.
+__global__ void __launch_bounds__(64) k_scratch_warm(uint32_t* sink) {
+    volatile uint32_t a[16];
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) a[i] = (uint32_t)i + threadIdx.x;
+    if (sink && a[threadIdx.x & 15u] == 0xFFFFFFFFu) *sink = 1u;
+}
+void launch_scratch_warm(hipStream_t st) { hipLaunchKernelGGL(k_scratch_warm, dim3(1), dim3(64), 0, st, (uint32_t*)nullptr); }
+
 // (m2s_device.h: preload_*) makes the runtime load this file's code object now instead of inside the first launch
 hipError_t preload_multipass() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_emit2)); }
 

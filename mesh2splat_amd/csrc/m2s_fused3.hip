@@ -208,9 +208,27 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
             for (int k = 0; k < 4; ++k) S.tri[wave][lane * 4 + k] = src[k];
         }
         if (__ballot(kind == kBig) != 0ull) {   // larger triangles (rare): the whole wave counts one of them, a pixel row per lane
-            const Geo gc = g;   // (a copy: only IT lives in memory, for the call)
-            const uint32_t cb = count_larger(&gc, R, kind == kBig, 0, lane);
-            if (kind == kBig) cnt = cb;
+            // (inline on purpose: as a non-inlined function this path gave the kernel a stack — 64 bytes of scratch per lane — and the
+            //  FIRST launch of a kernel that uses scratch pays the runtime's scratch allocation: first conversion 0.19 -> 0.31 ms)
+            Raster rb;                           // their full (64-bit) setup, only here
+            rb.x0 = rb.y0 = 0; rb.x1 = rb.y1 = -1; rb.ext = 0; rb.bias = 0; rb.area2 = 1;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { rb.a[i] = rb.b[i] = 0; rb.c[i] = 0; }
+            if (kind == kBig && !raster_setup(g, R, rb)) kind = kNone;
+            unsigned long long bigm = __ballot(kind == kBig);
+            while (bigm) {
+                const int src = __ffsll((long long)bigm) - 1;
+                bigm &= bigm - 1;
+                const Raster br = shfl_raster(rb, src);
+                uint32_t part = 0;
+                for (int y = br.y0 + lane; y <= br.y1; y += 64) {
+                    int xa, xb;
+                    row_span(br, y, xa, xb);
+                    part += (uint32_t)max(xb - xa + 1, 0);
+                }
+                part = wave_sum(part);
+                if (lane == src) cnt = part;
+            }
         }
     }
     if (cnt == 0) kind = kNone;

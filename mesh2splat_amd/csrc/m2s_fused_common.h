@@ -64,44 +64,6 @@ enum : int { kNone = 0, kSmall = 1, kMedium = 2, kBig = 3 };
     }
 }
 
-// Rare path of the kernels that shade only small triangles themselves (k_fused3, k_sparse), NOT inlined: the fragment counts of
-// the wave's LARGER triangles (`mine`: this lane has one; called by the whole wave).  Their full 64-bit raster setup lives only
-// here.  A triangle of at most `rows_lane_max` pixel rows is counted by its own lane, a taller one by the whole wave, one row per
-// lane.  Returns the lane's count (0: no larger triangle here, or one without area or without a covered pixel centre).
-[[maybe_unused]] static __device__ __noinline__ uint32_t count_larger(const Geo* gp, uint32_t R, bool mine, int rows_lane_max, int lane) {
-    Raster rs;
-    rs.x0 = rs.y0 = 0; rs.x1 = rs.y1 = -1; rs.ext = 0; rs.bias = 0; rs.area2 = 1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { rs.a[i] = rs.b[i] = 0; rs.c[i] = 0; }
-    const bool big = mine && raster_setup(*gp, R, rs);
-    const int rows = rs.y1 - rs.y0 + 1;
-    uint32_t cnt = 0;
-    if (big && rows <= rows_lane_max) {
-        RowWalker rw;
-        row_walker_init(rs, rs.y0, rw);
-        for (int y = rs.y0; y <= rs.y1; ++y) {
-            int xa, xb;
-            row_walker_next(rw, xa, xb);
-            cnt += (uint32_t)max(xb - xa + 1, 0);
-        }
-    }
-    unsigned long long bigm = __ballot(big && rows > rows_lane_max);
-    while (bigm) {
-        const int src = __ffsll((long long)bigm) - 1;
-        bigm &= bigm - 1;
-        const Raster br = shfl_raster(rs, src);
-        uint32_t part = 0;
-        for (int y = br.y0 + lane; y <= br.y1; y += 64) {
-            int xa, xb;
-            row_span(br, y, xa, xb);
-            part += (uint32_t)max(xb - xa + 1, 0);
-        }
-        part = wave_sum(part);
-        if (lane == src) cnt = part;
-    }
-    return cnt;
-}
-
 // Decoupled look-back: sum of the totals of all waves before `wid`.  Each poll inspects kLbWindows
 // windows of 64 consecutive chain words (lane l of window j reads word first-64j-l: coalesced 512-byte
 // reads, all issued before the first is consumed = one memory round trip for 512 predecessors).  All

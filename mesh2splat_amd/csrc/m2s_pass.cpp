@@ -184,7 +184,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
     // the code object of the pipeline this scene is about to run: loaded here, not inside the first conversion of the process
     if (!debug_on("M2S_NO_PRELOAD")) {
-        if (!single) { (void)preload_multipass(); }
+        if (!single) { (void)preload_multipass(); if (!debug_on("M2S_NO_SCRATCH_WARM")) launch_scratch_warm(st); }
         else if (use_sparse(c, ri)) { (void)preload_sparse(); (void)preload_fused2(); }   // (the sparse form falls back to the team on a stream overflow)
         else if (use_lean(c, ri)) { (void)preload_fused3(); }
         else if (use_team(c, ri)) { (void)preload_fused2(); }
