@@ -27,7 +27,7 @@ class RendezvousTimeout(RuntimeError):
 
 
 class FileRendezvous:
-    def __init__(self, rank: int, world: int, key: Optional[str] = None, timeout: float = 180.0):
+    def __init__(self, rank: int, world: int, key: Optional[str] = None, timeout: float = 300.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if key is None:
             # all ranks of one launch share their parent (the launcher); a relaunch on the same port gets a new directory
@@ -100,7 +100,7 @@ class FileRendezvous:
 class Ctl:
     """barrier / max / sum / gather for bench.py and the rank scripts; world == 1: everything is the identity."""
 
-    def __init__(self, rank: int, world: int, timeout: float = 180.0):
+    def __init__(self, rank: int, world: int, timeout: float = 300.0):   # (a rank's first `import torch` on a fresh box can take two minutes)
         self.rank, self.world = int(rank), int(world)
         self.rdzv = FileRendezvous(rank, world, timeout=timeout) if world > 1 else None
         self.exchange = None

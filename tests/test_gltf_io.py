@@ -278,3 +278,27 @@ def test_loader_threads_do_not_change_the_result(tmp_path, hiplib, monkeypatch):
         for k, t in serial.meshes[0].textures.items():
             assert np.array_equal(par.meshes[0].textures[k], t)
         assert np.array_equal(par.meshes[0].bbox_min, serial.meshes[0].bbox_min)
+
+
+def test_heterogeneous_scene_through_the_loader(tmp_path, hiplib, oracle):
+    """synth.sponza_like as a FILE: 64 meshes, materials with three maps / an albedo map only / none, 2-triangle planes next to
+    dense cloth — written as .glb, read back by the C++ loader: same geometry, same maps (and no map where there was none), same
+    cumulative bounding boxes, and therefore the same fragment count per triangle as the in-memory scene (oracle)."""
+    scene = synth.sponza_like(tex_scale=1.0 / 32.0)
+    p = str(tmp_path / "hetero.glb")
+    gltf_io.write_glb(scene, p, indexed=False)
+    got = gltf_io.load_glb(p)
+    assert got.n_meshes == scene.n_meshes == 64 and not got.warnings
+    kinds = set()
+    for a, b in zip(got.meshes, scene.meshes):
+        assert a.n_triangles == b.n_triangles
+        assert np.array_equal(a.vertices[:, 0:3], b.vertices[:, 0:3])
+        assert np.array_equal(a.vertices[:, 9:12], b.vertices[:, 9:12])
+        assert np.array_equal(a.bbox_min, b.bbox_min) and np.array_equal(a.bbox_max, b.bbox_max)
+        assert set(a.textures) == set(b.textures)
+        kinds.add(len(b.textures))
+        for k in b.textures:
+            assert np.array_equal(a.textures[k], b.textures[k])
+    assert kinds == {0, 1, 3}
+    R = 256
+    assert np.array_equal(oracle.count_per_triangle(got, R), oracle.count_per_triangle(scene, R))

@@ -117,3 +117,33 @@ def test_auto_runs_the_team_kernel_in_small_batches_at_the_lower_edge_of_the_mul
         assert h.last_pipeline == "multipass"
         assert t == oracle.convert(other, R, count_only=True)[0]
         h.close()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_sponza_like_shards_concatenate_to_the_unsharded_output(hiplib, hetero, world):
+    """The multi-GPU contract on the heterogeneous scene: fragment-balanced triangle ranges (m2s_dist_shard_ranges: the floor's two
+    triangles weigh as much as a cloth mesh), each converted by its own upload — ranges that start and end inside meshes, blocks of
+    256 counted from the range's first triangle, fine and dense blocks in every shard — concatenated in rank order give the bytes of
+    the one-GPU conversion."""
+    from mesh2splat_amd import dist as m2d
+    R = 1024
+    whole = Converter(0)
+    whole.set_max_gaussians(0)
+    whole.upload_scene(hetero)
+    total = whole.convert(R)
+    rec = whole.download()
+    whole.close()
+    plan = m2d.shard_ranges_native(hetero, R, world)
+    assert sum(c for _, c in plan) == hetero.n_triangles and len({c for _, c in plan}) > 1     # not an even split
+    parts, totals = [], []
+    for first, count in plan:
+        c = Converter(0)
+        c.set_triangle_range(first, count)
+        c.upload_scene(hetero)
+        c.set_max_gaussians(0)
+        totals.append(c.convert(R))
+        parts.append(c.download())
+        c.close()
+    assert sum(totals) == total
+    assert max(totals) < 2.5 * total / world                     # fragment-balanced, not triangle-balanced
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), rec.view(np.uint32))
