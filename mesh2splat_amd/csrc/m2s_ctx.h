@@ -129,6 +129,7 @@ struct m2s_ctx {
     void* d_sorted = nullptr;
     uint64_t sorted_cap = 0, sorted_n = 0;
     uint32_t* d_sort_u32 = nullptr;   // keys_in | vals_in | keys_out | vals_out
+    uint32_t sorted_key_offset = 0;   // keys_out holds key - this (m2s_device_sorted_keys adds it back once)
     void* d_sort_temp = nullptr;
     size_t sort_temp_cap = 0;
     uint64_t sort_u32_cap = 0;

@@ -209,8 +209,12 @@ size_t sort_prepass_temp_bytes(uint32_t n);
 hipError_t sort_prepass(const float* depths, const float4* quads, uint32_t n, uint32_t* keys_out, uint32_t* vals_out, void* temp,
                         size_t temp_bytes, float4* sorted, hipStream_t st);
 size_t sort_temp_bytes(uint32_t n);
+// *key_offset_out (may be NULL: then keys_out is made whole before returning): keys_out holds `key - offset` (the sort ran over the bits in
+// which the keys differ); launch_add_to_keys puts it back
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out,
-                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st);
+                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st,
+                         uint32_t* key_offset_out, uint32_t* pinned_mm /* two pinned host words for the key range, or NULL */);
+void launch_add_to_keys(uint32_t* keys, uint32_t n, uint32_t offset, hipStream_t st);
 
 // sample sort across ranks (m2s_dist.cpp): evenly spaced samples of sorted keys; split points of sorted keys
 void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st);

@@ -5,9 +5,11 @@
 // bits (so negative view-space z sorts front to back), then a gather of the 6 x vec4 records
 // (radixSortGather.glsl:30-49).  Key build and gather are hand-written; the sort itself is rocPRIM's
 // device radix sort (a plain library primitive, like the reference's third-party glu::RadixSort).
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "m2s_device.h"
 
@@ -24,23 +26,57 @@ __device__ __forceinline__ uint32_t depth_key(float4 p, float v02, float v12, fl
     const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;
     return __float_as_uint(z);
 }
+// Both key kernels also leave the smallest and the largest key of every WAVE behind (wave_mm[wave] = {min, max}: one 8-byte store per 64
+// records) and k_reduce_minmax folds those into minmax[0] / [1]: view-space depths of a bounded scene share their sign and most of their
+// exponent, so the keys differ only in their low 20-25 bits — sort_by_depth sorts `key - min` over exactly the bits that differ and saves a
+// radix pass.  (Atomics from the key kernels themselves — 95 k waves on two addresses, even behind a plain read that skips most of them —
+// or a grid-stride loop over few blocks each cost more than the pass they were to save: 0.095 -> 0.27-0.46 ms for the key stage.)
+__device__ __forceinline__ void wave_minmax(uint32_t& kmin, uint32_t& kmax) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+    }
+}
+__device__ __forceinline__ void reduce_minmax(uint32_t kmin, uint32_t kmax, uint2* __restrict__ wave_mm) {
+    wave_minmax(kmin, kmax);
+    if ((threadIdx.x & 63) == 0) wave_mm[(blockIdx.x * kBlock + threadIdx.x) >> 6] = make_uint2(kmin, kmax);
+}
+__global__ void __launch_bounds__(kBlock) k_reduce_minmax(const uint2* __restrict__ wave_mm, uint32_t n_waves, uint32_t* __restrict__ minmax) {
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_waves; i += gridDim.x * kBlock) {
+        const uint2 v = wave_mm[i];
+        kmin = min(kmin, v.x); kmax = max(kmax, v.y);
+    }
+    wave_minmax(kmin, kmax);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&minmax[0], kmin); atomicMax(&minmax[1], kmax); }
+}
 __global__ void __launch_bounds__(kBlock) k_depth_keys(const float4* __restrict__ rec, uint32_t n, float v02, float v12,
-                                                       float v22, float v32, uint32_t* __restrict__ key, float4* __restrict__ plane) {
+                                                       float v22, float v32, uint32_t* __restrict__ key, float4* __restrict__ plane,
+                                                       uint2* __restrict__ minmax) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = rec[(size_t)i * 6];  // position (xyz, 1)
-    key[i] = depth_key(p, v02, v12, v22, v32);
-    if (plane) plane[i] = p;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (i < n) {
+        const float4 p = rec[(size_t)i * 6];  // position (xyz, 1)
+        const uint32_t k = depth_key(p, v02, v12, v22, v32);
+        key[i] = k;
+        if (plane) plane[i] = p;
+        kmin = kmax = k;
+    }
+    reduce_minmax(kmin, kmax, minmax);
 }
 __global__ void __launch_bounds__(kBlock) k_depth_keys_from_plane(const float4* __restrict__ plane, uint32_t n, float v02, float v12,
-                                                                  float v22, float v32, uint32_t* __restrict__ key) {
+                                                                  float v22, float v32, uint32_t* __restrict__ key, uint2* __restrict__ minmax) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    key[i] = depth_key(plane[i], v02, v12, v22, v32);
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (i < n) {
+        const uint32_t k = depth_key(plane[i], v02, v12, v22, v32);
+        key[i] = k;
+        kmin = kmax = k;
+    }
+    reduce_minmax(kmin, kmax, minmax);
 }
 
-// one thread per float4: consecutive lanes write consecutive 16 B of the sorted buffer (fully coalesced
-// 1 KiB stores); the 96 B source records are gathered (6 lanes share one record)
 __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restrict__ src, const uint32_t* __restrict__ val,
                                                            uint32_t n, float4* __restrict__ dst) {
     const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -48,31 +84,77 @@ __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restr
     const uint32_t r = (uint32_t)(q / 6), k = (uint32_t)(q - (size_t)r * 6);
     dst[q] = src[(size_t)val[r] * 6 + k];
 }
+// the sorted keys of a reduced-range sort are `key - offset`: put the offset back (only when somebody asks for the keys)
+__global__ void __launch_bounds__(kBlock) k_add_to_keys(uint32_t* __restrict__ key, uint32_t n, uint32_t offset) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) key[i] += offset;
+}
+void launch_add_to_keys(uint32_t* keys, uint32_t n, uint32_t offset, hipStream_t st) {
+    if (n && offset) hipLaunchKernelGGL(k_add_to_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, keys, n, offset);
+}
+
+struct SubtractKey {
+    uint32_t m;
+    __host__ __device__ uint32_t operator()(uint32_t k) const { return k - m; }
+};
 
 size_t sort_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
+    size_t bytes = 0, bytes_t = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 32,
                                     (hipStream_t)0);
-    return bytes;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes_t, rocprim::make_transform_iterator((uint32_t*)nullptr, SubtractKey{ 0u }), (uint32_t*)nullptr,
+                                    rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 24, (hipStream_t)0);
+    // + the two words of the key range and the per-wave {min, max} table of the key kernels (at the end of the buffer)
+    return (((bytes > bytes_t ? bytes : bytes_t) + 15) & ~(size_t)15) + 16 + (size_t)((n + 63) / 64) * 8;
 }
 
 // plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  stage_ev (or nullptr): four
 // events recorded around the three stages (keys | radix sort | gather).  The values are the record indices: they come from a
 // counting iterator, not from memory.
 hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out,
-                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st) {
+                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st,
+                         uint32_t* key_offset_out, uint32_t* pinned_mm) {
+    if (key_offset_out) *key_offset_out = 0;
     if (!n) return hipSuccess;
+    const uint32_t n_waves = (n + 63) / 64;
+    const size_t tail = 16 + (size_t)n_waves * 8;
+    if (temp_bytes < tail + 16) return hipErrorInvalidValue;
+    temp_bytes = (temp_bytes - tail) & ~(size_t)15;
+    uint32_t* minmax = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + temp_bytes);
+    uint2* wave_mm = reinterpret_cast<uint2*>(minmax + 4);
+    const uint32_t init[2] = { 0xFFFFFFFFu, 0u };
+    hipError_t e = hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
     const dim3 grid((n + kBlock - 1) / kBlock);
     if (stage_ev) (void)hipEventRecord(stage_ev[0], st);
-    if (plane && plane_valid) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in);
-    else hipLaunchKernelGGL(k_depth_keys, grid, dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in, plane);
+    if (plane && plane_valid) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in, wave_mm);
+    else hipLaunchKernelGGL(k_depth_keys, grid, dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in, plane, wave_mm);
+    hipLaunchKernelGGL(k_reduce_minmax, dim3(std::min<uint32_t>((n_waves + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, st, wave_mm, n_waves, minmax);
     if (stage_ev) (void)hipEventRecord(stage_ev[1], st);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
+    // the keys' range decides how many radix passes the library makes: 8 bytes come back to the host (one sync, ~15 us of a ~1.7 ms call)
+    uint32_t mm_local[2] = { 0u, 0xFFFFFFFFu };
+    uint32_t* mm = pinned_mm ? pinned_mm : mm_local;          // (pinned: the copy is a DMA the sync waits for, not a staged pageable copy)
+    e = hipMemcpyAsync(mm, minmax, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    const uint32_t range = mm[1] >= mm[0] ? mm[1] - mm[0] : 0xFFFFFFFFu;
+    int bits = 1;
+    while (bits < 32 && (range >> bits) != 0u) ++bits;
+    uint32_t key_offset = 0;
+    if ((bits + 7) / 8 < 4) {   // fewer 8-bit passes than the full 32-bit sort: sort key - min over `bits` bits (same order, same stability)
+        key_offset = mm[0];
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractKey{ key_offset }), keys_out,
+                                      rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, bits, st);
+    } else {
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
+    }
     if (e != hipSuccess) return e;
     if (stage_ev) (void)hipEventRecord(stage_ev[2], st);
     const size_t nq = (size_t)n * 6;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
     if (stage_ev) (void)hipEventRecord(stage_ev[3], st);
+    if (key_offset_out) *key_offset_out = key_offset;            // keys_out holds key - offset (m2s_device_sorted_keys puts it back on demand)
+    else launch_add_to_keys(keys_out, n, key_offset, st);
     return hipGetLastError();
 }
 

@@ -54,7 +54,8 @@ m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t
     const bool plane_valid = c->d_pos_plane && c->pos_plane_of == c->last_records && c->pos_plane_n == n && c->pos_plane_epoch == c->records_epoch;
     uint32_t* u = c->d_sort_u32;     // keys_in | (unused) | keys_out | vals_out
     HIPCHK(c, sort_by_depth((const float4*)c->last_records, (uint32_t)n, world_to_view, u, u + 2 * n, u + 3 * n, c->d_sort_temp,
-                            c->sort_temp_cap, (float4*)c->d_sorted, (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream));
+                            c->sort_temp_cap, (float4*)c->d_sorted, (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream,
+                            &c->sorted_key_offset, reinterpret_cast<uint32_t*>(&c->h_total[10])));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_pos_plane) { c->pos_plane_of = c->last_records; c->pos_plane_n = n; c->pos_plane_epoch = c->records_epoch; }
     if (c->profiling) {
@@ -67,7 +68,20 @@ m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t
 
 const void* m2s_device_sorted_records(const m2s_ctx* c) { return c && c->sorted_n ? c->d_sorted : nullptr; }
 // the keys of those records (uint32, ascending): keys_out of the radix sort
-const void* m2s_device_sorted_keys(const m2s_ctx* c) { return c && c->sorted_n ? c->d_sort_u32 + 2 * c->sorted_n : nullptr; }
+// (the sort runs over the bits in which the keys differ, on `key - smallest key`: the smallest key is added back here, once, when
+//  somebody asks for the keys — the distributed sort does; a frame's sort + gather does not)
+const void* m2s_device_sorted_keys(const m2s_ctx* cc) {
+    m2s_ctx* c = const_cast<m2s_ctx*>(cc);
+    if (!c || !c->sorted_n) return nullptr;
+    uint32_t* keys = c->d_sort_u32 + 2 * c->sorted_n;
+    if (c->sorted_key_offset) {
+        if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+        launch_add_to_keys(keys, (uint32_t)c->sorted_n, c->sorted_key_offset, c->stream);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
+        c->sorted_key_offset = 0;
+    }
+    return keys;
+}
 uint64_t m2s_num_sorted(const m2s_ctx* c) { return c ? c->sorted_n : 0; }
 uint32_t m2s_last_resolution(const m2s_ctx* c) { return c ? c->last_R : 0; }
 
