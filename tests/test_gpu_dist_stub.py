@@ -183,8 +183,10 @@ def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
     assert "could not be created" in bad.stderr
 
 
+# (world 8 — eight processes with their polling threads on a 16-core box, all on one GPU — takes anything from 7 s to 5 min depending on the box's load:
+#  opt-in with M2S_TEST_DRY_SCALE_8=1; the rank-script and command-line tests above run at world 8 in every suite)
 @needs_stub
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4] + ([8] if os.environ.get("M2S_TEST_DRY_SCALE_8") else []))
 def test_bench_dry_scale_prints_the_scale_record(hiplib, tmp_path, world):
     """bench.py --gpus N --dry-scale: the N-process schedule of a SCALE run on the one GPU of a CI box (the stand-in is selected by
     bench.py itself), no torch.distributed anywhere: the line carries the record the driver reads — ranks, per-rank Gaussians,

@@ -19,6 +19,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_tr
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace_c3 -o k -- python $R/bench.py --no-overlap-extra --no-c5 --no-cpu-baseline --no-viewer-extra --no-cold --no-extra-workloads > $O/${TAG}_trace_c3.json 2> $O/${TAG}_trace_c3.err || echo "trace of c3 failed"
 for t in bench c3; do f=$(ls $O/${TAG}_trace_$t/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -9 $f | cut -c1-170; done
 cd $R
+# the driver's launch line for N > 1 (torchrun sets RANK / WORLD_SIZE / MASTER_*), here with both ranks on this one GPU through the RCCL stand-in
+D=$(mktemp -d); mkdir -p $D/objs
+M2S_RCCL_PATH=$R/tests/stub_rccl/_build/librccl_stub.so M2S_STUB_RCCL_DIR=$D/objs M2S_STUB_RCCL_LOG=$D/log M2S_STUB_RCCL_TIMEOUT=120 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --one-device --workload c2 --steps 5 --warmup 1 --no-extra-workloads --no-strong-scaling > $O/${TAG}_torchrun2.json 2> $O/${TAG}_torchrun2.err; python -c "
+import json; d=json.loads([l for l in open('$O/${TAG}_torchrun2.json') if l.startswith('{')][-1]); print('torchrun x2 (stand-in):', d['n_gpus'], d['exchange_transport'][:20], d['scale_record']['per_rank_gaussians'], round(d['scale_record']['bringup_ms'],1), d['multi_gpu_bringup']['errors'])" || tail -5 $O/${TAG}_torchrun2.err
 timeout 1500 python -m pytest tests -m gpu -q --durations=6 > $O/${TAG}_tests.log 2>&1; grep -E "passed|failed|^[0-9.]+s (call|setup)" $O/${TAG}_tests.log | head -10
 else
 cd /tmp && export TMPDIR=/tmp
