@@ -141,6 +141,8 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
         HIPCHK(c, hipStreamSynchronize(st));
         c->warm_big = c->h_total[1];
         c->h_total[1] = 0;
+        const unsigned long long tot = total;      // (d_total served as the accumulator: the total goes back, launch_run_order below reads it)
+        HIPCHK(c, hipMemcpy(c->d_total, &tot, sizeof tot, hipMemcpyHostToDevice));
     }
     // A scene small enough for ONE generation of workgroups (fused_tpw < 64) lasts as long as its slowest workgroup: cut it into
     // batches of equal estimated work instead of equal triangle counts (C2 stand-in: fragments per workgroup vary 1 : 3 over a
