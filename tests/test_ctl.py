@@ -55,3 +55,13 @@ def test_sequence_numbers_keep_rounds_apart(tmp_path):
         assert b.allgather("u64", b"B1") == [b"A1", b"B1"]
     finally:
         os.environ.pop("M2S_RDZV_DIR", None)
+
+
+def test_bench_has_no_second_rendezvous_mechanism():
+    """bench.py's control plane is mesh2splat_amd/ctl.py + the C-ABI communicator: no torch.distributed process group beside it
+    (VERDICT r4 item 6); ctl.py itself imports neither torch nor the HIP library."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "torch.distributed" not in src and "init_process_group" not in src and "dist.barrier" not in src
+    ctl = open(os.path.join(root, "mesh2splat_amd", "ctl.py")).read()
+    assert "import torch" not in ctl and "_lib" not in ctl
