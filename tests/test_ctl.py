@@ -64,4 +64,5 @@ def test_bench_has_no_second_rendezvous_mechanism():
     src = open(os.path.join(root, "bench.py")).read()
     assert "torch.distributed" not in src and "init_process_group" not in src and "dist.barrier" not in src
     ctl = open(os.path.join(root, "mesh2splat_amd", "ctl.py")).read()
-    assert "import torch" not in ctl and "_lib" not in ctl
+    code = [ln.split("#")[0] for ln in ctl.splitlines()]
+    assert not any(ln.strip().startswith(("import torch", "from torch")) or "_lib" in ln for ln in code)
