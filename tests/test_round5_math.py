@@ -239,3 +239,58 @@ def test_sorting_key_minus_min_over_the_bits_that_differ_is_the_same_sort():
         assert np.array_equal(order, np.argsort(key, kind="stable"))
     mixed = np.array([-1.0, 2.0, -0.5, 0.25], np.float32).view(np.uint32).astype(np.int64)
     assert int(mixed.max() - mixed.min()).bit_length() > 24            # a range that spans the sign keeps all 32 bits (four passes)
+
+
+def test_row_starts_plus_fill_reproduces_the_pixel_list():
+    """k_emit2's expansion (m2s_emit2.hip): every covered row writes ONE entry — at its first record inside [pos, bend), with the x of that
+    record — and sets the record's bit; the fill gives every record the nearest start at or before it plus the distance, 64 records at a
+    time with the last lane's entry carried into the next block.  Against the straightforward pixel-by-pixel list, for slices that begin
+    and end inside rows, rows longer than a block, and single-record rows."""
+    for trial in range(300):
+        wbase = int(RNG.integers(0, 4)) * 512
+        # rows of the triangles that overlap the slice: (slot, y, xa, length), in canonical order; the first may start before the slice
+        k = wbase - int(RNG.integers(0, 300))
+        rows = []
+        while k < wbase + 512 + 100:
+            ln = int(RNG.choice([1, 1, 2, 3, 7, 30, 64, 65, 200, 700]))
+            rows.append((int(RNG.integers(0, 64)), int(RNG.integers(0, 4096)), int(RNG.integers(0, 4096 - ln)), ln, k))
+            k += ln
+        pos = wbase + int(RNG.integers(0, 200)) if trial % 3 else wbase
+        bend = min(wbase + 512, pos + int(RNG.integers(1, 513)))
+        want = {}
+        for slot, y, xa, ln, k0 in rows:
+            for j in range(ln):
+                if pos <= k0 + j < bend:
+                    want[k0 + j] = (slot << 24) | (y << 12) | (xa + j)
+        assert sorted(want) == list(range(pos, bend))
+        # step 1: row starts (mark_row)
+        entries = [0xDEADBEEF] * 512
+        mask = 0
+        for slot, y, xa, ln, k0 in rows:
+            if ln and k0 < bend and k0 + ln > pos:
+                st = max(k0, pos)
+                i = st - wbase
+                entries[i] = (slot << 24) | (y << 12) | (xa + (st - k0))
+                mask |= 1 << i
+        # step 2: fill, block by block
+        i0, i1 = pos - wbase, bend - wbase
+        carry = 0
+        for blk in range(i0 >> 6, ((i1 - 1) >> 6) + 1):
+            m = (mask >> (64 * blk)) & ((1 << 64) - 1)
+            e_blk = []
+            for lane in range(64):
+                i = blk * 64 + lane
+                me = m & ((1 << (lane + 1)) - 1)
+                if me:
+                    src = me.bit_length() - 1
+                    e = (entries[blk * 64 + src] + (lane - src)) & 0xFFFFFFFF
+                else:
+                    e = (carry + lane + 1) & 0xFFFFFFFF
+                e_blk.append(e)
+            for lane in range(64):
+                i = blk * 64 + lane
+                if i0 <= i < i1:
+                    entries[i] = e_blk[lane]
+            carry = e_blk[63]
+        for kk in range(pos, bend):
+            assert entries[kk - wbase] == want[kk], (trial, kk)
