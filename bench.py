@@ -21,8 +21,9 @@ merged splat buffer.  Reported next to it, outside `value`:
   strong_scaling   ONE scene (C3, and the C4 stand-in) cut into N fragment-balanced triangle ranges: convert + counter
                    exchange ("no_gather": what per-rank .ply slice writers need) and convert + record exchange ("gather").
 N == 1 adds: cold_path (first call on a fresh context, densities never seen before, three rotating scene copies that
-do not fit the Infinity Cache), extra_workloads (C2 stand-in, a 26-fragments-per-triangle mesh, the C4 stand-in, BASELINE config 5
-at full size), overlapped (two asynchronous lanes),
+do not fit the Infinity Cache), extra_workloads (C2 stand-in, an 11.6- and a 26-fragments-per-triangle mesh, the C4 stand-in, the
+heterogeneous synth.sponza_like scene, BASELINE config 5 at full size; each with kernel times, one blocking call and roofline fractions —
+flat in roofline.workloads), overlapped (two asynchronous lanes),
 viewer_passes, cpu_baseline.
 
 Prints ONE JSON line on rank 0.
