@@ -156,7 +156,7 @@ m2s_status m2s_create(int device, m2s_ctx** out_ctx) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipMalloc(&c->d_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&c->h_total, (4 + 2 * M2S_MAX_IN_FLIGHT) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void**)&c->h_total, m2s_ctx::kPinnedWords * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);

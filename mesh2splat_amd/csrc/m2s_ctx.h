@@ -42,7 +42,11 @@ struct m2s_ctx {
     uint32_t* d_start = nullptr;
     size_t start_cap = 0;
     unsigned long long* d_total = nullptr;
-    unsigned long long* h_total = nullptr;  // pinned: [0] = fragment counter, [1] = status words of the fused kernel
+    unsigned long long* h_total = nullptr;  // pinned, kPinnedWords words: [0] = fragment counter, [1] = status words of the fused kernel,
+                                            // [2 + 2k], [3 + 2k] = the same of in-flight slot k, then one word each for the prepass and the depth sort
+    static constexpr int kPinnedPrepass = 2 + 2 * M2S_MAX_IN_FLIGHT;   // m2s_prepass: survivors
+    static constexpr int kPinnedSortMM = 3 + 2 * M2S_MAX_IN_FLIGHT;    // m2s_sort_by_depth: {min, max} of the keys (two 32-bit words)
+    static constexpr int kPinnedWords = 4 + 2 * M2S_MAX_IN_FLIGHT;
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
     m2s::BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions

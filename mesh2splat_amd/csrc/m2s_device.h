@@ -116,8 +116,11 @@ uint32_t emit2_slices(uint64_t limit);       // entries of start[] needed for `l
 uint32_t count_scan_blocks(uint32_t n_tri);  // chain words k_count_scan uses
 size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array + the tall-triangle table behind it
 size_t setup_tall_offset(uint32_t n_tri);    // where that table's 16-byte header starts (zero when the buffer is allocated)
+// limit / out: the conversion's record limit and buffer — fine blocks (m2s_emit2.hip) are emitted by k_count_scan itself; limit 0: count only.
+// total_host (pinned, may be nullptr): the last workgroup also stores the fragment counter there
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
-                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, hipStream_t st);
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, uint64_t limit, float4* out,
+                       unsigned long long* total_host, hipStream_t st);
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
                   uint64_t limit, const void* setup, float4* out, hipStream_t st);
 

@@ -303,10 +303,9 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
         uint32_t epoch;
         HIPCHK(c, next_epoch(c, &epoch));
         launch_count_scan(sc, R, c->d_off_b, c->d_start_b, emit2_slices(limit), c->d_chain_b, epoch, c->d_total_b, c->d_setup_b,
-                          reinterpret_cast<uint32_t*>(&h_res[1]), st);
+                          reinterpret_cast<uint32_t*>(&h_res[1]), limit, d_out, &h_res[0], st);
         launch_emit2(sc, R, c->d_off_b, c->d_start_b, c->d_total_b, limit, c->d_setup_b, d_out, st);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total_b, 8, hipMemcpyDeviceToHost, st));
         return M2S_OK;
     }
     if (multipass_v1()) {
@@ -325,13 +324,14 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
         HIPCHK(c, next_epoch(c, &epoch));
         if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
         launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
-                          reinterpret_cast<uint32_t*>(&h_res[1]), st);
+                          reinterpret_cast<uint32_t*>(&h_res[1]), limit, d_out, &h_res[0], st);
         if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
         launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
         if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+    // (second generation: k_count_scan's last workgroup has written the counter to *h_res itself — no copy behind the pipeline)
+    if (multipass_v1()) HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
     return M2S_OK;
 }
 }

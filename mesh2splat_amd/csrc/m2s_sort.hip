@@ -93,6 +93,9 @@ void launch_add_to_keys(uint32_t* keys, uint32_t n, uint32_t offset, hipStream_t
     if (n && offset) hipLaunchKernelGGL(k_add_to_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, keys, n, offset);
 }
 
+// waves of the key kernels' grid = entries of the per-wave {min, max} table
+static inline uint32_t sort_grid_waves(uint32_t n) { return (n + kBlock - 1) / kBlock * (kBlock / 64); }
+
 struct SubtractKey {
     uint32_t m;
     __host__ __device__ uint32_t operator()(uint32_t k) const { return k - m; }
@@ -104,8 +107,10 @@ size_t sort_temp_bytes(uint32_t n) {
                                     (hipStream_t)0);
     (void)rocprim::radix_sort_pairs(nullptr, bytes_t, rocprim::make_transform_iterator((uint32_t*)nullptr, SubtractKey{ 0u }), (uint32_t*)nullptr,
                                     rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 24, (hipStream_t)0);
-    // + the two words of the key range and the per-wave {min, max} table of the key kernels (at the end of the buffer)
-    return (((bytes > bytes_t ? bytes : bytes_t) + 15) & ~(size_t)15) + 16 + (size_t)((n + 63) / 64) * 8;
+    // + the two words of the key range and the per-wave {min, max} table of the key kernels (at the end of the buffer): one entry for
+    // EVERY wave of the key kernels' grid, the idle waves of the last workgroup included ((n + 63) / 64 entries were up to
+    // three short of what the grid writes)
+    return (((bytes > bytes_t ? bytes : bytes_t) + 15) & ~(size_t)15) + 16 + (size_t)sort_grid_waves(n) * 8;
 }
 
 // plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  stage_ev (or nullptr): four
@@ -116,7 +121,7 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
                          uint32_t* key_offset_out, uint32_t* pinned_mm) {
     if (key_offset_out) *key_offset_out = 0;
     if (!n) return hipSuccess;
-    const uint32_t n_waves = (n + 63) / 64;
+    const uint32_t n_waves = sort_grid_waves(n);       // (idle waves of the last workgroup store {0xFFFFFFFF, 0}: neutral for the fold)
     const size_t tail = 16 + (size_t)n_waves * 8;
     if (temp_bytes < tail + 16) return hipErrorInvalidValue;
     temp_bytes = (temp_bytes - tail) & ~(size_t)15;

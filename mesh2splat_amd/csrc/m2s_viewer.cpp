@@ -55,7 +55,7 @@ m2s_status m2s_sort_by_depth(m2s_ctx* c, const float world_to_view[16], uint64_t
     uint32_t* u = c->d_sort_u32;     // keys_in | (unused) | keys_out | vals_out
     HIPCHK(c, sort_by_depth((const float4*)c->last_records, (uint32_t)n, world_to_view, u, u + 2 * n, u + 3 * n, c->d_sort_temp,
                             c->sort_temp_cap, (float4*)c->d_sorted, (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream,
-                            &c->sorted_key_offset, reinterpret_cast<uint32_t*>(&c->h_total[10])));
+                            &c->sorted_key_offset, reinterpret_cast<uint32_t*>(&c->h_total[m2s_ctx::kPinnedSortMM])));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_pos_plane) { c->pos_plane_of = c->last_records; c->pos_plane_n = n; c->pos_plane_epoch = c->records_epoch; }
     if (c->profiling) {
@@ -157,7 +157,7 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
             k.depth = c->d_pp_depthtex;
         }
     } else k.depth_test = 0;
-    unsigned long long* res = &c->h_total[2 + 2 * M2S_MAX_IN_FLIGHT];
+    unsigned long long* res = &c->h_total[m2s_ctx::kPinnedPrepass];
     res[0] = 0; res[1] = 0;
     if (k.arrival_order) HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, sizeof(unsigned long long), c->stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
