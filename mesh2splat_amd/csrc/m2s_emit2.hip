@@ -26,15 +26,14 @@
 //                 64-triangle batches — each a dependent chain of global round trips (offsets, TriSetup, attributes, texels) —
 //                 walked by ONE wave: the heterogeneous scene's k_emit2 took 0.26 ms for 4.3 M fragments, 2.2 times the time per
 //                 fragment of the C4 stand-in, waiting for the ~30 waves inside its two foliage meshes.  k_count_scan therefore
-//                 classes every block of 256 triangles: FINE if the whole block yields at most kFineMax fragments (and none of its
+//                 classes every block of 256 triangles: FINE if the whole block yields at most 2048 fragments (and none of its
 //                 triangles is taller than 32 pixel rows).  Fine blocks are emitted triangle-partitioned — one workgroup per block,
-//                 one thread per triangle, the block's whole entry list in LDS; the output-partitioned slices step over them
+//                 one thread per triangle, the block's whole entry list in LDS, no inter-workgroup dependency because the offsets are
+//                 known — by extra workgroups of the SAME launch (emit_fine_block); the output-partitioned slices step over them
 //                 (one scalar load per block).  The pipeline choice has become a per-256-triangle decision taken on the device.
-//                 (round 6) ... and the workgroup that emits a fine block is the one that COUNTED it: k_count_scan's workgroup holds
-//                 the block's TriShade records and raster setups in registers when it learns the block's class, so it expands them
-//                 into its LDS while the look-back is under way and shades the strips as soon as the base is known — like the
-//                 single-pass kernels.  Until round 6 it wrote 112 bytes of TriSetup per covered triangle for extra workgroups of
-//                 k_emit2 to read straight back, and the count stage (20-30 % of a multi-pass conversion) did nothing but count.
+//                 (Round 6 tried the obvious next step — the workgroup of k_count_scan that counted a fine block emits it, no TriSetup
+//                 round trip — and measured it slower: the count stage lasts as long as its slowest workgroup and k_emit2 lost the
+//                 workgroups that filled its tail; tag r6-fine-fold-in-count, profiles/r06/negative_fine_blocks_folded_into_k_count_scan.log.)
 // Output: bit-identical to every other pipeline (same device functions, same operation order).
 #include <cstdlib>
 #include "m2s_fused_common.h"
@@ -81,8 +80,7 @@ __device__ __forceinline__ uint32_t* tall_header(const float4* setup, uint32_t n
     return reinterpret_cast<uint32_t*>(const_cast<float4*>(setup) + (size_t)max(n_tri, 1u) * 7);
 }
 // ... and behind that table one byte per block of kCountBlock triangles: 1 = fine block (see the file header)
-constexpr uint32_t kFineMax = 2032;           // fragments of a fine block: its entry list fits the workgroup's LDS (2048 entries, the last
-                                              // sixteen words of which hold k_count_scan's scan words: 40 KB per workgroup, four per CU)
+constexpr uint32_t kFineMax = 2048;           // fragments of a fine block: its entry list fits the workgroup's LDS
 __device__ __forceinline__ uint8_t* block_class(const float4* setup, uint32_t n_tri) {
     return reinterpret_cast<uint8_t*>(tall_header(setup, n_tri) + 4 + (size_t)kTallCap * kTallChunks);
 }
@@ -101,64 +99,6 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
     return r;
 }
 
-// ---- LDS of both kernels, and the strip both of them shade ----
-struct Emit2Lds {
-    float4 tri[64 * 5];          // TriShade of the current batch of (up to) 64 triangles
-    uint32_t entries[kSlice];    // slot << 24 | y << 12 | x, indexed by (record index - slice base)
-    float4 stage[32 * 6];        // half-wave record staging; during the expansion its first 64 bytes hold the row-start mask
-                                 // of the slice (one bit per record, row_mask below) — the two uses never overlap in time
-    __device__ __forceinline__ uint32_t* row_mask() { return reinterpret_cast<uint32_t*>(stage); }
-};
-static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of four waves per CU");
-// a fine block's workgroup: the TriShade of its 256 triangles, its whole entry list, one staging area per wave — the same 40 KB
-struct FineLds {
-    float4 tri[kCountBlock * 5];
-    uint32_t entries[2048];      // thread << 24 | y << 12 | x, indexed by (record index - block base): at most kFineMax of them; ...
-    static constexpr int kScanWords = 2048 - 16;   // ... the last sixteen words are k_count_scan's: wsum[4] | wtall[4] | base (2 words)
-    float4 stage[kBlock / 64][32 * 6];
-};
-static_assert(sizeof(FineLds) == sizeof(Emit2Lds) * (kBlock / 64) && sizeof(FineLds) == 40960, "40 KB per workgroup in both kernels: four workgroups per CU");
-static_assert(kFineMax <= (uint32_t)FineLds::kScanWords, "a fine block's entries end before the scan words");
-static_assert(kCountBlock == kBlock, "a fine block is emitted by one thread per triangle");
-
-// One strip: the fragments whose entries are strip[0 .. n) (slot << 24 | y << 12 | x; slot = index into `tri`, triangle t_base +
-// slot) are shaded and written to dst[0 .. n) — staged half a wave at a time, 16 B per lane, non-temporal.
-__device__ __forceinline__ void shade_and_store_strip(const SceneDev& sc, const float4* tri, const uint32_t* strip, uint32_t n, uint32_t t_base,
-                                                      float4* stage, float4* __restrict__ dst, int lane) {
-    const bool have = (uint32_t)lane < n;
-    uint32_t en = 0;
-    if (have) en = strip[lane];
-    const uint32_t tl = en >> 24;
-    uint32_t my_mesh = 0;
-    if (have) my_mesh = reinterpret_cast<const uint32_t*>(&tri[tl * 5 + 4])[3] & 0xFFFFFFu;
-    const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
-    const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
-    float4 rec[6];
-    if (have) {
-        const TriShade& ts = *reinterpret_cast<const TriShade*>(&tri[tl * 5]);
-        const uint32_t tt = t_base + tl;
-        if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
-        else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
-    }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        if (have && (lane >> 5) == half) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) stage[(lane & 31) * 6 + k] = rec[k];
-        }
-        wave_lds_sync();
-        float4* __restrict__ dsto = dst + 32u * half * 6u;
-        const uint32_t nv = n > 32u * half ? min(32u, n - 32u * half) : 0u;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t q = (uint32_t)lane + 64u * j;
-            const uint32_t r = q / 6u;
-            if (r < nv) nt_store(&dsto[q], stage[q]);
-        }
-        wave_lds_sync();
-    }
-}
-
 // ============================================================================================
 // k_count_scan
 // ============================================================================================
@@ -167,15 +107,18 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
                                                             unsigned long long* __restrict__ chain, uint32_t epoch,
                                                             unsigned long long* __restrict__ total_out,
                                                             float4* __restrict__ setup, uint32_t* __restrict__ status,
-                                                            unsigned long long limit, float4* __restrict__ out,
-                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */) {
-    __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
-    FineLds& F = *reinterpret_cast<FineLds*>(lds_raw);
-    uint32_t* const wsum = &F.entries[FineLds::kScanWords];            // [kCountBlock / 64]
-    uint32_t* const wtall = wsum + kCountBlock / 64;                   // [kCountBlock / 64]
-    unsigned long long* const base_sp = reinterpret_cast<unsigned long long*>(wtall + kCountBlock / 64);
+                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */,
+                                                            uint32_t block_lo, unsigned long long* __restrict__ chunk_end) {
+    __shared__ uint32_t wsum[kCountBlock / 64];
+    __shared__ uint32_t wtall[kCountBlock / 64];
+    __shared__ unsigned long long base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blockBase = blockIdx.x * kCountBlock;
+    // A launch covers the blocks [block_lo, block_lo + gridDim.x) of the scene: the whole scene, or one CHUNK of a conversion that is
+    // pipelined over two streams (m2s_pass.cpp: enqueue_multipass).  Chain words, offsets and classes are indexed by the block's
+    // number in the scene, so a later chunk's look-back simply continues in the words its predecessor left behind.
+    const uint32_t bid = block_lo + blockIdx.x;
+    const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
+    const uint32_t blockBase = bid * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
     const bool valid = t < sc.n_tri;
     const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
@@ -222,7 +165,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
             if (lane == 0) slot = atomicAdd(&hdr[0], 1u);
             slot = __builtin_amdgcn_readfirstlane(slot);
             const bool listed = slot < kTallCap;
-            uint32_t* const row = hdr + 4 + (size_t)(listed ? slot : 0u) * kTallChunks;
+            uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
             uint32_t run = 0, ci = 0;
             RowWalkerS rw;       // lane l: rows y0 + l, y0 + l + 64, ... (one closed-form setup per lane, then division-free steps)
             if (b.y0 + lane <= b.y1) row_walker_init_strided(b, b.y0 + lane, 64, rw);
@@ -249,59 +192,39 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         any_tall |= wtall[w];
     }
     // the block's class: who emits its fragments (see the file header)
-    const bool fine = tot <= kFineMax && !any_tall;
-    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[blockIdx.x] = fine ? 1 : 0;
-    // a fine block is emitted HERE, by the workgroup that has just counted it (a conversion that stores nothing only counts)
-    const bool emit_here = fine && tot != 0u && limit != 0ull;
+    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[bid] = (tot <= kFineMax && !any_tall) ? 1 : 0;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     // The workgroup's aggregate is published as soon as it is known — BEFORE the per-triangle setup records are computed and
     // stored: successors can resolve their bases while this workgroup is still busy, and this workgroup's own look-back
     // (below) finds its predecessors' words already in place.  (Setup first, then publish: k_count_scan 0.042 ms on the C4
     // stand-in; without any setup 0.027 ms, without the look-back 0.030 ms: the two used to add up on the critical path.)
     if (wave == 0 && lane == 0)
-        chain_store(&chain[blockIdx.x], (blockIdx.x == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
-    const uint32_t lo0 = woff + (incl - c);      // this triangle's first record, counted from the block's first
-    if (c) {   // the per-triangle half of the fragment stage, once
+        chain_store(&chain[bid], (bid == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+    if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
         if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
         else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
         s.ts.mesh |= m;
+        const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+        s.a0 = rs.a[0]; s.b0 = rs.b[0];
+        s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
+        s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
+        s.tall = tall_slot;
+        s.pad[0] = s.pad[1] = 0;
         const float4* src4 = reinterpret_cast<const float4*>(&s);
-        if (emit_here) {
-            // fine block: the TriShade goes to LDS and the triangle's pixels into the block's entry list — none of which needs the
-            // block's base, so the look-back (below, wave 0) has this much work to hide behind
+        float4* dst4 = setup + (size_t)t * 7;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) F.tri[threadIdx.x * 5 + k] = src4[k];
-            const uint32_t tag = (uint32_t)threadIdx.x << 24;
-            uint32_t k = lo0;
-            RowWalker rw;
-            row_walker_init(rs, rs.y0, rw);
-            for (int y = rs.y0; y <= rs.y1; ++y) {
-                int xa, xb;
-                row_walker_next(rw, xa, xb);
-                for (int x = xa; x <= xb; ++x, ++k) F.entries[k] = tag | ((uint32_t)y << 12) | (uint32_t)x;
-            }
-        } else {
-            // k_emit2 only reads it
-            const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
-            s.a0 = rs.a[0]; s.b0 = rs.b[0];
-            s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
-            s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
-            s.tall = tall_slot;
-            s.pad[0] = s.pad[1] = 0;
-            float4* dst4 = setup + (size_t)t * 7;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
-        }
+        for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
     }
 
     if (wave == 0) {
-        const uint32_t b = blockIdx.x;
+        const uint32_t b = bid;
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
-            *base_sp = base;
-            if (b == gridDim.x - 1) {
+            base_s = base;
+            if (blockIdx.x == gridDim.x - 1) *chunk_end = base + tot;     // where this launch's records end (k_emit2 of the chunk reads it)
+            if (b == n_tb - 1) {
                 *total_out = base + tot;
                 // the counter the host waits for: written by the kernel itself (like the single-pass kernels), no copy behind the pipeline
                 if (total_host) __hip_atomic_store(total_host, base + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -309,13 +232,15 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         }
     }
     __syncthreads();
-    const unsigned long long base = *base_sp;
-    const unsigned long long o0 = base + lo0;
+    const unsigned long long base = base_s;
+    const unsigned long long o0 = base + woff + (incl - c);
     if (valid) {
         // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
         const unsigned long long o1 = o0 + c;
         off[t] = (uint32_t)min(o0, 0xFFFFFFFFull);
-        if (t == sc.n_tri - 1) off[sc.n_tri] = (uint32_t)min(o1, 0xFFFFFFFFull);
+        // ... and the end of the launch's last triangle: k_emit2 of a chunk reads off[] up to and including its one-past-the-end
+        // triangle (the next chunk's first block stores the same value there, possibly at the same time)
+        if (t == min((block_lo + gridDim.x) * (uint32_t)kCountBlock, sc.n_tri) - 1u) off[t + 1] = (uint32_t)min(o1, 0xFFFFFFFFull);
     }
     // start[m] = the triangle that owns output record m * kSlice.  A triangle covering many slices (up to 32 768 for a
     // 4096 x 4096 px one) has the whole wave write them.
@@ -331,31 +256,130 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         const uint32_t tt = __shfl(t, src);
         for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) start[mm] = tt;
     }
-    // ---- a fine block's fragments: strips of 64 entries, the four waves in turn; the first `limit` records of the conversion are stored ----
-    if (emit_here && base < limit) {
-        const uint32_t n_store = (uint32_t)min((unsigned long long)tot, limit - base);
-        const uint32_t uwave = __builtin_amdgcn_readfirstlane((uint32_t)wave);
-        for (uint32_t s0 = uwave * 64u; s0 < n_store; s0 += (uint32_t)kCountBlock)
-            shade_and_store_strip(sc, F.tri, &F.entries[s0], min(64u, n_store - s0), blockBase, F.stage[uwave], out + ((size_t)base + s0) * 6, lane);
-    }
 }
 
 // ============================================================================================
 // k_emit2
 // ============================================================================================
+struct Emit2Lds {
+    float4 tri[64 * 5];          // TriShade of the current batch of (up to) 64 triangles
+    uint32_t entries[kSlice];    // slot << 24 | y << 12 | x, indexed by (record index - slice base)
+    float4 stage[32 * 6];        // half-wave record staging; during the expansion its first 64 bytes hold the row-start mask
+                                 // of the slice (one bit per record, row_mask below) — the two uses never overlap in time
+    __device__ __forceinline__ uint32_t* row_mask() { return reinterpret_cast<uint32_t*>(stage); }
+};
+static_assert(sizeof(Emit2Lds) == 10240, "10 KB per wave: four workgroups of four waves per CU");
+// a fine block's workgroup: the TriShade of its 256 triangles, its whole entry list, one staging area per wave — the same 40 KB
+struct FineLds {
+    float4 tri[kCountBlock * 5];
+    uint32_t entries[kFineMax];  // thread << 24 | y << 12 | x, indexed by (record index - block base)
+    float4 stage[kBlock / 64][32 * 6];
+};
+static_assert(sizeof(FineLds) == sizeof(Emit2Lds) * (kBlock / 64), "both kinds of workgroup of k_emit2 use the same LDS");
+static_assert(kCountBlock == kBlock, "a fine block is emitted by one thread per triangle");
+
+// One strip: the fragments whose entries are strip[0 .. n) (slot << 24 | y << 12 | x; slot = index into `tri`, triangle t_base +
+// slot) are shaded and written to dst[0 .. n) — staged half a wave at a time, 16 B per lane, non-temporal.
+__device__ __forceinline__ void shade_and_store_strip(const SceneDev& sc, const float4* tri, const uint32_t* strip, uint32_t n, uint32_t t_base,
+                                                      float4* stage, float4* __restrict__ dst, int lane) {
+    const bool have = (uint32_t)lane < n;
+    uint32_t en = 0;
+    if (have) en = strip[lane];
+    const uint32_t tl = en >> 24;
+    uint32_t my_mesh = 0;
+    if (have) my_mesh = reinterpret_cast<const uint32_t*>(&tri[tl * 5 + 4])[3] & 0xFFFFFFu;
+    const uint32_t m_first = __builtin_amdgcn_readfirstlane(my_mesh);   // lane 0 always holds a fragment
+    const bool uniform = sc.n_meshes == 1 || __ballot(have && my_mesh != m_first) == 0ull;
+    float4 rec[6];
+    if (have) {
+        const TriShade& ts = *reinterpret_cast<const TriShade*>(&tri[tl * 5]);
+        const uint32_t tt = t_base + tl;
+        if (uniform) shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), kConstMesh(sc.meshes + m_first), ts, rec);
+        else shade_from_tri(sc.tri, tt, (int)(en & 0xFFFu), (int)((en >> 12) & 0xFFFu), sc.meshes + my_mesh, ts, rec);
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (have && (lane >> 5) == half) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) stage[(lane & 31) * 6 + k] = rec[k];
+        }
+        wave_lds_sync();
+        float4* __restrict__ dsto = dst + 32u * half * 6u;
+        const uint32_t nv = n > 32u * half ? min(32u, n - 32u * half) : 0u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t q = (uint32_t)lane + 64u * j;
+            const uint32_t r = q / 6u;
+            if (r < nv) nt_store(&dsto[q], stage[q]);
+        }
+        wave_lds_sync();
+    }
+}
+
+// A fine block (at most kFineMax fragments from kCountBlock triangles of at most kRowsThread rows each): one thread per triangle
+// writes its pixels into the block's entry list, then the four waves take the strips in turn.
+__device__ __forceinline__ void emit_fine_block(const SceneDev& sc, const uint32_t* __restrict__ off, unsigned long long nw,
+                                                const float4* __restrict__ setup, float4* __restrict__ out, uint32_t blk, FineLds& F) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t T = sc.n_tri, t0 = blk * (uint32_t)kCountBlock, t1 = min(t0 + (uint32_t)kCountBlock, T);
+    const uint32_t base = off[t0], end = off[t1];
+    if (end <= base || (unsigned long long)base >= nw) return;
+    const uint32_t n_store = (uint32_t)min((unsigned long long)(end - base), nw - base);
+    const uint32_t t = t0 + threadIdx.x;
+    if (t < t1) {
+        const uint32_t o0 = off[t], o1 = off[t + 1];
+        if (o1 > o0 && o0 - base < n_store) {
+            TriSetup s;
+            const float4* src4 = setup + (size_t)t * 7;
+            float4* dst4 = reinterpret_cast<float4*>(&s);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) F.tri[threadIdx.x * 5 + k] = dst4[k];
+            const Raster rs = raster_from_setup(s);
+            const uint32_t tag = (uint32_t)threadIdx.x << 24;
+            uint32_t k = o0 - base;
+            RowWalker rw;
+            row_walker_init(rs, rs.y0, rw);
+            for (int y = rs.y0; y <= rs.y1 && k < n_store; ++y) {
+                int xa, xb;
+                row_walker_next(rw, xa, xb);
+                for (int x = xa; x <= xb && k < n_store; ++x, ++k) F.entries[k] = tag | ((uint32_t)y << 12) | (uint32_t)x;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s0 = wave * 64u; s0 < n_store; s0 += (uint32_t)kBlock)
+        shade_and_store_strip(sc, F.tri, &F.entries[s0], min(64u, n_store - s0), t0, F.stage[wave], out + ((size_t)base + s0) * 6, lane);
+}
+
 __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ start,
                                                      const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                      const float4* __restrict__ setup, float4* __restrict__ out,
-                                                     uint32_t run /* consecutive workgroups per XCD turn */) {
+                                                     uint32_t run /* consecutive workgroups per XCD turn */,
+                                                     uint32_t blk_lo, uint32_t blk_hi /* this launch emits the triangle blocks [blk_lo, blk_hi) ... */,
+                                                     const unsigned long long* __restrict__ rec_lo_p /* ... = the records [*rec_lo_p (nullptr: 0), */,
+                                                     uint32_t reset_tall /* *total_p): total_p = where k_count_scan of the chunk left its end */,
+                                                     uint32_t n_slice_wg /* workgroups of this launch behind the fine-block ones */,
+                                                     uint32_t* __restrict__ status /* pinned: [1] = 4 if they do not reach the chunk's end */) {
     __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long total = *total_p;
-    const unsigned long long nw = total < limit ? total : limit;  // records actually stored
-    const uint32_t T = sc.n_tri;
-    const uint8_t* __restrict__ cls = block_class(setup, T);
-    const uint32_t bid = blockIdx.x;
+    const unsigned long long nw = total < limit ? total : limit;  // records actually stored (of the scene's blocks [0, blk_hi))
+    const unsigned long long rec_lo = rec_lo_p ? *rec_lo_p : 0ull;   // the first record of this launch's blocks
+    const uint32_t Tall = sc.n_tri;
+    const uint32_t T = min(blk_hi * (uint32_t)kCountBlock, Tall);    // one past the last triangle of this launch
+    const uint8_t* __restrict__ cls = block_class(setup, Tall);
+    // the first workgroups of the launch (one per block of triangles, rounded up to whole groups of eight) take the FINE blocks
+    const uint32_t n_tb = blk_hi - blk_lo, n_fine_wg = (n_tb + 7u) & ~7u;
+    if (blockIdx.x < n_fine_wg) {
+        if (blockIdx.x < n_tb && cls[blk_lo + blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blk_lo + blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
+        return;
+    }
+    const uint32_t bid = blockIdx.x - n_fine_wg;
     Emit2Lds& L = reinterpret_cast<Emit2Lds*>(lds_raw)[wave];
     // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): the XCDs take turns of `run` consecutive
     // workgroups — runs of the output, of the mesh surface, of texture space meet in ONE L2 —, block-cyclically.  Until round 3
@@ -364,20 +388,28 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
     // inter-workgroup dependency, so any mapping is correct.
     // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
-    if (bid == 0 && threadIdx.x == 0) tall_header(setup, T)[0] = 0;
+    // (the launch that emits the scene's last blocks: every k_count_scan of the conversion has finished)
+    if (reset_tall && bid == 0 && threadIdx.x == 0) tall_header(setup, Tall)[0] = 0;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
     const uint32_t xcd = bid & 7u, turn = (bid >> 3) / run, in_run = (bid >> 3) % run;
-    const uint32_t lblock = (turn * 8u + xcd) * run + in_run;
+    const uint32_t lblock = (uint32_t)(rec_lo / per_wg) + (turn * 8u + xcd) * run + in_run;   // (workgroups are counted from the one that holds record rec_lo)
+    // A chunk's launch is sized from the host's ESTIMATE of where the chunk's records lie (exact at the density the upload counted
+    // at); should the real range end beyond the last workgroup, say so: the host repeats the conversion in one piece.
+    if (bid == 0 && threadIdx.x == 0 && (unsigned long long)nblk > rec_lo / per_wg + n_slice_wg)
+        __hip_atomic_store(&status[1], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lblock >= nblk) return;
     const uint32_t slice = lblock * (kBlock / 64) + wave;
     const unsigned long long wbase64 = (unsigned long long)slice * kSlice;
-    if (wbase64 >= nw) return;
+    if (wbase64 >= nw || wbase64 + kSlice <= rec_lo) return;
     const uint32_t wbase = (uint32_t)wbase64;
     const uint32_t wend = (uint32_t)(nw - wbase64 < (unsigned long long)kSlice ? nw : wbase64 + kSlice);
 
-    uint32_t pos = wbase;                 // next record to produce
-    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; ) {
+    // A slice that straddles the launch's first record belongs to two launches: the earlier one stopped at rec_lo (its nw), this one
+    // begins there, at the first triangle of its blocks.
+    const bool straddles = wbase64 < rec_lo;
+    uint32_t pos = straddles ? (uint32_t)rec_lo : wbase;                 // next record to produce
+    for (uint32_t t_cur = straddles ? blk_lo * (uint32_t)kCountBlock : start[slice]; pos < wend && t_cur < T; ) {
         // ---- the batch: up to 64 consecutive triangles, one per lane.  A fine block is stepped over; a batch that would run from a
         // dense block into a fine one ends at the block boundary.  Everything the decision needs is requested at once (the classes of
         // this block and the next, the offsets at both possible ends, the lanes' own offsets): one round trip, as before round 5 ----
@@ -457,7 +489,7 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
                 // (running sums never decrease; a chunk without fragments shares its sum with the next one and is skipped)
                 const uint32_t rel = pos - acc;
                 const int nch = min((b.y1 - b.y0) / 64 + 1, (int)kTallChunks);
-                const uint32_t* row = tall_header(setup, T) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
+                const uint32_t* row = tall_header(setup, Tall) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
                 const uint32_t pre = lane < nch ? row[lane] : 0xFFFFFFFFu;
                 const unsigned long long le = __ballot(pre <= rel);
                 const int c0 = le ? 63 - __clzll((long long)le) : 0;
@@ -507,27 +539,41 @@ size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (siz
 size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
 
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
-                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, uint64_t limit, float4* out,
-                       unsigned long long* total_host, hipStream_t st) {
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st,
+                       uint32_t block_lo, uint32_t block_hi, unsigned long long* chunk_end) {
     if (!sc.n_tri) return;
-    hipLaunchKernelGGL(k_count_scan, dim3(count_scan_blocks(sc.n_tri)), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
-                       epoch & 0xFFFFu, total, (float4*)setup, status, (unsigned long long)limit, out, total_host);
+    const uint32_t n_tb = count_scan_blocks(sc.n_tri);
+    if (block_hi > n_tb) block_hi = n_tb;
+    if (block_lo >= block_hi) return;
+    hipLaunchKernelGGL(k_count_scan, dim3(block_hi - block_lo), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
+                       epoch & 0xFFFFu, total, (float4*)setup, status, total_host, block_lo, chunk_end ? chunk_end : total);
 }
 
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
-                  uint64_t limit, const void* setup, float4* out, hipStream_t st) {
+                  uint64_t limit, const void* setup, float4* out, uint32_t* status, hipStream_t st, uint32_t block_lo, uint32_t block_hi,
+                  const unsigned long long* rec_lo, bool last_chunk, uint64_t est_lo, uint64_t est_hi) {
     if (!sc.n_tri) return;
+    const uint32_t n_tb = count_scan_blocks(sc.n_tri);
+    if (block_hi > n_tb) block_hi = n_tb;
+    if (block_lo >= block_hi) return;
     if (!limit) {   // a counting-only conversion: nothing to emit, but the tall-triangle table's slot counter still goes back to zero
-        (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 4, st);
+        if (last_chunk) (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 4, st);
         return;
     }
     const uint32_t per_wg = kSlice * (kBlock / 64);
-    uint32_t n_blocks = (uint32_t)((limit + per_wg - 1) / per_wg);
+    // workgroups for the records [est_lo, est_hi) — the whole limit by default; a chunk: the host's bounds on its range (the kernel
+    // counts its workgroups from the one that holds the chunk's REAL first record and reports a launch that falls short)
+    if (est_hi > limit) est_hi = limit;
+    if (est_lo > est_hi) est_lo = est_hi;
+    uint32_t n_blocks = (uint32_t)((est_hi + per_wg - 1) / per_wg - est_lo / per_wg);
+    if (!n_blocks) n_blocks = 1;
     uint32_t run = 16;                          // workgroups per XCD turn (profiles/r03/ab_emit2_xcd_turns.log)
     if (const char* v = debug_env("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
     n_blocks = (n_blocks + 8u * run - 1u) / (8u * run) * (8u * run);   // whole rounds of turns; surplus workgroups leave at once
+    const uint32_t n_slice_wg = n_blocks;
+    n_blocks += ((block_hi - block_lo) + 7u) & ~7u;              // in front of them: one workgroup per block of triangles (the fine blocks)
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
-                       (const float4*)setup, out, run);
+                       (const float4*)setup, out, run, block_lo, block_hi, rec_lo, last_chunk ? 1u : 0u, n_slice_wg, status);
 }
 
 // The multi-pass kernels keep a few spilled registers in scratch memory (12-32 bytes per lane), and the runtime sets a queue's scratch
