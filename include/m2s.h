@@ -384,9 +384,6 @@ enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
 /* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2), _LEAN (k_fused3) or _SPARSE (k_sparse); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);
-/* Into how many chunks of triangle blocks the last MULTI-PASS conversion was pipelined over two streams (2: the second chunk
- * was counted while the first was emitted; 1: one piece); 0 if the last conversion ran a single-pass kernel. */
-int m2s_last_chunks(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_FUSED = 4, M2S_K_N = 5 };

@@ -286,11 +286,6 @@ class Converter:
         return {0: "none", 1: "multipass", 2: "wave", 3: "team", 4: "sparse", 5: "lean"}[self._L.m2s_last_pipeline(self._h)]
 
     # -- measurement --------------------------------------------------------------------------------
-    @property
-    def last_chunks(self) -> int:
-        """chunks of the last multi-pass conversion (2: pipelined over two streams), 0 for a single-pass kernel"""
-        return int(self._L.m2s_last_chunks(self._h))
-
     def set_profiling(self, on: bool):
         self._check(self._L.m2s_set_profiling(self._h, 1 if on else 0))
 

@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <map>
 #include <string>
-#include <vector>
 
 namespace m2s_host {
 constexpr uint32_t kMaxGaussiansToSort = 7000000u;  // RenderPass.hpp:9
@@ -65,8 +64,6 @@ struct m2s_ctx {
         bool lean_off = false;     // k_fused3 overflowed its LDS stream or deferred many triangles at this R: use k_fused2
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
-        bool mp_planned = false;   // multi-pass: the chunk plan for this R has been made ...
-        uint32_t mp_cut = 0;       // ... chunks = blocks [0, mp_cut) and [mp_cut, end) of 256 triangles; 0: one chunk
         bool bands_ready = false;  // the run table of this R (slot band_slot of d_bands: where every run's output starts) is in place ...
         uint32_t bands_unit = 0;   // ... in units of this many triangles (256: recorded by a k_fused2 launch, 512: k_sparse)
         int band_slot = 0;
@@ -91,14 +88,7 @@ struct m2s_ctx {
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
     void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
-    // A multi-pass conversion pipelined in two chunks of triangle blocks (m2s_pass.cpp: enqueue_multipass): k_count_scan of the chunks
-    // on stream_cnt, k_emit2 on the conversion's stream, so that the second chunk is counted while the first is emitted.
-    hipStream_t stream_cnt = nullptr;
-    hipEvent_t ev_mp[3] = {};               // [0], [1]: k_count_scan of chunk 0 / 1 has finished; [2]: the conversion's stream has reached this conversion
-    unsigned long long* d_chunk_end = nullptr;   // where the records of chunk 0 end (chunk 1 ends at d_total)
-    std::vector<unsigned long long> block_prefix;   // fragments in front of every block of 256 triangles at warm_R (+ the total), from the upload's count
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
-    int last_chunks = 0;                    // ... and, multi-pass, in how many chunks (m2s_last_chunks)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
     // and record buffer, so that consecutive single-kernel conversions overlap (the tail of one, where the GPU drains,
     // with the head of the next) instead of paying ~8 us between dependent kernels on one stream

@@ -117,16 +117,10 @@ uint32_t count_scan_blocks(uint32_t n_tri);  // chain words k_count_scan uses
 size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array + the tall-triangle table behind it
 size_t setup_tall_offset(uint32_t n_tri);    // where that table's 16-byte header starts (zero when the buffer is allocated)
 // total_host (pinned, may be nullptr): the last workgroup also stores the fragment counter there
-// Both kernels work on the triangle blocks [block_lo, block_hi) of the scene (default: all of it) — one CHUNK of a conversion that
-// enqueue_multipass pipelines over two streams.  chunk_end (device; nullptr: `total`): where the chunk's records end, written by its
-// k_count_scan; launch_emit2's `total` = that word of ITS chunk, rec_lo = the previous chunk's (nullptr: record 0).
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
-                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st,
-                       uint32_t block_lo = 0, uint32_t block_hi = 0xFFFFFFFFu, unsigned long long* chunk_end = nullptr);
-// est_lo / est_hi: bounds on the chunk's record range that size the launch (default: [0, limit)); status[1] = 4 reports a launch that fell short
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st);
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
-                  uint64_t limit, const void* setup, float4* out, uint32_t* status, hipStream_t st, uint32_t block_lo = 0, uint32_t block_hi = 0xFFFFFFFFu,
-                  const unsigned long long* rec_lo = nullptr, bool last_chunk = true, uint64_t est_lo = 0, uint64_t est_hi = UINT64_MAX);
+                  uint64_t limit, const void* setup, float4* out, hipStream_t st);
 
 // device-side .ply row encoder, formats 1 and 2 (m2s_export.hip)
 void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float scale_multiplier, uint8_t* out, hipStream_t st);

@@ -31,9 +31,11 @@
 //                 one thread per triangle, the block's whole entry list in LDS, no inter-workgroup dependency because the offsets are
 //                 known — by extra workgroups of the SAME launch (emit_fine_block); the output-partitioned slices step over them
 //                 (one scalar load per block).  The pipeline choice has become a per-256-triangle decision taken on the device.
-//                 (Round 6 tried the obvious next step — the workgroup of k_count_scan that counted a fine block emits it, no TriSetup
-//                 round trip — and measured it slower: the count stage lasts as long as its slowest workgroup and k_emit2 lost the
-//                 workgroups that filled its tail; tag r6-fine-fold-in-count, profiles/r06/negative_fine_blocks_folded_into_k_count_scan.log.)
+//                 (Round 6 tried the two obvious next steps and measured both SLOWER, same bytes: the workgroup of k_count_scan that
+//                 counted a fine block emits it — the count stage lasts as long as its slowest workgroup and k_emit2 lost the
+//                 workgroups that filled its tail, tag r6-fine-fold-in-count —; and the conversion cut into two chunks of blocks,
+//                 count(B) beside emit(A) on a second stream — three cross-queue waits on the critical path of a 0.16 ms
+//                 conversion, tag r6-two-stream-chunks.  profiles/r06/negative_*.log.)
 // Output: bit-identical to every other pipeline (same device functions, same operation order).
 #include <cstdlib>
 #include "m2s_fused_common.h"
@@ -107,18 +109,12 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
                                                             unsigned long long* __restrict__ chain, uint32_t epoch,
                                                             unsigned long long* __restrict__ total_out,
                                                             float4* __restrict__ setup, uint32_t* __restrict__ status,
-                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */,
-                                                            uint32_t block_lo, unsigned long long* __restrict__ chunk_end) {
+                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */) {
     __shared__ uint32_t wsum[kCountBlock / 64];
     __shared__ uint32_t wtall[kCountBlock / 64];
     __shared__ unsigned long long base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // A launch covers the blocks [block_lo, block_lo + gridDim.x) of the scene: the whole scene, or one CHUNK of a conversion that is
-    // pipelined over two streams (m2s_pass.cpp: enqueue_multipass).  Chain words, offsets and classes are indexed by the block's
-    // number in the scene, so a later chunk's look-back simply continues in the words its predecessor left behind.
-    const uint32_t bid = block_lo + blockIdx.x;
-    const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
-    const uint32_t blockBase = bid * kCountBlock;
+    const uint32_t blockBase = blockIdx.x * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
     const bool valid = t < sc.n_tri;
     const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
@@ -192,14 +188,14 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         any_tall |= wtall[w];
     }
     // the block's class: who emits its fragments (see the file header)
-    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[bid] = (tot <= kFineMax && !any_tall) ? 1 : 0;
+    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[blockIdx.x] = (tot <= kFineMax && !any_tall) ? 1 : 0;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     // The workgroup's aggregate is published as soon as it is known — BEFORE the per-triangle setup records are computed and
     // stored: successors can resolve their bases while this workgroup is still busy, and this workgroup's own look-back
     // (below) finds its predecessors' words already in place.  (Setup first, then publish: k_count_scan 0.042 ms on the C4
     // stand-in; without any setup 0.027 ms, without the look-back 0.030 ms: the two used to add up on the critical path.)
     if (wave == 0 && lane == 0)
-        chain_store(&chain[bid], (bid == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+        chain_store(&chain[blockIdx.x], (blockIdx.x == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
     if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
         if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
@@ -218,13 +214,12 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     }
 
     if (wave == 0) {
-        const uint32_t b = bid;
+        const uint32_t b = blockIdx.x;
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
             base_s = base;
-            if (blockIdx.x == gridDim.x - 1) *chunk_end = base + tot;     // where this launch's records end (k_emit2 of the chunk reads it)
-            if (b == n_tb - 1) {
+            if (b == gridDim.x - 1) {
                 *total_out = base + tot;
                 // the counter the host waits for: written by the kernel itself (like the single-pass kernels), no copy behind the pipeline
                 if (total_host) __hip_atomic_store(total_host, base + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -238,9 +233,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
         const unsigned long long o1 = o0 + c;
         off[t] = (uint32_t)min(o0, 0xFFFFFFFFull);
-        // ... and the end of the launch's last triangle: k_emit2 of a chunk reads off[] up to and including its one-past-the-end
-        // triangle (the next chunk's first block stores the same value there, possibly at the same time)
-        if (t == min((block_lo + gridDim.x) * (uint32_t)kCountBlock, sc.n_tri) - 1u) off[t + 1] = (uint32_t)min(o1, 0xFFFFFFFFull);
+        if (t == sc.n_tri - 1) off[sc.n_tri] = (uint32_t)min(o1, 0xFFFFFFFFull);
     }
     // start[m] = the triangle that owns output record m * kSlice.  A triangle covering many slices (up to 32 768 for a
     // 4096 x 4096 px one) has the whole wave write them.
@@ -358,25 +351,18 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
                                                      const uint32_t* __restrict__ start,
                                                      const unsigned long long* __restrict__ total_p, unsigned long long limit,
                                                      const float4* __restrict__ setup, float4* __restrict__ out,
-                                                     uint32_t run /* consecutive workgroups per XCD turn */,
-                                                     uint32_t blk_lo, uint32_t blk_hi /* this launch emits the triangle blocks [blk_lo, blk_hi) ... */,
-                                                     const unsigned long long* __restrict__ rec_lo_p /* ... = the records [*rec_lo_p (nullptr: 0), */,
-                                                     uint32_t reset_tall /* *total_p): total_p = where k_count_scan of the chunk left its end */,
-                                                     uint32_t n_slice_wg /* workgroups of this launch behind the fine-block ones */,
-                                                     uint32_t* __restrict__ status /* pinned: [1] = 4 if they do not reach the chunk's end */) {
+                                                     uint32_t run /* consecutive workgroups per XCD turn */) {
     __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long total = *total_p;
-    const unsigned long long nw = total < limit ? total : limit;  // records actually stored (of the scene's blocks [0, blk_hi))
-    const unsigned long long rec_lo = rec_lo_p ? *rec_lo_p : 0ull;   // the first record of this launch's blocks
-    const uint32_t Tall = sc.n_tri;
-    const uint32_t T = min(blk_hi * (uint32_t)kCountBlock, Tall);    // one past the last triangle of this launch
-    const uint8_t* __restrict__ cls = block_class(setup, Tall);
+    const unsigned long long nw = total < limit ? total : limit;  // records actually stored
+    const uint32_t T = sc.n_tri;
+    const uint8_t* __restrict__ cls = block_class(setup, T);
     // the first workgroups of the launch (one per block of triangles, rounded up to whole groups of eight) take the FINE blocks
-    const uint32_t n_tb = blk_hi - blk_lo, n_fine_wg = (n_tb + 7u) & ~7u;
+    const uint32_t n_tb = (T + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock, n_fine_wg = (n_tb + 7u) & ~7u;
     if (blockIdx.x < n_fine_wg) {
-        if (blockIdx.x < n_tb && cls[blk_lo + blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blk_lo + blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
+        if (blockIdx.x < n_tb && cls[blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
         return;
     }
     const uint32_t bid = blockIdx.x - n_fine_wg;
@@ -388,28 +374,20 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
     // inter-workgroup dependency, so any mapping is correct.
     // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
-    // (the launch that emits the scene's last blocks: every k_count_scan of the conversion has finished)
-    if (reset_tall && bid == 0 && threadIdx.x == 0) tall_header(setup, Tall)[0] = 0;
+    if (bid == 0 && threadIdx.x == 0) tall_header(setup, T)[0] = 0;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
     const uint32_t xcd = bid & 7u, turn = (bid >> 3) / run, in_run = (bid >> 3) % run;
-    const uint32_t lblock = (uint32_t)(rec_lo / per_wg) + (turn * 8u + xcd) * run + in_run;   // (workgroups are counted from the one that holds record rec_lo)
-    // A chunk's launch is sized from the host's ESTIMATE of where the chunk's records lie (exact at the density the upload counted
-    // at); should the real range end beyond the last workgroup, say so: the host repeats the conversion in one piece.
-    if (bid == 0 && threadIdx.x == 0 && (unsigned long long)nblk > rec_lo / per_wg + n_slice_wg)
-        __hip_atomic_store(&status[1], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t lblock = (turn * 8u + xcd) * run + in_run;
     if (lblock >= nblk) return;
     const uint32_t slice = lblock * (kBlock / 64) + wave;
     const unsigned long long wbase64 = (unsigned long long)slice * kSlice;
-    if (wbase64 >= nw || wbase64 + kSlice <= rec_lo) return;
+    if (wbase64 >= nw) return;
     const uint32_t wbase = (uint32_t)wbase64;
     const uint32_t wend = (uint32_t)(nw - wbase64 < (unsigned long long)kSlice ? nw : wbase64 + kSlice);
 
-    // A slice that straddles the launch's first record belongs to two launches: the earlier one stopped at rec_lo (its nw), this one
-    // begins there, at the first triangle of its blocks.
-    const bool straddles = wbase64 < rec_lo;
-    uint32_t pos = straddles ? (uint32_t)rec_lo : wbase;                 // next record to produce
-    for (uint32_t t_cur = straddles ? blk_lo * (uint32_t)kCountBlock : start[slice]; pos < wend && t_cur < T; ) {
+    uint32_t pos = wbase;                 // next record to produce
+    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; ) {
         // ---- the batch: up to 64 consecutive triangles, one per lane.  A fine block is stepped over; a batch that would run from a
         // dense block into a fine one ends at the block boundary.  Everything the decision needs is requested at once (the classes of
         // this block and the next, the offsets at both possible ends, the lanes' own offsets): one round trip, as before round 5 ----
@@ -489,7 +467,7 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
                 // (running sums never decrease; a chunk without fragments shares its sum with the next one and is skipped)
                 const uint32_t rel = pos - acc;
                 const int nch = min((b.y1 - b.y0) / 64 + 1, (int)kTallChunks);
-                const uint32_t* row = tall_header(setup, Tall) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
+                const uint32_t* row = tall_header(setup, T) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
                 const uint32_t pre = lane < nch ? row[lane] : 0xFFFFFFFFu;
                 const unsigned long long le = __ballot(pre <= rel);
                 const int c0 = le ? 63 - __clzll((long long)le) : 0;
@@ -539,41 +517,27 @@ size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (siz
 size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
 
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
-                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st,
-                       uint32_t block_lo, uint32_t block_hi, unsigned long long* chunk_end) {
+                       uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st) {
     if (!sc.n_tri) return;
-    const uint32_t n_tb = count_scan_blocks(sc.n_tri);
-    if (block_hi > n_tb) block_hi = n_tb;
-    if (block_lo >= block_hi) return;
-    hipLaunchKernelGGL(k_count_scan, dim3(block_hi - block_lo), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
-                       epoch & 0xFFFFu, total, (float4*)setup, status, total_host, block_lo, chunk_end ? chunk_end : total);
+    hipLaunchKernelGGL(k_count_scan, dim3(count_scan_blocks(sc.n_tri)), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
+                       epoch & 0xFFFFu, total, (float4*)setup, status, total_host);
 }
 
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
-                  uint64_t limit, const void* setup, float4* out, uint32_t* status, hipStream_t st, uint32_t block_lo, uint32_t block_hi,
-                  const unsigned long long* rec_lo, bool last_chunk, uint64_t est_lo, uint64_t est_hi) {
+                  uint64_t limit, const void* setup, float4* out, hipStream_t st) {
     if (!sc.n_tri) return;
-    const uint32_t n_tb = count_scan_blocks(sc.n_tri);
-    if (block_hi > n_tb) block_hi = n_tb;
-    if (block_lo >= block_hi) return;
     if (!limit) {   // a counting-only conversion: nothing to emit, but the tall-triangle table's slot counter still goes back to zero
-        if (last_chunk) (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 4, st);
+        (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 4, st);
         return;
     }
     const uint32_t per_wg = kSlice * (kBlock / 64);
-    // workgroups for the records [est_lo, est_hi) — the whole limit by default; a chunk: the host's bounds on its range (the kernel
-    // counts its workgroups from the one that holds the chunk's REAL first record and reports a launch that falls short)
-    if (est_hi > limit) est_hi = limit;
-    if (est_lo > est_hi) est_lo = est_hi;
-    uint32_t n_blocks = (uint32_t)((est_hi + per_wg - 1) / per_wg - est_lo / per_wg);
-    if (!n_blocks) n_blocks = 1;
+    uint32_t n_blocks = (uint32_t)((limit + per_wg - 1) / per_wg);
     uint32_t run = 16;                          // workgroups per XCD turn (profiles/r03/ab_emit2_xcd_turns.log)
     if (const char* v = debug_env("M2S_EMIT2_RUN")) { const unsigned long r = strtoul(v, nullptr, 10); if (r >= 1 && r <= 65536) run = (uint32_t)r; }   // debug
     n_blocks = (n_blocks + 8u * run - 1u) / (8u * run) * (8u * run);   // whole rounds of turns; surplus workgroups leave at once
-    const uint32_t n_slice_wg = n_blocks;
-    n_blocks += ((block_hi - block_lo) + 7u) & ~7u;              // in front of them: one workgroup per block of triangles (the fine blocks)
+    n_blocks += (count_scan_blocks(sc.n_tri) + 7u) & ~7u;              // in front of them: one workgroup per block of triangles (the fine blocks)
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
-                       (const float4*)setup, out, run, block_lo, block_hi, rec_lo, last_chunk ? 1u : 0u, n_slice_wg, status);
+                       (const float4*)setup, out, run);
 }
 
 // The multi-pass kernels keep a few spilled registers in scratch memory (12-32 bytes per lane), and the runtime sets a queue's scratch

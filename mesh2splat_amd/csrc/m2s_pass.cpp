@@ -184,25 +184,6 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total, R);
     const uint64_t cap = resolve_cap(c, R);
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
-    // multi-pass scenes: where the fragments are, block of 256 triangles by block — what plan_chunks cuts the conversion by
-    c->block_prefix.clear();
-    if (!single && !multipass_v1() && !debug_on("M2S_NO_CHUNKS")) {
-        const uint32_t n_tb = count_scan_blocks(sc.n_tri);
-        if (n_tb >= 16u && n_tb <= (1u << 18)) {
-            unsigned long long* tmp = nullptr;
-            if (hipMalloc((void**)&tmp, (size_t)n_tb * sizeof(unsigned long long)) == hipSuccess) {
-                launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, 256u, 0u, tmp, st);
-                try {
-                    c->block_prefix.resize((size_t)n_tb + 1);
-                    if (hipMemcpyAsync(c->block_prefix.data(), tmp, (size_t)n_tb * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                        hipStreamSynchronize(st) != hipSuccess) c->block_prefix.clear();
-                    else c->block_prefix[n_tb] = total;
-                } catch (...) { c->block_prefix.clear(); }
-                (void)hipFree(tmp);
-            }
-            (void)hipGetLastError();
-        }
-    }
     // the code object of the pipeline this scene is about to run: loaded here, not inside the first conversion of the process
     if (!debug_on("M2S_NO_PRELOAD")) {
         if (!single) { (void)preload_multipass(); if (!debug_on("M2S_NO_SCRATCH_WARM")) launch_scratch_warm(st); }
@@ -267,46 +248,6 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
     return M2S_OK;
 }
 
-// ---- one multi-pass conversion as a two-stage pipeline over two streams ---------------------------------------------------------
-// k_emit2 cannot start before k_count_scan has finished, and k_count_scan is ONE generation of latency-bound workgroups: 20-30 % of
-// every multi-pass conversion during which the memory system idles (heterogeneous scene: count 0.050 + emit 0.109 ms; two LANES
-// hide it across conversions — 0.114 ms per step — but the reference's call is one blocking conversion).  Cut the scene's blocks of
-// 256 triangles into two chunks A | B:    stream_cnt:  count(A)  count(B)
-//                                         stream:          wait A -> emit(A)   wait B -> emit(B)
-// count(B) runs beside emit(A); what stays exposed is count(A), and A is chosen small.  Nothing else changes: chain words, offsets,
-// TriSetup records and classes are indexed by block, so chunk B's look-back continues where A's ended, and the records come out in
-// the same canonical order at the same addresses (same bytes: the fuzz runs both ways).
-// Where to cut: from the upload's exact count (block_prefix; fragments scale with R^2 everywhere alike, so the cut serves every
-// density) and a three-constant cost model fitted to the measurements of profiles/r06 — count(n blocks) = 0.016 + 0.000033 n ms,
-// emit(f fragments) = 0.004 + 2.45e-8 f ms, 0.010 ms for the extra launches and the two cross-stream waits.
-static uint32_t plan_chunks(const m2s_ctx* c, uint32_t R) {
-    const size_t n_tb = c->block_prefix.size() ? c->block_prefix.size() - 1 : 0;
-    if (n_tb < 16 || !c->warm_R || debug_on("M2S_NO_CHUNKS")) return 0u;
-    if (const char* v = debug_env("M2S_CHUNK_CUT")) return (uint32_t)std::min<unsigned long>(strtoul(v, nullptr, 10), (unsigned long)n_tb - 1);   // debug: A/B
-    const double scale = ((double)R * (double)R) / ((double)c->warm_R * (double)c->warm_R);
-    const uint64_t cap = resolve_cap(c, R);
-    auto frags = [&](size_t b) { double f = (double)c->block_prefix[b] * scale; return cap ? std::min(f, (double)cap) : f; };
-    auto count_ms = [](double blocks) { return 0.016 + 0.000033 * blocks; };
-    auto emit_ms = [](double f) { return 0.004 + 2.45e-8 * f; };
-    const double F = frags(n_tb);
-    const double whole = count_ms((double)n_tb) + 0.006 + emit_ms(F);
-    double best = whole - 0.004;     // (a chunked conversion must be expected to win by more than the noise)
-    uint32_t cut = 0;
-    for (size_t x = 8; x + 8 <= n_tb; x += 8) {      // cuts at multiples of eight blocks
-        const double fa = frags(x);
-        const double t = count_ms((double)x) + std::max(emit_ms(fa), count_ms((double)(n_tb - x))) + emit_ms(F - fa) + 0.010;
-        if (t < best) { best = t; cut = (uint32_t)x; }
-    }
-    return cut;
-}
-
-static m2s_status ensure_chunk_objects(m2s_ctx* c) {
-    if (!c->stream_cnt) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_cnt, hipStreamNonBlocking));
-    for (auto& ev : c->ev_mp) if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (!c->d_chunk_end) HIPCHK(c, hipMalloc((void**)&c->d_chunk_end, sizeof(unsigned long long)));
-    return M2S_OK;
-}
-
 namespace m2s_host {
 // The second lane of asynchronous submissions (m2s_set_async_lanes(2)): its stream, its look-back chain and its record buffer,
 // allocated at its first use.  A record buffer that has become too small is replaced after every conversion still writing it has finished.
@@ -358,13 +299,12 @@ m2s_status ensure_second_lane_multipass(m2s_ctx* c, uint32_t n_start) {
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                                     unsigned long long* h_res, hipStream_t st, bool second_lane) {
     const SceneDev& sc = c->scene;
-    c->last_chunks = 1;
     if (second_lane) {   // the second lane's own work buffers (ensure_second_lane_multipass); second generation only
         uint32_t epoch;
         HIPCHK(c, next_epoch(c, &epoch));
         launch_count_scan(sc, R, c->d_off_b, c->d_start_b, emit2_slices(limit), c->d_chain_b, epoch, c->d_total_b, c->d_setup_b,
                           reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
-        launch_emit2(sc, R, c->d_off_b, c->d_start_b, c->d_total_b, limit, c->d_setup_b, d_out, reinterpret_cast<uint32_t*>(&h_res[1]), st);
+        launch_emit2(sc, R, c->d_off_b, c->d_start_b, c->d_total_b, limit, c->d_setup_b, d_out, st);
         HIPCHK(c, hipGetLastError());
         return M2S_OK;
     }
@@ -382,45 +322,12 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
     } else {
         uint32_t epoch;
         HIPCHK(c, next_epoch(c, &epoch));
-        m2s_ctx::RInfo& ri = rinfo_for(c, R);
-        if (!ri.mp_planned) { ri.mp_planned = true; ri.mp_cut = limit ? plan_chunks(c, R) : 0u; }
-        const uint32_t cut = (ri.mp_cut && ri.mp_cut < count_scan_blocks(sc.n_tri) && limit && ensure_chunk_objects(c) == M2S_OK) ? ri.mp_cut : 0u;
-        uint32_t* const status = reinterpret_cast<uint32_t*>(&h_res[1]);
-        c->last_chunks = cut ? 2 : 1;
-        if (!cut) {
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-            launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup, status, &h_res[0], st);
-            if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
-            launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, status, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-        } else {
-            // bounds on the chunks' record ranges (sizes of the two k_emit2 launches): exact at the density the upload counted at,
-            // else the R^2-scaled counts with 4 % + 8192 records of room; a launch that falls short reports it (run_multipass repeats)
-            const double scale = ((double)R * (double)R) / ((double)c->warm_R * (double)c->warm_R);
-            const double ea = (double)c->block_prefix[cut] * scale, et = (double)c->block_prefix.back() * scale;
-            const bool exact = R == c->warm_R;
-            const uint64_t a_hi = (uint64_t)(exact ? ea : ea * 1.04) + (exact ? 0u : 8192u) + 1u;
-            const uint64_t a_lo = exact ? (uint64_t)ea : (uint64_t)std::max(0.0, ea * 0.96 - 8192.0);
-            const uint64_t t_hi = (uint64_t)(exact ? et : et * 1.04) + (exact ? 0u : 8192u) + 1u;
-            // two chunks, two streams (see plan_chunks).  The counting stream may not touch the work buffers before whatever is in
-            // front of this conversion on ITS stream (an earlier conversion's k_emit2 reading them) has finished.
-            hipStream_t sc_ = c->stream_cnt;
-            HIPCHK(c, hipEventRecord(c->ev_mp[2], st));
-            HIPCHK(c, hipStreamWaitEvent(sc_, c->ev_mp[2], 0));
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], sc_));
-            launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup, status, &h_res[0], sc_,
-                              0u, cut, c->d_chunk_end);
-            HIPCHK(c, hipEventRecord(c->ev_mp[0], sc_));
-            if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], sc_)); HIPCHK(c, hipEventRecord(c->ev[3], sc_)); }   // "count" = the exposed one; "emit" = everything after it
-            launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup, status, &h_res[0], sc_,
-                              cut, 0xFFFFFFFFu, c->d_total);
-            HIPCHK(c, hipEventRecord(c->ev_mp[1], sc_));
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_mp[0], 0));
-            launch_emit2(sc, R, c->d_off, c->d_start, c->d_chunk_end, limit, c->d_setup, d_out, status, st, 0u, cut, nullptr, false, 0u, a_hi);
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_mp[1], 0));
-            launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, status, st, cut, 0xFFFFFFFFu, c->d_chunk_end, true, a_lo, t_hi);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-        }
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
+                          reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
+        if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
+        launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
     }
     HIPCHK(c, hipGetLastError());
     // (second generation: k_count_scan's last workgroup has written the counter to *h_res itself — no copy behind the pipeline)
@@ -435,15 +342,6 @@ static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t 
     c->h_total[0] = 0; c->h_total[1] = 0;
     { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
     HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
-    if ((c->h_total[1] >> 32) == 4ull) {
-        // a chunk's k_emit2 was sized from a prediction that fell short (a density the upload did not count at): once more, in one piece
-        m2s_ctx::RInfo& ri = rinfo_for(c, R);
-        ri.mp_planned = true; ri.mp_cut = 0;
-        if (debug_on("M2S_DEBUG")) fprintf(stderr, "[m2s] chunked multi-pass conversion at R = %u: a launch fell short of its chunk; repeated in one piece\n", R);
-        c->h_total[0] = 0; c->h_total[1] = 0;
-        { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
-        HIPCHK(c, wait_stream(st));
-    }
     if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
     if (prof) {
         if (multipass_v1()) { for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
