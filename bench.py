@@ -80,6 +80,14 @@ def parse():
                     help="tests: every rank on device 0 (several processes share one GPU; needs an RCCL stand-in that allows it: M2S_RCCL_PATH)")
     ap.add_argument("--pipeline", default=None, choices=["auto", "multipass", "wave", "team", "sparse", "lean"],
                     help="A/B: force a pipeline setting for the headline workload (default: the library's AUTO)")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="repetitions of the timed region (each: EXACTLY --steps conversions between barrier + synchronize); ms_per_step / value "
+                         "are the MEDIAN repetition, all of them are in ms_per_step_reps.  Default: 5 when --steps < 100 (a 2.3 ms window "
+                         "must not decide the headline), else 1")
+    ap.add_argument("--bringup-timeout", type=float, default=100.0, help="N > 1: seconds the ranks get to meet and create the communicator; "
+                    "then every rank leaves non-zero and rank 0 prints scale_record with the error text")
+    ap.add_argument("--headline-timeout", type=float, default=240.0, help="N > 1: seconds for the weak-scaling headline after the bring-up")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end leg (the command line: load + upload + convert + export)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL init, convert_into, counter all-gather) even with 1 rank")
     return ap.parse_args()
@@ -255,20 +263,24 @@ def viewer_extra(conv, R, total):
 def self_launch(a) -> int:
     """`python bench.py --gpus N` typed by hand: start N ranks ourselves, one per GPU — plain processes with the launcher
     environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT); the ranks meet through mesh2splat_amd/ctl.py."""
+    import shutil
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]      # (only names the rendezvous directory)
+    port = s.getsockname()[1]
     s.close()
+    rdzv = tempfile.mkdtemp(prefix="m2s_rdzv_")      # a private (0700) directory of this launch: where its ranks meet (ctl.py)
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M2S_RDZV_DIR=rdzv)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p_ in procs:
         rc = p_.wait() or rc
+    shutil.rmtree(rdzv, ignore_errors=True)
     return rc
 
 
@@ -381,7 +393,7 @@ class Rig:
         self.conv.close()
 
 
-def timed_loop(torch, ctl, multi, rig, steps, warmup, sync_steps=False):
+def timed_loop(torch, ctl, multi, rig, steps, warmup, sync_steps=False, reset=True):
     """warmup, barrier + sync, `steps` conversions, barrier + sync; returns (seconds (max over ranks), last counter)"""
     def sync():
         torch.cuda.synchronize()
@@ -391,7 +403,8 @@ def timed_loop(torch, ctl, multi, rig, steps, warmup, sync_steps=False):
     if warmup:
         rig.run(warmup, sync_steps=sync_steps)
         rig.drain_counts()
-    rig.reset_kms()
+    if reset:
+        rig.reset_kms()
     sync()
     t0 = time.perf_counter()
     total = rig.run(steps, timed=True, sync_steps=sync_steps)
@@ -618,6 +631,46 @@ def c5_workload(torch, local_rank, steps=8):
     return res
 
 
+def end_to_end(scene_one_mesh, R):
+    """SURVEY 8d's second metric, "end-to-end ms/mesh (load + convert + write)": the headless command line (tools/mesh2splat_cli.cpp ==
+    the reference's load -> ConversionPass::execute -> exportPly, SceneManager.cpp:195-459, ConversionPass.cpp:9-68, parsers.cpp:431-514)
+    on the headline scene written as a .glb with PNG maps; export formats 0 (the reference's 248-byte rows) and 1.  Best of two
+    processes per format; every process pays the HIP runtime's start (on a second thread, overlapped with the .glb parse)."""
+    import re
+    import subprocess
+    import tempfile
+    from mesh2splat_amd import gltf_io
+    cli = os.path.join(ROOT, "mesh2splat_amd", "_build", "mesh2splat")
+    if not os.path.exists(cli):
+        return {"error": "mesh2splat_amd/_build/mesh2splat is not built"}
+    out = {"what": "mesh2splat <in.glb> <out.ply> --density R --format f --timing: wall clock of the stages inside the process, ms",
+           "R": int(R)}
+    pat = re.compile(r"load ([\d.]+) ms \(HIP runtime \+ context ([\d.]+) ms, on a second thread; waited ([\d.]+) ms for it\) \| upload ([\d.]+) ms "
+                     r"\(geometry ([\d.]+), textures ([\d.]+), allocations ([\d.]+)\) \| convert ([\d.]+) ms.*\| export ([\d.]+) ms \| total ([\d.]+) ms")
+    with tempfile.TemporaryDirectory() as tmp:
+        glb = os.path.join(tmp, "scene.glb")
+        gltf_io.write_glb(scene_one_mesh, glb)
+        out["glb_bytes"] = os.path.getsize(glb)
+        for fmt in (0, 1):
+            ply = os.path.join(tmp, "out%d.ply" % fmt)
+            best = None
+            for _ in range(2):
+                w0 = time.perf_counter()
+                r = subprocess.run([cli, glb, ply, "--density", str(int(R)), "--format", str(fmt), "--timing"], capture_output=True, text=True, timeout=600)
+                wall = (time.perf_counter() - w0) * 1e3
+                m = pat.search(r.stdout) if r.returncode == 0 else None
+                if m is None:
+                    return {"error": (r.stderr or r.stdout)[-400:]}
+                t = dict(zip(("load_ms", "hip_init_ms_overlapped", "waited_for_init_ms", "upload_ms", "upload_geometry_ms", "upload_textures_ms",
+                              "upload_alloc_ms", "convert_first_call_ms", "export_ms", "total_ms"), map(float, m.groups())))
+                t["wall_ms_whole_process"] = wall
+                if best is None or t["total_ms"] < best["total_ms"]:
+                    best = t
+            best["ply_bytes"] = os.path.getsize(ply)
+            out["format%d" % fmt] = best
+    return out
+
+
 class stdout_to_stderr:
     """gloo and librccl announce themselves on C stdout; the driver reads ONE JSON line from this process's stdout.  While the
     process group / the communicator come up, file descriptor 1 points at stderr."""
@@ -662,14 +715,51 @@ def main():
     exchange = None
     phases = {}          # multi-GPU: how long each bring-up step took on this rank, and every error met on the way (-> the JSON line)
     dist_errors = []
-    ctl = Ctl(rank, world)
+    import threading
+    from mesh2splat_amd.ctl import RendezvousTimeout
+
+    def leave(phase, text, code=3):
+        """A multi-rank phase did not complete: say so in the shape of the record the run was started for, and leave non-zero.
+        Rank 0 prints it on stdout (the line a driver reads) and stderr; the other ranks on stderr."""
+        rec = {"error": f"{phase}: {text}", "n_gpus": world, "value": None, "exchange_transport": getattr(exchange, "transport", None),
+               "scale_record": {"rccl_ranks": getattr(exchange, "world", None), "error": f"{phase}: {text}", "phase": phase, "rank": rank,
+                                "errors": dist_errors, "dry_scale": bool(a.dry_scale)},
+               "multi_gpu_bringup": phases}
+        line = json.dumps(rec)
+        print(line, file=sys.stderr, flush=True)
+        if rank == 0:
+            print(line, flush=True)
+        os._exit(code)
+
+    class TimeBox:
+        """every N > 1 phase runs under one: a hang in a collective becomes a record with the phase's name after `seconds`"""
+        def __init__(self, phase, seconds):
+            self.t = threading.Timer(seconds, lambda: leave(phase, f"no progress after {seconds:.0f} s (time box)", 4)) if world > 1 or a.force_dist else None
+            if self.t:
+                self.t.daemon = True
+                self.t.start()
+
+        def done(self):
+            if self.t:
+                self.t.cancel()
+
+    try:
+        ctl = Ctl(rank, world, timeout=a.bringup_timeout)
+    except RendezvousTimeout as e:
+        leave("rendezvous", str(e))
     if multi:
+        box = TimeBox("bring-up (rendezvous + m2s_dist_create + first exchange)", a.bringup_timeout + 10.0)
+        if ctl.rdzv is not None:
+            ctl.rdzv.set_deadline(a.bringup_timeout)
         os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's own account of a failure goes to stderr
         # ONE user of RCCL per process — the C-ABI communicator (m2s_dist_*), which carries the data path — and ONE rendezvous: the
         # ranks meet in a directory (mesh2splat_amd/ctl.py) for the 128-byte id and the agreement that every rank has a communicator;
         # from then on the barriers and reductions of this run are 8-byte all-gathers of that communicator.
         t_pg = time.perf_counter()
-        ctl.barrier()
+        try:
+            ctl.barrier()
+        except RendezvousTimeout as e:
+            leave("rendezvous", str(e))
         phases["control_plane"] = "directory rendezvous (mesh2splat_amd/ctl.py) until m2s_dist_create, then the communicator's own 8-byte all-gather"
         phases["control_plane_init_s"] = time.perf_counter() - t_pg
 
@@ -685,7 +775,10 @@ def main():
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
                 dist_errors.append(f"rank 0: m2s_dist_unique_id: {e!r}")
                 payload = b"\x00"
-        payload = ctl.broadcast_bytes("rccl_id", payload)
+        try:
+            payload = ctl.broadcast_bytes("rccl_id", payload)
+        except RendezvousTimeout as e:
+            leave("rendezvous (RCCL id)", str(e))
         exchange, ok = None, 0
         if payload[:1] == b"\x01":
             ident = bytes(payload[1:129])
@@ -703,18 +796,22 @@ def main():
                 print(f"[rank {rank}] C-ABI RCCL exchange unavailable: {e!r}", file=sys.stderr, flush=True)
                 dist_errors.append(f"rank {rank}: m2s_dist_create: {e!r}")
                 exchange, ok = None, 0
-        reports = ctl.gather_obj("comm_ok", {"ok": ok, "errors": dist_errors})
+        try:
+            reports = ctl.gather_obj("comm_ok", {"ok": ok, "errors": dist_errors})
+        except RendezvousTimeout as e:
+            leave("rendezvous (did every rank get a communicator?)", str(e))
         if min(r_["ok"] for r_ in reports) == 0:
             # NO fallback: the exchange under test is the product's (m2s_dist_* behind the C ABI: RCCL).  A run whose ranks cannot
             # create that communicator must not report a number measured on something else: every rank leaves, rank 0 says why.
             if exchange is not None:
                 exchange.close()
-            if rank == 0:
-                print(json.dumps({"error": "the C-ABI communicator (m2s_dist_create) could not be created on every rank; no measurement was taken",
-                                  "n_gpus": world, "exchange_transport": None, "errors": [e for r_ in reports for e in r_["errors"]],
-                                  "multi_gpu_bringup": phases}), file=sys.stderr, flush=True)
-            ctl.close()
-            raise SystemExit(3)
+            dist_errors[:] = [e for r_ in reports for e in r_["errors"]]
+            exchange = None
+            try:
+                ctl.close()
+            except Exception:  # noqa: BLE001
+                pass
+            leave("m2s_dist_create", "the C-ABI communicator could not be created on every rank; no measurement was taken")
         ctl.use(exchange)
         if exchange is not None:           # the first exchange of all: 8 bytes per rank, timed on its own
             t_x = time.perf_counter()
@@ -729,6 +826,9 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
+        if ctl.rdzv is not None:
+            ctl.rdzv.set_deadline(None)
+        box.done()
 
     n, tex, R = WORKLOADS[a.workload]
     if n in ("grid", "sponza_like"):
@@ -746,11 +846,21 @@ def main():
     rig = Rig(torch, local_rank, scene, R, tri_range=(rank * tri_per_mesh, tri_per_mesh), cap=0 if multi else -1,
               out_rows=0 if multi else None, exchange=exchange, pipeline=a.pipeline)
     T_local = rig.conv.num_triangles
-    dt, total = timed_loop(torch, ctl, multi, rig, a.steps, a.warmup, sync_steps=a.sync_steps)
+    box = TimeBox("weak-scaling headline (timed loop + counter exchange)", a.headline_timeout)
+    # The timed region: W warm-up steps, then EXACTLY K steps between barrier + synchronize, max over ranks — repeated `reps` times
+    # (warm-up only in front of the first); the line's ms_per_step / value are those of the MEDIAN repetition.
+    reps = a.reps if a.reps > 0 else (5 if a.steps < 100 else 1)
+    rep_dt = []
+    for i in range(reps):
+        dt_i, total = timed_loop(torch, ctl, multi, rig, a.steps, a.warmup if i == 0 else 0, sync_steps=a.sync_steps, reset=(i == 0))
+        rep_dt.append(dt_i)
+    dt = sorted(rep_dt)[len(rep_dt) // 2]
     per_rank_total = ctl.gather_u64(total) if multi else [int(total)]
+    box.done()
     n_all = int(sum(per_rank_total))
     ms_per_step = dt / a.steps * 1e3
     value = n_all / (dt / a.steps)
+    rep_ms = [d / a.steps * 1e3 for d in rep_dt]
     kms = rig.kernel_ms()
     n_prof = rig.n_prof
     last_pipeline = rig.conv.last_pipeline
@@ -811,7 +921,10 @@ def main():
             "metric": "Gaussians/sec emitted (mesh->3DGS conversion pass, density 1024^2)" if R == 1024 else
                       f"Gaussians/sec emitted (mesh->3DGS conversion pass, density {R}^2)",
             "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "ms_per_mesh": ms_per_step,
+            "ms_per_step_reps": {"reps": reps, "all": rep_ms, "min": min(rep_ms), "max": max(rep_ms), "median": ms_per_step,
+                                 "what": f"{reps} repetition(s) of the timed region, each exactly {a.steps} steps; ms_per_step and value are the median repetition's"},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "exchange_transport": exchange.transport if multi else "none (single GPU: no exchange)",
             "config": {"workload": (f"synth.sponza_like: 64 meshes, {tri_per_mesh} triangles of 0.1 ... 500 000 px, maps of 256^2 ... 2048^2, R={R}") if n == "sponza_like" else
@@ -828,7 +941,7 @@ def main():
                                      "pipelined 2 deep (m2s_convert_submit/wait): every conversion completes and its counter is read back in the timed region"},
             "sync_ms_per_step": sync_ms, "sync_ms_stats": sync_stats, "overlapped": overlapped, "viewer_passes": viewer,
             "kernel_ms": kms,
-            "kernel_timing": f"HIP events on the launch stream around every 4th launch of the timed region ({n_prof} launches)",
+            "kernel_timing": f"HIP events on the launch stream around every 4th launch of the timed region(s) ({n_prof} launches)",
             "kernel_ms_dedicated": {"what": "64 blocking launches after the timed region, HIP events on every one", **dedicated},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "kernel": kname,
@@ -868,6 +981,13 @@ def main():
                                "ms_per_step": ms_per_step, "exchange_ms": xch_ms,
                                "bringup_ms": (phases.get("control_plane_init_s", 0.0) + phases.get("rccl_comm_init_s", 0.0)) * 1e3,
                                "transport": exchange.transport, "dry_scale": bool(a.dry_scale),
+                               # what the record exchange (`gather`, below) cannot beat on xGMI (MI355X_MICROARCH.md: 7 links x ~153 GB/s per
+                               # GPU, point to point): every rank receives the other ranks' blocks, each over the one link to that peer
+                               "gather_link_floor_ms": {
+                                   "all_7_links": (world - 1) / max(world, 1) * 96.0 * n_all / (7 * 153e9) * 1e3,
+                                   "links_in_use": (96.0 * max(per_rank_total) / 153e9 * 1e3) if world > 1 else 0.0,
+                                   "what": "all_7_links: (N-1)/N x 96 B x N_total / (7 x 153 GB/s); links_in_use: the largest block over ONE link "
+                                           "(a rank has N-1 peers, one link each: with N < 8 only N-1 links carry data)"},
                                "what": "exchange_ms: one blocking 8-byte counter all-gather; bringup_ms: rendezvous + m2s_dist_create (ncclCommInitRank)"}
         res["dry_scale"] = bool(a.dry_scale)
         res["multi_gpu_bringup"] = {**phases, "exchange": getattr(exchange, "transport", None), "errors": dist_errors,
@@ -1055,6 +1175,11 @@ def main():
                 if rf.get(key) is not None:
                     wl[name_] = rf[key]
             rf["workloads"] = wl
+            if not a.no_end_to_end:
+                try:
+                    res["end_to_end_ms"] = end_to_end(one, R)
+                except Exception as e:  # noqa: BLE001
+                    res["end_to_end_ms"] = {"error": str(e)}
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(one, R, a.cpu_seconds, gpu_total=total)
         print(json.dumps(res), flush=True)

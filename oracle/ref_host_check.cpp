@@ -12,6 +12,8 @@
 //                                                     stb_image_write) — a writer that shares no code and no author with this
 //                                                     repository's mesh2splat_amd/gltf_io.py, whose files the loader tests
 //                                                     otherwise read
+//   ref_host_check glbwrite2 spec2.bin out.glb        the same with shared images / materials, several primitives in one mesh, JPEG
+//                                                     images, an occlusion map: files shaped like SciFiHelmet.glb / Sponza.glb
 //
 // The reference uploads its vertex vector with glBufferData and its textures with glTexImage2D; there is
 // no GL on this machine, so the nine GLEW entry points that translation unit touches are defined HERE as
@@ -240,6 +242,128 @@ static int do_glbwrite(const char* in, const char* out) {
     return 0;
 }
 
+
+// ---- glbwrite2: the same authoring path for files SHAPED like the assets BASELINE configs 2 and 4 name ----------
+// What glbwrite cannot express: images and materials SHARED between primitives (Sponza: ~100 primitives on ~25 materials), several
+// primitives in ONE mesh under ONE node, JPEG-encoded images (stb_image_write through tiny_gltf's writer, as for PNG), a fourth
+// (occlusion) texture that the reference ignores, indexed geometry with real vertex reuse.
+// spec2.bin (little endian): u32 flags (2: one interleaved vertex view with byteStride per primitive; 64: separate views that state
+// byteStride = element size; 32: all primitives in one mesh
+// under one node, whose TRS is the FIRST primitive's); u32 n_images, each: u32 w, h, jpeg (0 / 1), u8 rgba[4 w h]; u32 n_materials,
+// each: str name, f32 baseColorFactor[4], i32 image of {base colour, normal, metallic-roughness, occlusion} (-1: none); u32
+// n_primitives, each: str name, u32 n_vertices, f32 position[3 n], normal[3 n], tangent[4 n], uv[2 n], u32 n_indices (0: not
+// indexed), u32 index[], u32 material, f32 translation[3], rotation[4] (x y z w), scale[3].
+static int do_glbwrite2(const char* in, const char* out) {
+    SpecReader r;
+    { std::ifstream f(in, std::ios::binary); r.b.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()); }
+    const uint32_t flags = r.u32();
+    tinygltf::Model m;
+    m.asset.version = "2.0";
+    m.asset.generator = "tiny_gltf (the reference's copy), driven by oracle/ref_host_check glbwrite2";
+    m.buffers.emplace_back();
+    const uint32_t n_images = r.u32();
+    for (uint32_t k = 0; k < n_images && r.ok; ++k) {
+        const uint32_t w = r.u32(), h = r.u32(), jpeg = r.u32();
+        tinygltf::Image img;
+        img.width = (int)w; img.height = (int)h; img.component = 4; img.bits = 8; img.pixel_type = TINYGLTF_COMPONENT_TYPE_UNSIGNED_BYTE;
+        img.image = r.arr<unsigned char>((size_t)w * h * 4);
+        img.mimeType = jpeg ? "image/jpeg" : "image/png";
+        img.name = "image_" + std::to_string(k);
+        m.images.push_back(img);
+        tinygltf::Texture tex;
+        tex.source = (int)k;
+        m.textures.push_back(tex);
+    }
+    const uint32_t n_materials = r.u32();
+    for (uint32_t k = 0; k < n_materials && r.ok; ++k) {
+        tinygltf::Material mat;
+        mat.name = r.str();
+        float color[4];
+        r.get(color, 16);
+        mat.pbrMetallicRoughness.baseColorFactor.assign(color, color + 4);
+        int32_t t[4];
+        r.get(t, 16);
+        if (t[0] >= 0) mat.pbrMetallicRoughness.baseColorTexture.index = t[0];
+        if (t[1] >= 0) mat.normalTexture.index = t[1];
+        if (t[2] >= 0) mat.pbrMetallicRoughness.metallicRoughnessTexture.index = t[2];
+        if (t[3] >= 0) mat.occlusionTexture.index = t[3];
+        m.materials.push_back(mat);
+    }
+    const uint32_t n_prims = r.u32();
+    tinygltf::Scene scene;
+    tinygltf::Mesh one_mesh;
+    one_mesh.name = "mesh";
+    tinygltf::Node one_node;
+    one_node.name = "node";
+    for (uint32_t k = 0; k < n_prims && r.ok; ++k) {
+        const std::string name = r.str();
+        const uint32_t nv = r.u32();
+        const auto pos = r.arr<float>(3 * (size_t)nv), nrm = r.arr<float>(3 * (size_t)nv), tan = r.arr<float>(4 * (size_t)nv), uv = r.arr<float>(2 * (size_t)nv);
+        const uint32_t ni = r.u32();
+        const auto idx = r.arr<uint32_t>(ni);
+        const uint32_t material = r.u32();
+        float T[3], Rq[4], S[3];
+        r.get(T, 12); r.get(Rq, 16); r.get(S, 12);
+        if (!r.ok) break;
+        float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+        for (uint32_t i = 0; i < nv; ++i) for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], pos[3 * i + c]); mx[c] = std::max(mx[c], pos[3 * i + c]); }
+        tinygltf::Primitive prim;
+        prim.mode = TINYGLTF_MODE_TRIANGLES;
+        if (flags & 2u) {
+            std::vector<float> inter((size_t)nv * 12);
+            for (uint32_t i = 0; i < nv; ++i) {
+                memcpy(&inter[(size_t)i * 12 + 0], &pos[3 * i], 12); memcpy(&inter[(size_t)i * 12 + 3], &nrm[3 * i], 12);
+                memcpy(&inter[(size_t)i * 12 + 6], &tan[4 * i], 16); memcpy(&inter[(size_t)i * 12 + 10], &uv[2 * i], 8);
+            }
+            const int v = add_view(m, inter.data(), inter.size() * 4, TINYGLTF_TARGET_ARRAY_BUFFER, 48);
+            prim.attributes["POSITION"] = add_accessor(m, v, 0, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC3, nv, mn, mx);
+            prim.attributes["NORMAL"] = add_accessor(m, v, 12, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC3, nv);
+            prim.attributes["TANGENT"] = add_accessor(m, v, 24, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC4, nv);
+            prim.attributes["TEXCOORD_0"] = add_accessor(m, v, 40, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC2, nv);
+        } else {
+            // (64: the views say byteStride = element size, as the exporters of the Khronos sample assets write it)
+            const size_t s3 = (flags & 64u) ? 12 : 0, s4 = (flags & 64u) ? 16 : 0, s2 = (flags & 64u) ? 8 : 0;
+            prim.attributes["POSITION"] = add_accessor(m, add_view(m, pos.data(), pos.size() * 4, TINYGLTF_TARGET_ARRAY_BUFFER, s3), 0, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC3, nv, mn, mx);
+            prim.attributes["NORMAL"] = add_accessor(m, add_view(m, nrm.data(), nrm.size() * 4, TINYGLTF_TARGET_ARRAY_BUFFER, s3), 0, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC3, nv);
+            prim.attributes["TANGENT"] = add_accessor(m, add_view(m, tan.data(), tan.size() * 4, TINYGLTF_TARGET_ARRAY_BUFFER, s4), 0, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC4, nv);
+            prim.attributes["TEXCOORD_0"] = add_accessor(m, add_view(m, uv.data(), uv.size() * 4, TINYGLTF_TARGET_ARRAY_BUFFER, s2), 0, TINYGLTF_COMPONENT_TYPE_FLOAT, TINYGLTF_TYPE_VEC2, nv);
+        }
+        if (ni) prim.indices = add_accessor(m, add_view(m, idx.data(), idx.size() * 4, TINYGLTF_TARGET_ELEMENT_ARRAY_BUFFER), 0, TINYGLTF_COMPONENT_TYPE_UNSIGNED_INT, TINYGLTF_TYPE_SCALAR, ni);
+        if (material >= n_materials) { fprintf(stderr, "glbwrite2: primitive %u names material %u of %u\n", k, material, n_materials); return 2; }
+        prim.material = (int)material;
+        if (flags & 32u) {
+            one_mesh.primitives.push_back(prim);
+            if (k == 0) { one_node.translation.assign(T, T + 3); one_node.rotation.assign(Rq, Rq + 4); one_node.scale.assign(S, S + 3); }
+        } else {
+            tinygltf::Mesh mesh;
+            mesh.name = name;
+            mesh.primitives.push_back(prim);
+            m.meshes.push_back(mesh);
+            tinygltf::Node node;
+            node.name = name + "_node";
+            node.mesh = (int)m.meshes.size() - 1;
+            node.translation.assign(T, T + 3); node.rotation.assign(Rq, Rq + 4); node.scale.assign(S, S + 3);
+            m.nodes.push_back(node);
+            scene.nodes.push_back((int)m.nodes.size() - 1);
+        }
+    }
+    if (!r.ok) { fprintf(stderr, "glbwrite2: truncated spec\n"); return 2; }
+    if (flags & 32u) {
+        m.meshes.push_back(one_mesh);
+        one_node.mesh = 0;
+        m.nodes.push_back(one_node);
+        scene.nodes.push_back(0);
+    }
+    m.scenes.push_back(scene);
+    m.defaultScene = 0;
+    tinygltf::TinyGLTF writer;
+    if (!writer.WriteGltfSceneToFile(&m, out, /*embedImages*/ true, /*embedBuffers*/ true, /*prettyPrint*/ false, /*writeBinary*/ true)) {
+        fprintf(stderr, "glbwrite2: tiny_gltf could not write %s\n", out);
+        return 3;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     static_assert(sizeof(utils::GaussianDataSSBO) == 96, "record layout");
     const std::string mode = argc > 1 ? argv[1] : "";
@@ -261,6 +385,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (mode == "glbwrite" && argc == 4) return do_glbwrite(argv[2], argv[3]);
-    fprintf(stderr, "usage: ref_host_check scene in.glb out.bin | plywrite rec.bin out.ply fmt mult | plyread in.ply out.bin | glbwrite spec.bin out.glb\n");
+    if (mode == "glbwrite2" && argc == 4) return do_glbwrite2(argv[2], argv[3]);
+    fprintf(stderr, "usage: ref_host_check scene in.glb out.bin | plywrite rec.bin out.ply fmt mult | plyread in.ply out.bin | glbwrite spec.bin out.glb | glbwrite2 spec2.bin out.glb\n");
     return 64;
 }

@@ -1,9 +1,13 @@
-"""-m gpu: real assets, when somebody supplies them.  BASELINE configs C2 (SciFiHelmet.glb, R = 512) and C4 (Sponza.glb, R = 1024) are
-quoted on files this repository cannot ship (no network, no assets in the reference: SURVEY §8c); the bench and the parity suite run
-on stand-ins.  With M2S_ASSET_DIR=<directory of .glb files> every file found there goes .glb -> m2s_load_glb -> HIP conversion ->
-.ply through the command line, and the same scene through the oracle: counter equal, records within tolerance, file rows equal to
-the Python mirror's.  R: 512 for a file named like the helmet, 1024 for Sponza, M2S_ASSET_R (default 256) otherwise.
-Without the variable (the GPU box of this build): skipped, and says so."""
+"""-m gpu: BASELINE configs C2 (SciFiHelmet.glb, R = 512) and C4 (Sponza.glb, R = 1024) as FILES.
+The real assets cannot ship with this repository (no network, none in the reference: SURVEY 8c), so two things run here:
+  * always: files SHAPED like them (tests/assets.py: 70 074 indexed triangles in one primitive under a node with TRS, four 2048^2 maps
+    as PNG and JPEG, a UV atlas with seams and charts outside [0, 1]; 103 primitives of one mesh on 25 materials sharing 34 images, two-
+    triangle planes beside sub-pixel foliage), authored on the box by the REFERENCE's own tiny_gltf + stb_image_write
+    (oracle/_ref/ref_host_check glbwrite2, prebuilt) — a writer this repository's loader shares nothing with;
+  * with M2S_ASSET_DIR=<directory of .glb files>: every file found there (the real SciFiHelmet.glb / Sponza.glb when somebody has them).
+Every file goes .glb -> m2s_load_glb -> HIP conversion -> .ply through the command line, and the same scene through the oracle: counter
+equal, records within tolerance (up to the reference's cap), file rows equal to the Python mirror's.  R: 512 for a file named like the
+helmet, 1024 for Sponza, M2S_ASSET_R (default 256) otherwise."""
 import glob
 import os
 import subprocess
@@ -30,23 +34,47 @@ def density_for(path: str) -> int:
     return int(os.environ.get("M2S_ASSET_R", "256"))
 
 
-@pytest.mark.skipif(not FILES, reason="M2S_ASSET_DIR is not set (or holds no .glb): no real asset to run C2 / C4 as written")
-@pytest.mark.parametrize("path", FILES or ["-"], ids=lambda p: os.path.basename(p))
-def test_real_asset_through_cli_and_oracle(tmp_path, hiplib, oracle, path):
-    R = density_for(path)
+def check_through_cli_and_oracle(tmp_path, oracle, path, R):
     out = str(tmp_path / "cli.ply")
     r = subprocess.run([EXE, path, out, "--density", str(R), "--format", "1", "--std", "0.65"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     loaded = gltf_io.load_glb(path)              # the Python reader (tests/test_ref_host.py ties both readers to the reference's)
     ctx = RenderContext(loaded, resolutionTarget=R, gaussianStd=0.65)
     ConversionPass().execute(ctx)
-    ototal, orec, _ = oracle.convert(loaded, R)
+    ototal, orec, _ = oracle.convert(loaded, R, n_threads=os.cpu_count() or 1)
     assert ctx.numberOfGaussians == ototal
     keep = min(ototal, oracle.reference_cap(R, loaded.n_meshes))
     assert_records_match(ctx.converter.download()[:keep], orec[:keep], os.path.basename(path))
     ref_ply = str(tmp_path / "py.ply")
     SceneManager(ctx).exportPly(ref_ply, 1)
     assert open(out, "rb").read() == open(ref_ply, "rb").read()
+    return loaded, ototal, ctx.converter.last_pipeline
+
+
+@pytest.mark.skipif(not FILES, reason="M2S_ASSET_DIR is not set (or holds no .glb): no real asset to run C2 / C4 as written")
+@pytest.mark.parametrize("path", FILES or ["-"], ids=lambda p: os.path.basename(p))
+def test_real_asset_through_cli_and_oracle(tmp_path, hiplib, oracle, path):
+    check_through_cli_and_oracle(tmp_path, oracle, path, density_for(path))
+
+
+@pytest.mark.parametrize("name", ["helmet_like_2048", "sponza_like_1.0"])
+def test_files_shaped_like_the_named_assets_through_cli_and_oracle(tmp_path, hiplib, oracle, name):
+    """BASELINE configs[1] and configs[3] on files the reference's own glTF stack wrote: the whole product path —
+    C++ loader (PNG + JPEG decoders, node transform, index fetch, shared images), upload, AUTO's pipeline, exporter — against the
+    oracle on the loaded scene, at the density the config names."""
+    import json
+    import assets
+    if not assets.available():
+        pytest.skip("oracle/_ref/ref_host_check is not on this box")
+    spec = assets.helmet_like(2048) if name.startswith("helmet") else assets.sponza_like(1.0)
+    path = str(tmp_path / ("SciFiHelmet_shaped.glb" if name.startswith("helmet") else "Sponza_shaped.glb"))
+    sha = assets.author(spec, path, str(tmp_path))
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "asset_hashes.json")))[name]
+    print(name, "sha256", sha[:16], "as committed" if sha == want["sha256"] else "DIFFERS from tests/golden/asset_hashes.json (another numpy / CPU?)")
+    loaded, total, pipeline = check_through_cli_and_oracle(tmp_path, oracle, path, density_for(path))
+    assert loaded.n_triangles == want["triangles"]
+    print(name, "R", density_for(path), "->", total, "Gaussians,", loaded.n_meshes, "mesh(es), pipeline", pipeline)
+    assert total > 300_000
 
 
 def test_asset_hook_is_reported():

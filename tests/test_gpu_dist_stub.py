@@ -167,7 +167,8 @@ def test_command_line_with_a_rank_that_dies(hiplib, tmp_path):
 def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
     """bench.py --gpus 2, one process per rank (the launcher environment RANK / WORLD_SIZE / MASTER_*; here both on device 0): the line
     says which transport moved the bytes — the C ABI's RCCL, here the stand-in — and carries gather / strong-scaling sections;
-    and when the communicator cannot be created the run exits non-zero WITHOUT a line (no silent fall-back)."""
+    and when the communicator cannot be created the run exits non-zero WITHOUT a measurement (no silent fall-back): rank 0's line
+    then has value null and a scale_record that carries the error text."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--workload", "c2", "--steps", "4", "--warmup", "1",
            "--no-extra-workloads", "--extras-timeout", "200"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=stub_env(tmp_path))
@@ -179,8 +180,27 @@ def test_bench_multi_rank_goes_through_the_c_abi_or_fails(hiplib, tmp_path):
     assert "gather" in line and line["gather"].get("ms_per_step", 0) > 0, line.get("gather")
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=stub_env(tmp_path, M2S_BENCH_FAIL_COMM="1"))
     assert bad.returncode != 0
-    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")], "a measurement line was printed although the communicator failed"
+    lines = [json.loads(ln) for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None, "a measurement line was printed although the communicator failed"
+    assert "could not be created" in lines[0]["error"] and "could not be created" in lines[0]["scale_record"]["error"]
+    assert any("M2S_BENCH_FAIL_COMM" in e for e in lines[0]["scale_record"]["errors"])
     assert "could not be created" in bad.stderr
+
+
+@needs_stub
+def test_bench_bring_up_is_time_boxed(hiplib, tmp_path):
+    """a rank that never arrives must not cost the lease 300 s of silence: rank 0 of a world of 2, alone, leaves
+    non-zero within its --bringup-timeout and prints the scale_record with the phase and the error text."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--workload", "small", "--steps", "2", "--warmup", "1",
+           "--no-extra-workloads", "--bringup-timeout", "6"]
+    env = stub_env(tmp_path, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", TMPDIR=str(tmp_path))
+    env.pop("M2S_RDZV_DIR", None)
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] is None and line["scale_record"]["phase"].startswith("rendezvous") and "rank 1" in line["scale_record"]["error"]
+
 
 
 # (world 8 — eight processes with their polling threads on a 16-core box, all on one GPU — takes anything from 7 s to 5 min depending on the box's load:
@@ -204,6 +224,8 @@ def test_bench_dry_scale_prints_the_scale_record(hiplib, tmp_path, world):
     assert rec["rccl_ranks"] == world and len(rec["per_rank_gaussians"]) == world and rec["transport"].startswith("rccl:")
     assert len(set(rec["per_rank_gaussians"])) == 1 and sum(rec["per_rank_gaussians"]) == line["config"]["gaussians_per_step"]
     assert rec["exchange_ms"] > 0 and rec["bringup_ms"] > 0 and line["value"] > 0
+    floor = rec["gather_link_floor_ms"]      # (what the record exchange cannot beat on xGMI: stated so that a measured number can be judged at once)
+    assert floor["all_7_links"] > 0 and floor["links_in_use"] > 0
     assert not line["multi_gpu_bringup"]["errors"]
     assert line["gather"]["ms_per_step"] > 0                       # the all-pairs record exchange ran as well
 
