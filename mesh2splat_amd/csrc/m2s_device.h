@@ -249,6 +249,7 @@ inline uint32_t fused_tpw(uint32_t n_tri) {
 }
 inline uint32_t n_fused_waves(uint32_t n_tri) { const uint32_t w = fused_tpw(n_tri); return (n_tri + w - 1) / w; }
 // entries (batches + 1) a BatchTable for n_tri triangles may need; 0: the scene takes uniform 64-triangle batches
-inline uint32_t batch_table_capacity(uint32_t n_tri) { return fused_tpw(n_tri) < 64u ? n_fused_waves(n_tri) + n_tri / 64u + 16u : 0u; }
+// (room for one batch per wave slot of the lean kernel — 4096 — where that is more than one per wave of k_fused2)
+inline uint32_t batch_table_capacity(uint32_t n_tri) { return fused_tpw(n_tri) < 64u ? (n_fused_waves(n_tri) > 4096u ? n_fused_waves(n_tri) : 4096u) + n_tri / 64u + 16u : 0u; }
 
 }  // namespace m2s

@@ -104,17 +104,20 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
 // ============================================================================================
 // k_count_scan
 // ============================================================================================
-__global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(SceneDev sc, uint32_t R, uint32_t* __restrict__ off,
-                                                            uint32_t* __restrict__ start, uint32_t n_start,
-                                                            unsigned long long* __restrict__ chain, uint32_t epoch,
-                                                            unsigned long long* __restrict__ total_out,
-                                                            float4* __restrict__ setup, uint32_t* __restrict__ status,
-                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */) {
-    __shared__ uint32_t wsum[kCountBlock / 64];
-    __shared__ uint32_t wtall[kCountBlock / 64];
-    __shared__ unsigned long long base_s;
+// The body of k_count_scan for block `bid` of the scene (the shipping kernel passes its own block index; inlined).
+// -DM2S_PERSISTENT_COUNT builds the round-5 experiment again — at most 1024 workgroups that take blocks by ticket, this body as a
+// NON-inlined function — for tools/crash_probe.py (profiles/r06/count_scan_fault_analysis.md); it is not part of the library.
+#ifdef M2S_PERSISTENT_COUNT
+#define M2S_COUNT_BODY __device__ __noinline__
+#else
+#define M2S_COUNT_BODY __device__ __forceinline__
+#endif
+M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* __restrict__ off, uint32_t* __restrict__ start, uint32_t n_start,
+                                     unsigned long long* __restrict__ chain, uint32_t epoch, unsigned long long* __restrict__ total_out,
+                                     float4* __restrict__ setup, uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
+                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blockBase = blockIdx.x * kCountBlock;
+    const uint32_t blockBase = bid * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
     const bool valid = t < sc.n_tri;
     const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
@@ -188,14 +191,14 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         any_tall |= wtall[w];
     }
     // the block's class: who emits its fragments (see the file header)
-    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[blockIdx.x] = (tot <= kFineMax && !any_tall) ? 1 : 0;
+    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[bid] = (tot <= kFineMax && !any_tall) ? 1 : 0;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     // The workgroup's aggregate is published as soon as it is known — BEFORE the per-triangle setup records are computed and
     // stored: successors can resolve their bases while this workgroup is still busy, and this workgroup's own look-back
     // (below) finds its predecessors' words already in place.  (Setup first, then publish: k_count_scan 0.042 ms on the C4
     // stand-in; without any setup 0.027 ms, without the look-back 0.030 ms: the two used to add up on the critical path.)
     if (wave == 0 && lane == 0)
-        chain_store(&chain[blockIdx.x], (blockIdx.x == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+        chain_store(&chain[bid], (bid == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
     if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
         if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
@@ -214,12 +217,12 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     }
 
     if (wave == 0) {
-        const uint32_t b = blockIdx.x;
+        const uint32_t b = bid;
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
-            base_s = base;
-            if (b == gridDim.x - 1) {
+            *base_sp = base;
+            if (b == n_tb - 1) {
                 *total_out = base + tot;
                 // the counter the host waits for: written by the kernel itself (like the single-pass kernels), no copy behind the pipeline
                 if (total_host) __hip_atomic_store(total_host, base + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         }
     }
     __syncthreads();
-    const unsigned long long base = base_s;
+    const unsigned long long base = *base_sp;
     const unsigned long long o0 = base + woff + (incl - c);
     if (valid) {
         // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
@@ -249,6 +252,38 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         const uint32_t tt = __shfl(t, src);
         for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) start[mm] = tt;
     }
+}
+
+
+__global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(SceneDev sc, uint32_t R, uint32_t* __restrict__ off,
+                                                            uint32_t* __restrict__ start, uint32_t n_start,
+                                                            unsigned long long* __restrict__ chain, uint32_t epoch,
+                                                            unsigned long long* __restrict__ total_out,
+                                                            float4* __restrict__ setup, uint32_t* __restrict__ status,
+                                                            unsigned long long* __restrict__ total_host /* pinned, or nullptr */) {
+    __shared__ uint32_t wsum[kCountBlock / 64];
+    __shared__ uint32_t wtall[kCountBlock / 64];
+    __shared__ unsigned long long base_s;
+    const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
+#ifndef M2S_PERSISTENT_COUNT
+    count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s);
+#else
+    // tickets: words 2 and 3 of the tall-triangle table's header (zero when allocated; the last workgroup out zeroes them again)
+    __shared__ uint32_t s_bid;
+    uint32_t* const tk = tall_header(setup, sc.n_tri) + 2;
+    for (;;) {
+        __syncthreads();                       // every wave is done with the previous block's shared words
+        if (threadIdx.x == 0) s_bid = atomicAdd(&tk[0], 1u);
+        __syncthreads();
+        const uint32_t bid = s_bid;
+        if (bid >= n_tb) break;
+        count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&tk[1], 1u) == gridDim.x - 1u) { tk[0] = 0u; tk[1] = 0u; }
+    }
+#endif
 }
 
 // ============================================================================================
@@ -519,7 +554,11 @@ size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_t
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
                        uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st) {
     if (!sc.n_tri) return;
-    hipLaunchKernelGGL(k_count_scan, dim3(count_scan_blocks(sc.n_tri)), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
+    uint32_t grid = count_scan_blocks(sc.n_tri);
+#ifdef M2S_PERSISTENT_COUNT
+    if (grid > 1024u) grid = 1024u;
+#endif
+    hipLaunchKernelGGL(k_count_scan, dim3(grid), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
                        epoch & 0xFFFFu, total, (float4*)setup, status, total_host);
 }
 

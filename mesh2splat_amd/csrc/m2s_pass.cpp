@@ -153,7 +153,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
             std::vector<uint32_t> cnt(sc.n_tri), first;
             HIPCHK(c, hipMemcpy(cnt.data(), c->d_cnt, (size_t)sc.n_tri * sizeof(uint32_t), hipMemcpyDeviceToHost));
             uint32_t n_target = n_fused_waves(sc.n_tri);
-            if (const char* v = debug_env("M2S_BATCH_TARGET")) { const unsigned long q = strtoul(v, nullptr, 10); if (q >= 1 && q <= 3072) n_target = (uint32_t)q; }   // debug: A/B
+            if (const char* v = debug_env("M2S_BATCH_TARGET")) { const unsigned long q = strtoul(v, nullptr, 10); if (q >= 1 && q <= 8192) n_target = (uint32_t)q; }   // debug: A/B
             double ct = 214.0;
             const double cf = 140.0;
             if (const char* v = debug_env("M2S_BATCH_CT")) ct = atof(v);   // debug: A/B of the work model

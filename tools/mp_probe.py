@@ -11,6 +11,10 @@ from mesh2splat_amd.ctl import Ctl  # noqa: E402
 names = sys.argv[1:] or ["mid", "c4", "hetero"]
 torch.cuda.set_device(0)
 ctl = Ctl(0, 1)
+pipe = os.environ.get("M2S_PROBE_PIPELINE")      # A/B: force a pipeline setting
+if pipe:
+    _Rig = bench.Rig
+    bench.Rig = lambda *a, **k: _Rig(*a, **dict(k, pipeline=pipe))
 for n in names:
     r = bench.extra_workload(torch, ctl, 0, n)
     keep = {k: r[k] for k in ("workload", "gaussians", "pipeline", "kernel_ms", "kernels_total_ms", "blocking_ms", "ms_per_step", "roofline_blocking")}
