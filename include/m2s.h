@@ -384,9 +384,6 @@ enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
 /* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2), _LEAN (k_fused3) or _SPARSE (k_sparse); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);
-/* MULTI-PASS conversions: in how many chunks of triangle blocks the last one ran as ONE launch (k_multipass: chunk k + 1 is counted
- * while chunk k is emitted); 0: it ran as two kernels (count, then emit), or the last conversion was a single-pass kernel. */
-int m2s_last_chunks(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */
 enum { M2S_K_COUNT = 0, M2S_K_SCAN = 1, M2S_K_OFFSETS = 2, M2S_K_EMIT = 3, M2S_K_FUSED = 4, M2S_K_N = 5 };

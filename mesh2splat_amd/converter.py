@@ -285,11 +285,6 @@ class Converter:
         """What the last conversion ran: 'multipass', 'wave' (k_fused) or 'team' (k_fused2)."""
         return {0: "none", 1: "multipass", 2: "wave", 3: "team", 4: "sparse", 5: "lean"}[self._L.m2s_last_pipeline(self._h)]
 
-    @property
-    def last_chunks(self) -> int:
-        """multi-pass: chunks of the last conversion when it ran as ONE launch (k_multipass); 0: two kernels, or a single-pass kernel"""
-        return int(self._L.m2s_last_chunks(self._h))
-
     # -- measurement --------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         self._check(self._L.m2s_set_profiling(self._h, 1 if on else 0))

@@ -41,7 +41,6 @@ void free_scene(m2s_ctx* c) {
     ++c->rinfo_gen;
     c->frag_per_R2 = -1.0;
     c->warm_R = 0; c->warm_total = 0; c->warm_mismatch_seen = false;
-    c->block_prefix.clear();
     c->sparse_off_R = c->team_off_R = c->lean_off_R = UINT32_MAX;
     c->lean_ok = false;
     c->scene = SceneDev{};
@@ -186,7 +185,6 @@ void m2s_destroy(m2s_ctx* c) {
     if (c->d_records) (void)hipFree(c->d_records);
     if (c->d_records_b) (void)hipFree(c->d_records_b);
     if (c->stream_b) { (void)hipStreamSynchronize(c->stream_b); (void)hipStreamDestroy(c->stream_b); }
-    if (c->d_mp_words) (void)hipFree(c->d_mp_words);
     if (c->d_sorted) (void)hipFree(c->d_sorted);
     if (c->d_quads) (void)hipFree(c->d_quads);
     if (c->d_sorted_quads) (void)hipFree(c->d_sorted_quads);
@@ -249,7 +247,6 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
 }
 
 int m2s_last_pipeline(const m2s_ctx* c) { return c ? c->last_pipeline : 0; }
-int m2s_last_chunks(const m2s_ctx* c) { return (c && c->last_pipeline == M2S_PIPELINE_MULTIPASS) ? c->last_chunks : 0; }
 
 m2s_status m2s_debug_set_launch_counter(m2s_ctx* c, uint32_t value) {
     if (!c) return M2S_ERR_INVALID;

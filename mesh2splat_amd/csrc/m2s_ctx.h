@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <map>
 #include <string>
-#include <vector>
 
 namespace m2s_host {
 constexpr uint32_t kMaxGaussiansToSort = 7000000u;  // RenderPass.hpp:9
@@ -65,10 +64,6 @@ struct m2s_ctx {
         bool lean_off = false;     // k_fused3 overflowed its LDS stream or deferred many triangles at this R: use k_fused2
         bool async_ok = false;     // a completed conversion needed no host decision between kernels
         bool mp_ready = false;     // a multi-pass conversion has completed (its work buffers are sized)
-        bool mp_planned = false;   // multi-pass: the chunk plan of this R has been made: mp_chunks chunks at the blocks mp_blk[] ...
-        bool mp_merged_off = false;   // ... or a one-launch conversion at this R reported a short launch / a timeout: two kernels
-        uint32_t mp_chunks = 0, mp_blk[m2s::kMpChunks + 1] = {};
-        uint64_t mp_est_lo[m2s::kMpChunks] = {}, mp_est_hi[m2s::kMpChunks] = {};   // bounds on the chunks' record ranges (sizes of their emitters)
         bool bands_ready = false;  // the run table of this R (slot band_slot of d_bands: where every run's output starts) is in place ...
         uint32_t bands_unit = 0;   // ... in units of this many triangles (256: recorded by a k_fused2 launch, 512: k_sparse)
         int band_slot = 0;
@@ -93,12 +88,6 @@ struct m2s_ctx {
     uint32_t n_batch_tab = 0;               // batches in it (0: uniform batches)
     size_t chain_words = 0;                 // words of d_chain (and of the second lane's chain)
     void* d_setup = nullptr;                // multi-pass pipeline: per-triangle TriSetup records (allocated at its first use)
-    // the multi-pass conversion in ONE launch (k_multipass): chunk ends + done counters on the device, the counters' values on the host,
-    // and where the fragments are, block of 256 triangles by block (the upload's exact count at warm_R): what the chunks are cut by
-    unsigned long long* d_mp_words = nullptr;
-    unsigned long long mp_done[m2s::kMpChunks] = {};
-    std::vector<unsigned long long> block_prefix;
-    int last_chunks = 0;                    // chunks of the last multi-pass conversion (0: the two-kernel path); m2s_last_chunks
     int last_pipeline = 0;                  // what the last conversion ran (m2s_last_pipeline)
     // second lane for context-owned asynchronous submissions: odd slots run on their own stream with their own chain
     // and record buffer, so that consecutive single-kernel conversions overlap (the tail of one, where the GPU drains,

@@ -122,24 +122,6 @@ void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* 
 void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start, const unsigned long long* total,
                   uint64_t limit, const void* setup, float4* out, hipStream_t st);
 
-// ... and the whole multi-pass conversion in ONE launch (k_multipass, m2s_emit2.hip): chunks of blocks, counted and emitted in an
-// interleaved grid.  The host fills blk[] (chunk boundaries in blocks of 256 triangles), n_slice_wg[] (emitting workgroups per chunk
-// behind its fine-block ones: a multiple of 128) and done_target[]; the launcher derives the sections.
-constexpr int kMpChunks = 6;
-struct MpPlan {
-    uint32_t n_chunks;
-    uint32_t blk[kMpChunks + 1];
-    uint32_t sec_first[kMpChunks + 2];
-    uint32_t n_cgroups[kMpChunks + 1];
-    uint32_t n_egroups[kMpChunks + 1];
-    uint32_t n_slice_wg[kMpChunks];
-    unsigned long long done_target[kMpChunks];
-};
-// mp_words: kMpChunks chunk-end words followed by kMpChunks done counters (device; the counters only ever grow)
-void launch_multipass(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain, uint32_t epoch,
-                      unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, uint64_t limit, float4* out,
-                      unsigned long long* mp_words, MpPlan& plan, hipStream_t st);
-
 // device-side .ply row encoder, formats 1 and 2 (m2s_export.hip)
 void launch_encode_rows(const float4* rec, uint64_t n, uint32_t format, float scale_multiplier, uint8_t* out, hipStream_t st);
 

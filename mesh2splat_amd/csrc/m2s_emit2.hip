@@ -35,7 +35,9 @@
 //                 counted a fine block emits it — the count stage lasts as long as its slowest workgroup and k_emit2 lost the
 //                 workgroups that filled its tail, tag r6-fine-fold-in-count —; and the conversion cut into two chunks of blocks,
 //                 count(B) beside emit(A) on a second stream — three cross-queue waits on the critical path of a 0.16 ms
-//                 conversion, tag r6-two-stream-chunks.  profiles/r06/negative_*.log.)
+//                 conversion, tag r6-two-stream-chunks —; and count and emit as two roles of ONE launch with in-kernel dependencies
+//                 between chunks — waiting emitters hold workgroup slots and stall the in-order dispatcher, 1.6-2x slower, tag
+//                 r6-one-launch-multipass.  profiles/r06/negative_*.log.)
 // Output: bit-identical to every other pipeline (same device functions, same operation order).
 #include <cstdlib>
 #include "m2s_fused_common.h"
@@ -81,36 +83,10 @@ constexpr uint32_t kTallChunks = 64;          // 4096 rows / 64
 __device__ __forceinline__ uint32_t* tall_header(const float4* setup, uint32_t n_tri) {
     return reinterpret_cast<uint32_t*>(const_cast<float4*>(setup) + (size_t)max(n_tri, 1u) * 7);
 }
-// ... and behind that table one word per block of kCountBlock triangles: 1 = fine block (see the file header)
+// ... and behind that table one byte per block of kCountBlock triangles: 1 = fine block (see the file header)
 constexpr uint32_t kFineMax = 2048;           // fragments of a fine block: its entry list fits the workgroup's LDS
-__device__ __forceinline__ uint32_t* block_class(const float4* setup, uint32_t n_tri) {
-    return tall_header(setup, n_tri) + 4 + (size_t)kTallCap * kTallChunks;
-}
-
-// ---- data that passes from a counting workgroup to an emitting workgroup of the SAME launch (k_multipass below) -------------------
-// gfx950 has one L2 per XCD and they are not coherent with each other for ordinary loads and stores: inside one kernel a workgroup
-// on XCD a sees what a workgroup on XCD b wrote only if the store went through to memory and the load does not hit a stale line.
-// kCo = true: stores are agent-scope atomics (sc1: write-through) and the few loads that can share a 128-byte line with data still
-// being written (block classes, slice starts, tall-table rows, chunk ends) are agent-scope atomics too (sc1: bypass); offsets and
-// TriSetup records are laid out so that a line belongs to ONE block of 256 triangles and is read only after that block is done.
-// kCo = false (the two-kernel path): plain accesses, the kernel boundary does the rest.
-#ifndef M2S_CO_STORES
-#define M2S_CO_STORES 0      // 1: write-through (sc1) stores; 0: plain stores + one agent-scope release (L2 write-back) per counting workgroup
-#endif
-template <bool kCo> __device__ __forceinline__ void co_store(uint32_t* p, uint32_t v) {
-    if constexpr (kCo && M2S_CO_STORES) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-template <bool kCo> __device__ __forceinline__ uint32_t co_load(const uint32_t* p) {
-    if constexpr (kCo) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
-}
-template <bool kCo> __device__ __forceinline__ void co_store16(float4* p, float4 v) {
-    if constexpr (kCo && M2S_CO_STORES) {
-        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-        const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-        const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
-        __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else *p = v;
+__device__ __forceinline__ uint8_t* block_class(const float4* setup, uint32_t n_tri) {
+    return reinterpret_cast<uint8_t*>(tall_header(setup, n_tri) + 4 + (size_t)kTallCap * kTallChunks);
 }
 
 __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
@@ -138,13 +114,10 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
 #else
 #define M2S_COUNT_BODY __device__ __forceinline__
 #endif
-// chunk_end (k_multipass: the word of the chunk this block belongs to, written by the chunk's LAST block; else nullptr)
-template <bool kCo>
 M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* __restrict__ off, uint32_t* __restrict__ start, uint32_t n_start,
                                      unsigned long long* __restrict__ chain, uint32_t epoch, unsigned long long* __restrict__ total_out,
                                      float4* __restrict__ setup, uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
-                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp,
-                                     unsigned long long* __restrict__ chunk_end = nullptr) {
+                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = bid * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
@@ -201,7 +174,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
                 const int y = yc + lane;
                 int xa = 0, xb = -1;
                 if (y <= b.y1) row_walker_next(rw, xa, xb);
-                if (listed && lane == 0 && ci < kTallChunks) co_store<kCo>(&row[ci], run);
+                if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
                 run += wave_sum((uint32_t)max(xb - xa + 1, 0));
             }
             if (lane == src) { c = run; tall_slot = listed ? slot + 1u : 0u; }
@@ -220,7 +193,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         any_tall |= wtall[w];
     }
     // the block's class: who emits its fragments (see the file header)
-    if (threadIdx.x == 0) co_store<kCo>(&block_class(setup, sc.n_tri)[bid], (tot <= kFineMax && !any_tall) ? 1u : 0u);
+    if (threadIdx.x == 0) block_class(setup, sc.n_tri)[bid] = (tot <= kFineMax && !any_tall) ? 1 : 0;
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     // The workgroup's aggregate is published as soon as it is known — BEFORE the per-triangle setup records are computed and
     // stored: successors can resolve their bases while this workgroup is still busy, and this workgroup's own look-back
@@ -242,7 +215,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         const float4* src4 = reinterpret_cast<const float4*>(&s);
         float4* dst4 = setup + (size_t)t * 7;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) co_store16<kCo>(&dst4[k], src4[k]);
+        for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
     }
 
     if (wave == 0) {
@@ -251,7 +224,6 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
             *base_sp = base;
-            if (chunk_end) __hip_atomic_store(chunk_end, base + tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b == n_tb - 1) {
                 *total_out = base + tot;
                 // the counter the host waits for: written by the kernel itself (like the single-pass kernels), no copy behind the pipeline
@@ -265,22 +237,22 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     if (valid) {
         // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
         const unsigned long long o1 = o0 + c;
-        co_store<kCo>(&off[t], (uint32_t)min(o0, 0xFFFFFFFFull));
-        if (t == sc.n_tri - 1) co_store<kCo>(&off[sc.n_tri], (uint32_t)min(o1, 0xFFFFFFFFull));
+        off[t] = (uint32_t)min(o0, 0xFFFFFFFFull);
+        if (t == sc.n_tri - 1) off[sc.n_tri] = (uint32_t)min(o1, 0xFFFFFFFFull);
     }
     // start[m] = the triangle that owns output record m * kSlice.  A triangle covering many slices (up to 32 768 for a
     // 4096 x 4096 px one) has the whole wave write them.
     const unsigned long long mf = (o0 + kSlice - 1) / kSlice, ml = c ? (o0 + c - 1) / kSlice : 0;
     const bool few = valid && c && ml >= mf && (ml - mf) < 16;
     if (few)
-        for (unsigned long long mm = mf; mm <= ml && mm < n_start; ++mm) co_store<kCo>(&start[mm], t);
+        for (unsigned long long mm = mf; mm <= ml && mm < n_start; ++mm) start[mm] = t;
     unsigned long long many = __ballot(valid && c && ml >= mf && !few);
     while (many) {
         const int src = __ffsll((long long)many) - 1;
         many &= many - 1;
         const unsigned long long f = __shfl(mf, src), l = __shfl(ml, src);
         const uint32_t tt = __shfl(t, src);
-        for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) co_store<kCo>(&start[mm], tt);
+        for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) start[mm] = tt;
     }
 }
 
@@ -296,7 +268,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     __shared__ unsigned long long base_s;
     const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
 #ifndef M2S_PERSISTENT_COUNT
-    count_scan_block<false>(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s);
+    count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s);
 #else
     // tickets: words 2 and 3 of the tall-triangle table's header (zero when allocated; the last workgroup out zeroes them again)
     __shared__ uint32_t s_bid;
@@ -307,7 +279,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         __syncthreads();
         const uint32_t bid = s_bid;
         if (bid >= n_tb) break;
-        count_scan_block<false>(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s);
+        count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s);
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -374,34 +346,19 @@ __device__ __forceinline__ void shade_and_store_strip(const SceneDev& sc, const 
     }
 }
 
-// What an emitting workgroup knows about the part of the scene it works on: the whole scene (k_emit2), or one CHUNK of blocks of a
-// launch that also counts (k_multipass): the triangles [t_lo, t_hi) = whole blocks of kCountBlock, whose records are [rec_lo, nw).
-struct EmitRange {
-    uint32_t t_lo, t_hi;         // triangles of the range (t_hi: one past; offsets of triangle t_hi are NOT read: rec_hi stands for them)
-    unsigned long long rec_lo;   // first record of the range
-    unsigned long long rec_hi;   // one past its last record (before the limit is applied)
-    unsigned long long nw;       // records stored: min(rec_hi, limit)
-};
-// off[t] for t in [t_lo, t_hi]: the range's one-past-the-end offset is a line that belongs to the NEXT chunk's first block (which may
-// be writing it right now, k_multipass): its value is known without reading it
-__device__ __forceinline__ uint32_t off_at(const uint32_t* __restrict__ off, uint32_t t, const EmitRange& er) {
-    return t >= er.t_hi ? (uint32_t)min(er.rec_hi, 0xFFFFFFFFull) : off[t];
-}
-
 // A fine block (at most kFineMax fragments from kCountBlock triangles of at most kRowsThread rows each): one thread per triangle
 // writes its pixels into the block's entry list, then the four waves take the strips in turn.
-__device__ __forceinline__ void emit_fine_block(const SceneDev& sc, const uint32_t* __restrict__ off, const EmitRange& er,
+__device__ __forceinline__ void emit_fine_block(const SceneDev& sc, const uint32_t* __restrict__ off, unsigned long long nw,
                                                 const float4* __restrict__ setup, float4* __restrict__ out, uint32_t blk, FineLds& F) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long nw = er.nw;
-    const uint32_t t0 = blk * (uint32_t)kCountBlock, t1 = min(t0 + (uint32_t)kCountBlock, er.t_hi);
-    const uint32_t base = off[t0], end = off_at(off, t1, er);
+    const uint32_t T = sc.n_tri, t0 = blk * (uint32_t)kCountBlock, t1 = min(t0 + (uint32_t)kCountBlock, T);
+    const uint32_t base = off[t0], end = off[t1];
     if (end <= base || (unsigned long long)base >= nw) return;
     const uint32_t n_store = (uint32_t)min((unsigned long long)(end - base), nw - base);
     const uint32_t t = t0 + threadIdx.x;
     if (t < t1) {
-        const uint32_t o0 = off[t], o1 = off_at(off, t + 1, er);
+        const uint32_t o0 = off[t], o1 = off[t + 1];
         if (o1 > o0 && o0 - base < n_store) {
             TriSetup s;
             const float4* src4 = setup + (size_t)t * 7;
@@ -427,56 +384,47 @@ __device__ __forceinline__ void emit_fine_block(const SceneDev& sc, const uint32
         shade_and_store_strip(sc, F.tri, &F.entries[s0], min(64u, n_store - s0), t0, F.stage[wave], out + ((size_t)base + s0) * 6, lane);
 }
 
-// One emitting workgroup.  e = its number among the emitting workgroups of the range: the first n_fine_wg (one per block of the
-// range, rounded up to whole groups of eight) take the FINE blocks, the others four slices of kSlice records each.
-template <bool kCo>
-__device__ __forceinline__ void emit2_wg(const SceneDev& sc, const uint32_t* __restrict__ off, const uint32_t* __restrict__ start,
-                                         const EmitRange& er, const float4* __restrict__ setup, float4* __restrict__ out,
-                                         uint32_t run /* consecutive workgroups per XCD turn */, uint32_t e, uint32_t n_slice_wg,
-                                         uint32_t* __restrict__ status, bool reset_tall, float4* lds_raw) {
+__global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ start,
+                                                     const unsigned long long* __restrict__ total_p, unsigned long long limit,
+                                                     const float4* __restrict__ setup, float4* __restrict__ out,
+                                                     uint32_t run /* consecutive workgroups per XCD turn */) {
+    __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long nw = er.nw;
-    const uint32_t Tall = sc.n_tri, T = er.t_hi;
-    const uint32_t* __restrict__ cls = block_class(setup, Tall);
-    const uint32_t blk_lo = er.t_lo / (uint32_t)kCountBlock;
-    const uint32_t n_tb = (T - er.t_lo + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock, n_fine_wg = (n_tb + 7u) & ~7u;
-    if (e < n_fine_wg) {
-        if (e < n_tb && cls[blk_lo + e]) emit_fine_block(sc, off, er, setup, out, blk_lo + e, *reinterpret_cast<FineLds*>(lds_raw));
+    const unsigned long long total = *total_p;
+    const unsigned long long nw = total < limit ? total : limit;  // records actually stored
+    const uint32_t T = sc.n_tri;
+    const uint8_t* __restrict__ cls = block_class(setup, T);
+    // the first workgroups of the launch (one per block of triangles, rounded up to whole groups of eight) take the FINE blocks
+    const uint32_t n_tb = (T + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock, n_fine_wg = (n_tb + 7u) & ~7u;
+    if (blockIdx.x < n_fine_wg) {
+        if (blockIdx.x < n_tb && cls[blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
         return;
     }
-    const uint32_t bid = e - n_fine_wg;
+    const uint32_t bid = blockIdx.x - n_fine_wg;
     Emit2Lds& L = reinterpret_cast<Emit2Lds*>(lds_raw)[wave];
     // XCD-aware mapping (hardware workgroup b runs on XCD b % 8, private L2 each): the XCDs take turns of `run` consecutive
     // workgroups — runs of the output, of the mesh surface, of texture space meet in ONE L2 —, block-cyclically.  Until round 3
     // every XCD had one contiguous EIGHTH of the output: fine for one uniform mesh, but a record does not cost the same
     // everywhere (triangles per slice, magnified or minified maps): on the C4 stand-in the kernel ran 7 % faster with NO mapping
-    // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; the slices have no
-    // inter-workgroup dependency, so any mapping is correct.  (Callers keep e congruent to the hardware workgroup index modulo 8.)
-    // the tall-triangle table's slot counter goes back to zero for the next conversion (the emitters only read the table; reset_tall:
-    // this range holds the scene's last blocks, i.e. every counting workgroup of the conversion has finished)
-    if (reset_tall && bid == 0 && threadIdx.x == 0) tall_header(setup, Tall)[0] = 0;
+    // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
+    // inter-workgroup dependency, so any mapping is correct.
+    // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
+    if (bid == 0 && threadIdx.x == 0) tall_header(setup, T)[0] = 0;
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
-    const uint32_t lblock0 = (uint32_t)(er.rec_lo / per_wg);     // (workgroups are counted from the one that holds the range's first record)
     const uint32_t xcd = bid & 7u, turn = (bid >> 3) / run, in_run = (bid >> 3) % run;
-    const uint32_t lblock = lblock0 + (turn * 8u + xcd) * run + in_run;
-    // A chunk's emitters are sized from the host's ESTIMATE of where the chunk's records lie (exact at the density the upload counted
-    // at); should the real range end beyond the last workgroup, say so: the host repeats the conversion with the two-kernel path.
-    if (kCo && bid == 0 && threadIdx.x == 0 && (unsigned long long)nblk > (unsigned long long)lblock0 + n_slice_wg)
-        __hip_atomic_store(&status[1], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t lblock = (turn * 8u + xcd) * run + in_run;
     if (lblock >= nblk) return;
     const uint32_t slice = lblock * (kBlock / 64) + wave;
     const unsigned long long wbase64 = (unsigned long long)slice * kSlice;
-    if (wbase64 >= nw || wbase64 + kSlice <= er.rec_lo) return;
+    if (wbase64 >= nw) return;
     const uint32_t wbase = (uint32_t)wbase64;
     const uint32_t wend = (uint32_t)(nw - wbase64 < (unsigned long long)kSlice ? nw : wbase64 + kSlice);
 
-    // A slice that straddles the range's first record belongs to two ranges: the earlier one stopped at rec_lo (its nw), this one
-    // begins there, at the first triangle of its blocks.
-    const bool straddles = wbase64 < er.rec_lo;
-    uint32_t pos = straddles ? (uint32_t)er.rec_lo : wbase;                 // next record to produce
-    for (uint32_t t_cur = straddles ? er.t_lo : co_load<kCo>(&start[slice]); pos < wend && t_cur < T; ) {
+    uint32_t pos = wbase;                 // next record to produce
+    for (uint32_t t_cur = start[slice]; pos < wend && t_cur < T; ) {
         // ---- the batch: up to 64 consecutive triangles, one per lane.  A fine block is stepped over; a batch that would run from a
         // dense block into a fine one ends at the block boundary.  Everything the decision needs is requested at once (the classes of
         // this block and the next, the offsets at both possible ends, the lanes' own offsets): one round trip, as before round 5 ----
@@ -485,9 +433,9 @@ __device__ __forceinline__ void emit2_wg(const SceneDev& sc, const uint32_t* __r
         const uint32_t t_full = min(t_cur + 64u, T);
         const uint32_t t = t_cur + lane;
         uint32_t o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
-        if (t < t_full) { o0 = off[t]; o1 = off_at(off, t + 1, er); }
-        const uint32_t c_here = cls[blk], c_next = t_full > blk_end ? cls[blk + 1u] : 0u;     // (k_multipass: chunks are cut at multiples of 32 blocks — a 128-byte line of class words belongs to ONE chunk)
-        const uint32_t o_full = off_at(off, t_full, er), o_blk = off_at(off, blk_end, er);
+        if (t < t_full) { o0 = off[t]; o1 = off[t + 1]; }
+        const uint32_t c_here = cls[blk], c_next = t_full > blk_end ? cls[blk + 1u] : 0u;
+        const uint32_t o_full = off[t_full], o_blk = off[blk_end];
         const bool fine_blk = c_here != 0;
         const uint32_t t_next = (fine_blk || c_next != 0) ? blk_end : t_full;
         const uint32_t o_next = t_next == t_full ? o_full : o_blk;   // first record of the next batch
@@ -556,8 +504,8 @@ __device__ __forceinline__ void emit2_wg(const SceneDev& sc, const uint32_t* __r
                 // (running sums never decrease; a chunk without fragments shares its sum with the next one and is skipped)
                 const uint32_t rel = pos - acc;
                 const int nch = min((b.y1 - b.y0) / 64 + 1, (int)kTallChunks);
-                const uint32_t* row = tall_header(setup, Tall) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
-                const uint32_t pre = lane < nch ? co_load<kCo>(&row[lane]) : 0xFFFFFFFFu;
+                const uint32_t* row = tall_header(setup, T) + 4 + (size_t)(ts_ - 1u) * kTallChunks;
+                const uint32_t pre = lane < nch ? row[lane] : 0xFFFFFFFFu;
                 const unsigned long long le = __ballot(pre <= rel);
                 const int c0 = le ? 63 - __clzll((long long)le) : 0;
                 acc += (uint32_t)__shfl((int)pre, c0);
@@ -585,9 +533,9 @@ __device__ __forceinline__ void emit2_wg(const SceneDev& sc, const uint32_t* __r
                 const unsigned long long me = m & (~0ull >> (63 - lane));        // row starts at or before my record, in this block
                 const int srcl = me ? 63 - __clzll((long long)me) : lane;
                 const uint32_t from = (uint32_t)__shfl((int)raw, srcl);
-                const uint32_t e_ = me ? from + (uint32_t)(lane - srcl) : carry + (uint32_t)lane + 1u;
-                if (i >= i0 && i < i1) L.entries[i] = e_;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)e_, 63);
+                const uint32_t e = me ? from + (uint32_t)(lane - srcl) : carry + (uint32_t)lane + 1u;
+                if (i >= i0 && i < i1) L.entries[i] = e;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)e, 63);
             }
         }
         wave_lds_sync();
@@ -599,123 +547,10 @@ __device__ __forceinline__ void emit2_wg(const SceneDev& sc, const uint32_t* __r
     }
 }
 
-__global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
-                                                     const uint32_t* __restrict__ start,
-                                                     const unsigned long long* __restrict__ total_p, unsigned long long limit,
-                                                     const float4* __restrict__ setup, float4* __restrict__ out,
-                                                     uint32_t run /* consecutive workgroups per XCD turn */) {
-    __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
-    const unsigned long long total = *total_p;
-    EmitRange er;
-    er.t_lo = 0; er.t_hi = sc.n_tri; er.rec_lo = 0; er.rec_hi = total;
-    er.nw = total < limit ? total : limit;  // records actually stored
-    emit2_wg<false>(sc, off, start, er, setup, out, run, blockIdx.x, 0u, nullptr, true, lds_raw);
-}
-
-// ============================================================================================
-// k_multipass (round 6): the whole multi-pass conversion in ONE launch
-// ============================================================================================
-// The two kernels above cannot overlap: k_emit2 starts when the last workgroup of k_count_scan has finished, and k_count_scan is one
-// generation of workgroups bound by the issue of 64-bit / fp64 / IEEE-division sequences while the memory system idles — 20-30 % of
-// a conversion (heterogeneous scene: 0.050 + 0.110 ms; two LANES overlap the count of one conversion with the emission of the
-// previous one and reach 0.123 ms per step, but the reference's call is ONE blocking conversion, ConversionPass.cpp:50-59).
-// Round 6 measured two ways of overlapping them from the host — emission folded into the counting workgroups, two chunks on two
-// streams — and both lost (profiles/r06/negative_*.log).  Here the overlap is inside the launch:
-//   * the scene's blocks of 256 triangles are cut into up to kMpChunks CHUNKS (host: plan from the upload's exact count);
-//   * the grid is a sequence of SECTIONS of groups of eight workgroups (one per XCD): count(1) | count(2) with emit(1) | count(3)
-//     with emit(2) | ... | emit(K), the two kinds of group interleaved inside a section so that both are resident together: chunk
-//     k + 1 is counted WHILE chunk k is emitted, and only count(1) — a small chunk, one short generation — stays exposed;
-//   * an emitting workgroup of chunk k waits until every counting workgroup of chunk k has finished (done[k], one counter per
-//     chunk that only ever grows: the host passes the value it must reach).  Workgroups are dispatched in index order on every XCD and
-//     a workgroup only ever waits for workgroups of lower index — counting workgroups for their look-back predecessors, emitters for
-//     the counting workgroups of their chunk — so the lowest unfinished workgroup is always resident and runs: no deadlock (the
-//     assumption the single-pass kernels' look-back already makes).  Waits are bounded (kSpinLimit): a timeout is reported and the
-//     host repeats the conversion with the two kernels above.
-// What crosses from a counting to an emitting workgroup crosses XCDs: see co_store / co_load.  Same records at the same addresses.
-__global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_multipass(SceneDev sc, uint32_t R, uint32_t* __restrict__ off, uint32_t* __restrict__ start,
-                                                         uint32_t n_start, unsigned long long* __restrict__ chain, uint32_t epoch,
-                                                         unsigned long long* __restrict__ total_out, float4* __restrict__ setup,
-                                                         uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
-                                                         unsigned long long limit, float4* __restrict__ out, uint32_t run,
-                                                         unsigned long long* __restrict__ chunk_end /* [kMpChunks] */,
-                                                         unsigned long long* __restrict__ done /* [kMpChunks] */, MpPlan plan) {
-    __shared__ float4 lds_raw[sizeof(FineLds) / sizeof(float4)];
-    static_assert(kCountBlock == kBlock, "both roles run in workgroups of 256 threads");
-    // ---- which role? section, then the position of this group of eight inside it ----
-    uint32_t s_ = 0;
-#pragma unroll
-    for (int k = 1; k <= kMpChunks; ++k) if ((uint32_t)k <= plan.n_chunks && blockIdx.x >= plan.sec_first[k]) s_ = (uint32_t)k;
-    const uint32_t j = blockIdx.x - plan.sec_first[s_], g = j >> 3, lane8 = j & 7u;
-    const uint32_t nc = plan.n_cgroups[s_], ne = plan.n_egroups[s_];
-    // interleave: one counting group, then q emitting groups, ...; what is left over of either kind follows
-    bool counting;
-    uint32_t gi;                                // index of the group among the groups of its kind in this section
-    if (nc == 0) { counting = false; gi = g; }
-    else if (ne == 0) { counting = true; gi = g; }
-    else {
-        const uint32_t q = ne / nc, period = q + 1u;          // q >= 0 emitting groups after every counting group
-        const uint32_t paired = nc * period;                  // groups in the interleaved part
-        if (g < paired) { const uint32_t pr = g / period, r = g - pr * period; counting = r == 0u; gi = counting ? pr : pr * q + (r - 1u); }
-        else { counting = false; gi = nc * q + (g - paired); }
-    }
-    const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
-    if (counting) {
-        const uint32_t bid = plan.blk[s_] + gi * 8u + lane8;
-        if (bid >= plan.blk[s_ + 1u]) return;               // (the chunk's blocks rounded up to a whole group)
-        uint32_t* const words = reinterpret_cast<uint32_t*>(lds_raw);
-        const bool last_of_chunk = bid == plan.blk[s_ + 1u] - 1u;
-        count_scan_block<true>(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, words, words + 4,
-                               reinterpret_cast<unsigned long long*>(words + 8), last_of_chunk ? &chunk_end[s_] : nullptr);
-        // every store of this block has reached memory (they are write-through; vmcnt counts their acknowledgements) before it counts as done
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave: its stores have been acknowledged (by memory if write-through, else by the L2)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#if !M2S_CO_STORES
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // ONE write-back of this XCD's L2 per counting workgroup
-#endif
-            __hip_atomic_fetch_add(&done[s_], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    // ---- emitting workgroup of chunk c ----
-    const uint32_t c = s_ - 1u;
-    const uint32_t e = gi * 8u + lane8;
-    {   // wait for the chunk's counting workgroups (bounded): ONE lane of the workgroup polls — thousands of waves reading one word
-        // through to memory are a hot spot that slows the counting workgroups they wait for —, the others park at the barrier
-        uint32_t* const flag = reinterpret_cast<uint32_t*>(lds_raw);
-        if (threadIdx.x == 0) {
-            uint32_t spins = 0, ok = 1u;
-            const unsigned long long want = plan.done_target[c];
-            while (__hip_atomic_load(&done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                if (++spins > (kSpinLimit >> 2)) { ok = 0u; break; }
-                __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);      // (~7 us between polls)
-            }
-            if (!ok) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            *flag = ok;
-        }
-        __syncthreads();
-        const uint32_t ok = *flag;
-        __syncthreads();                                             // (the word is part of the emitters' LDS)
-        if (!ok) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (no load below may be moved above the wait)
-    }
-#ifdef M2S_MP_NO_EMIT
-    return;      // (timing experiment: what the counting part of the launch costs)
-#endif
-    EmitRange er;
-    er.t_lo = plan.blk[c] * (uint32_t)kCountBlock;
-    er.t_hi = min(plan.blk[c + 1u] * (uint32_t)kCountBlock, sc.n_tri);
-    er.rec_lo = c ? __hip_atomic_load(&chunk_end[c - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    er.rec_hi = __hip_atomic_load(&chunk_end[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    er.nw = er.rec_hi < limit ? er.rec_hi : limit;
-    if (er.rec_lo > er.nw) er.rec_lo = er.nw;
-    emit2_wg<true>(sc, off, start, er, setup, out, run, e, plan.n_slice_wg[c], status, c + 1u == plan.n_chunks, lds_raw);
-}
-
 // ---- launchers ---------------------------------------------------------------------------------------------------
 uint32_t emit2_slices(uint64_t limit) { return (uint32_t)((limit + kSlice - 1) / kSlice); }
 uint32_t count_scan_blocks(uint32_t n_tri) { return (n_tri + kCountBlock - 1) / kCountBlock; }
-size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (size_t)kTallCap * kTallChunks * sizeof(uint32_t) + (size_t)((count_scan_blocks(n_tri) + 63u) & ~63u) * sizeof(uint32_t); }
+size_t setup_bytes(uint32_t n_tri) { return setup_tall_offset(n_tri) + 16 + (size_t)kTallCap * kTallChunks * sizeof(uint32_t) + ((count_scan_blocks(n_tri) + 63u) & ~63u); }
 size_t setup_tall_offset(uint32_t n_tri) { return (size_t)std::max<uint32_t>(n_tri, 1u) * sizeof(TriSetup); }
 
 void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain,
@@ -744,24 +579,6 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
     n_blocks += (count_scan_blocks(sc.n_tri) + 7u) & ~7u;              // in front of them: one workgroup per block of triangles (the fine blocks)
     hipLaunchKernelGGL(k_emit2, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total, (unsigned long long)limit,
                        (const float4*)setup, out, run);
-}
-
-void launch_multipass(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* start, uint32_t n_start, unsigned long long* chain, uint32_t epoch,
-                      unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, uint64_t limit, float4* out,
-                      unsigned long long* mp_words, MpPlan& plan, hipStream_t st) {
-    if (!sc.n_tri || !plan.n_chunks) return;
-    // sections: s = 0 counts chunk 0; s = k counts chunk k beside the emitters of chunk k - 1; s = n_chunks emits the last chunk
-    uint32_t at = 0;
-    for (uint32_t s_ = 0; s_ <= plan.n_chunks; ++s_) {
-        plan.sec_first[s_] = at;
-        plan.n_cgroups[s_] = s_ < plan.n_chunks ? (plan.blk[s_ + 1] - plan.blk[s_] + 7u) / 8u : 0u;
-        plan.n_egroups[s_] = s_ ? ((((plan.blk[s_] - plan.blk[s_ - 1]) + 7u) & ~7u) + plan.n_slice_wg[s_ - 1]) / 8u : 0u;
-        at += 8u * (plan.n_cgroups[s_] + plan.n_egroups[s_]);
-    }
-    plan.sec_first[plan.n_chunks + 1] = at;
-    for (uint32_t s_ = plan.n_chunks + 2; s_ < kMpChunks + 2; ++s_) plan.sec_first[s_] = at;
-    hipLaunchKernelGGL(k_multipass, dim3(at), dim3(kBlock), 0, st, sc, R, off, start, n_start, chain, epoch & 0xFFFFu, total, (float4*)setup, status,
-                       total_host, (unsigned long long)limit, out, 16u, mp_words, mp_words + kMpChunks, plan);
 }
 
 // The multi-pass kernels keep a few spilled registers in scratch memory (12-32 bytes per lane), and the runtime sets a queue's scratch

@@ -184,25 +184,6 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
     if (c->pipeline == M2S_PIPELINE_AUTO && !ri.decided) decide(c, ri, (double)total, R);
     const uint64_t cap = resolve_cap(c, R);
     const bool single = c->pipeline != M2S_PIPELINE_MULTIPASS && !ri.multipass;
-    // multi-pass scenes: where the fragments are, block of 256 triangles by block — what the one-launch conversion is cut by (plan_chunks)
-    c->block_prefix.clear();
-    if (!single && !multipass_v1() && !debug_on("M2S_NO_MERGED")) {
-        const uint32_t n_tb = count_scan_blocks(sc.n_tri);
-        if (n_tb >= 32u && n_tb <= (1u << 18)) {
-            unsigned long long* tmp = nullptr;
-            if (hipMalloc((void**)&tmp, (size_t)n_tb * sizeof(unsigned long long)) == hipSuccess) {
-                launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, 256u, 0u, tmp, st);
-                try {
-                    c->block_prefix.resize((size_t)n_tb + 1);
-                    if (hipMemcpyAsync(c->block_prefix.data(), tmp, (size_t)n_tb * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                        hipStreamSynchronize(st) != hipSuccess) c->block_prefix.clear();
-                    else c->block_prefix[n_tb] = total;
-                } catch (...) { c->block_prefix.clear(); }
-                (void)hipFree(tmp);
-            }
-            (void)hipGetLastError();
-        }
-    }
     // the code object of the pipeline this scene is about to run: loaded here, not inside the first conversion of the process
     if (!debug_on("M2S_NO_PRELOAD")) {
         if (!single) { (void)preload_multipass(); if (!debug_on("M2S_NO_SCRATCH_WARM")) launch_scratch_warm(st); }
@@ -267,62 +248,6 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
     return M2S_OK;
 }
 
-// ---- the multi-pass conversion in ONE launch (k_multipass, m2s_emit2.hip) ---------------------------------------------------------
-// Chunks of blocks of 256 triangles: chunk k + 1 is counted while chunk k is emitted, only the first chunk's count stays exposed — so
-// the first chunk is small and the chunks grow.  Cut where the blend of "share of the blocks" (what counting costs) and "share of the
-// fragments" (what emitting costs) passes fixed marks; from the upload's exact count (block_prefix: fragments scale with R^2
-// everywhere alike, so the cuts serve every density).  The emitters of a chunk are sized from the same counts: exact at the density
-// the upload counted at, else with 4 % + 8192 records of room — a launch that falls short reports it and the conversion is repeated
-// with the two kernels (run_multipass).
-static bool plan_chunks(const m2s_ctx* c, m2s_ctx::RInfo& ri, uint32_t R) {
-    ri.mp_planned = true;
-    ri.mp_chunks = 0;
-    const size_t n_tb = c->block_prefix.size() ? c->block_prefix.size() - 1 : 0;
-    if (n_tb < 32 || n_tb != count_scan_blocks(c->scene.n_tri) || !c->warm_R || debug_on("M2S_NO_MERGED")) return false;
-    const double F = std::max<double>((double)c->block_prefix[n_tb], 1.0);
-    static const double marks_default[kMpChunks] = { 0.07, 0.18, 0.36, 0.62, 1.0, 1.0 };
-    double marks[kMpChunks];
-    int n_marks = 5;
-    for (int k = 0; k < kMpChunks; ++k) marks[k] = marks_default[k];
-    if (const char* v = debug_env("M2S_MP_MARKS")) {     // debug: A/B, e.g. "0.1,0.3,0.6,1"
-        n_marks = 0;
-        for (const char* q = v; *q && n_marks < kMpChunks;) { marks[n_marks++] = atof(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        if (!n_marks || marks[n_marks - 1] < 1.0) return false;
-    }
-    uint32_t nch = 0, at = 0;
-    ri.mp_blk[0] = 0;
-    for (int k = 0; k < n_marks && at < n_tb; ++k) {
-        uint32_t b = at;
-        if (marks[k] >= 1.0) b = (uint32_t)n_tb;
-        else {
-            // (cuts at multiples of 32 blocks: 128-byte lines of offsets, TriSetup records AND class words then belong to one chunk)
-            while (b < n_tb && 0.5 * (double)c->block_prefix[b] / F + 0.5 * (double)b / (double)n_tb < marks[k]) b += 32;
-            b = std::min<uint32_t>(b, (uint32_t)n_tb);
-        }
-        if (b <= at) continue;
-        at = b;
-        ri.mp_blk[++nch] = at;
-    }
-    if (at < n_tb) { if (nch == kMpChunks) ri.mp_blk[nch] = (uint32_t)n_tb; else ri.mp_blk[++nch] = (uint32_t)n_tb; }
-    if (nch < 2) return false;
-    // bounds on every chunk's record range (what its emitters are sized by, see mp_slice_workgroups)
-    const double scale = ((double)R * (double)R) / ((double)c->warm_R * (double)c->warm_R);
-    const bool exact = R == c->warm_R;
-    for (uint32_t k = 0; k < nch; ++k) {
-        const double lo = (double)c->block_prefix[ri.mp_blk[k]] * scale, hi = (double)c->block_prefix[ri.mp_blk[k + 1]] * scale;
-        ri.mp_est_lo[k] = exact ? (uint64_t)lo : (uint64_t)std::max(0.0, lo * 0.96 - 8192.0);
-        ri.mp_est_hi[k] = (exact ? (uint64_t)hi : (uint64_t)(hi * 1.04) + 8192u) + 1u;
-    }
-    ri.mp_chunks = nch;
-    return true;
-}
-// emitting workgroups of chunk k behind its fine-block ones, under this conversion's record limit: whole rounds of XCD turns (8 x 16)
-static uint32_t mp_slice_workgroups(const m2s_ctx::RInfo& ri, uint32_t k, uint64_t limit) {
-    const uint64_t e_hi = std::min<uint64_t>(ri.mp_est_hi[k], limit), e_lo = std::min<uint64_t>(ri.mp_est_lo[k], e_hi);
-    const uint64_t wgs = (e_hi + 2047u) / 2048u - e_lo / 2048u + 1u;
-    return (uint32_t)std::min<uint64_t>((wgs + 127u) / 128u * 128u, 1u << 22);
-}
-
 namespace m2s_host {
 // The second lane of asynchronous submissions (m2s_set_async_lanes(2)): its stream, its look-back chain and its record buffer,
 // allocated at its first use.  A record buffer that has become too small is replaced after every conversion still writing it has finished.
@@ -374,7 +299,6 @@ m2s_status ensure_second_lane_multipass(m2s_ctx* c, uint32_t n_start) {
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                                     unsigned long long* h_res, hipStream_t st, bool second_lane) {
     const SceneDev& sc = c->scene;
-    c->last_chunks = 0;
     if (second_lane) {   // the second lane's own work buffers (ensure_second_lane_multipass); second generation only
         uint32_t epoch;
         HIPCHK(c, next_epoch(c, &epoch));
@@ -398,36 +322,12 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
     } else {
         uint32_t epoch;
         HIPCHK(c, next_epoch(c, &epoch));
-        m2s_ctx::RInfo& ri = rinfo_for(c, R);
-        if (limit && !ri.mp_planned) (void)plan_chunks(c, ri, R);
-        if (ri.mp_chunks >= 2 && !ri.mp_merged_off && limit) {
-            // ONE launch: chunks counted and emitted in an interleaved grid (k_multipass)
-            if (!c->d_mp_words) {
-                HIPCHK(c, hipMalloc((void**)&c->d_mp_words, 2 * kMpChunks * sizeof(unsigned long long)));
-                HIPCHK(c, hipMemsetAsync(c->d_mp_words, 0, 2 * kMpChunks * sizeof(unsigned long long), st));
-                memset(c->mp_done, 0, sizeof c->mp_done);
-            }
-            MpPlan plan{};
-            plan.n_chunks = ri.mp_chunks;
-            for (uint32_t k = 0; k <= ri.mp_chunks; ++k) plan.blk[k] = ri.mp_blk[k];
-            for (uint32_t k = 0; k < ri.mp_chunks; ++k) {
-                plan.n_slice_wg[k] = mp_slice_workgroups(ri, k, limit);
-                c->mp_done[k] += plan.blk[k + 1] - plan.blk[k];
-                plan.done_target[k] = c->mp_done[k];
-            }
-            c->last_chunks = (int)ri.mp_chunks;
-            if (prof) { HIPCHK(c, hipEventRecord(c->ev[0], st)); HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
-            launch_multipass(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
-                             reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], limit, d_out, c->d_mp_words, plan, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-        } else {
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-            launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
-                              reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
-            if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
-            launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
-            if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-        }
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+        launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
+                          reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
+        if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
+        launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
     }
     HIPCHK(c, hipGetLastError());
     // (second generation: k_count_scan's last workgroup has written the counter to *h_res itself — no copy behind the pipeline)
@@ -442,22 +342,6 @@ static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t 
     c->h_total[0] = 0; c->h_total[1] = 0;
     { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
     HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
-    if (c->last_chunks && (c->h_total[1] >> 32)) {
-        // the one-launch conversion fell short (4: a chunk's emitters were sized from a prediction that did not hold — a density the
-        // upload did not count at) or a wait timed out (1): once more with the two kernels; remembered for this (scene, R)
-        const unsigned code = (unsigned)(c->h_total[1] >> 32);
-        m2s_ctx::RInfo& ri = rinfo_for(c, R);
-        ri.mp_merged_off = true;
-        if (debug_on("M2S_DEBUG")) fprintf(stderr, "[m2s] one-launch multi-pass conversion at R = %u reported %u: repeated with two kernels\n", R, code);
-        if (code != 4u && c->d_mp_words) {     // (after a timeout the done counters are not what the host thinks: start over)
-            HIPCHK(c, hipStreamSynchronize(st));
-            HIPCHK(c, hipMemsetAsync(c->d_mp_words, 0, 2 * kMpChunks * sizeof(unsigned long long), st));
-            memset(c->mp_done, 0, sizeof c->mp_done);
-        }
-        c->h_total[0] = 0; c->h_total[1] = 0;
-        { const m2s_status s = enqueue_multipass(c, R, d_out, limit, prof, c->h_total, st); if (s != M2S_OK) return s; }
-        HIPCHK(c, wait_stream(st));
-    }
     if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
     if (prof) {
         if (multipass_v1()) { for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
