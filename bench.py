@@ -311,7 +311,10 @@ class Rig:
             self.conv.set_triangle_range(*tri_range)
         self.conv.upload_scene(scene)
         self.conv.set_max_gaussians(cap)
-        self.stream = torch.cuda.current_stream().cuda_stream
+        # (caller-owned record buffers are converted into on a stream of the CALLER's: a non-blocking one of its own — torch's current
+        #  stream is the legacy default stream, whose launches synchronise with every blocking stream of the process, the exchange's included)
+        self._tstream = torch.cuda.Stream() if out_rows is not None else None
+        self.stream = self._tstream.cuda_stream if self._tstream is not None else torch.cuda.current_stream().cuda_stream
         self.out = None
         if out_rows is not None:        # caller-owned record buffer (multi-GPU: the block this rank contributes)
             if out_rows == 0:
@@ -584,6 +587,7 @@ def c5_workload(torch, local_rank, steps=8):
     conv = Converter(local_rank)
     conv.set_max_gaussians(0)          # (before the upload: it prepares the record pool for the conversion below)
     conv.set_resolution_hint(2048)
+    conv.set_keep_positions(True)      # BASELINE config 5 sorts what it converts: the conversion also leaves the 16-byte position plane (+16 B written per record, counted in its time)
     t0 = time.perf_counter()
     conv.upload_scene(scene)
     up_s = time.perf_counter() - t0
@@ -610,9 +614,10 @@ def c5_workload(torch, local_rank, steps=8):
         view = np.eye(4, dtype=np.float32)
         view[2, 3] = -6.0
         n = conv.sort_by_depth(view, download=False)          # (allocations, first touch of the buffers)
-        conv.convert(2048)                                    # new records at the same address: the position plane is stale
+        conv.convert(2048)                                    # new records at the same address: a plane left by an earlier SORT would be stale
+        plane_ready = conv.positions_ready
         conv.sort_by_depth(view, download=False)
-        first = {"ms": conv.last_sort_ms, **conv.last_sort_stage_ms}
+        first = {"ms": conv.last_sort_ms, **conv.last_sort_stage_ms, "keys_from": "the position plane the conversion left behind (m2s_set_keep_positions)" if plane_ready else "the records (96-byte stride)"}
         rep, stages = [], []
         for k in range(5):
             view[2, 3] = -6.0 - 0.25 * (k + 1)

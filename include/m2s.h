@@ -248,6 +248,14 @@ m2s_status m2s_dist_wait(m2s_dist* d, void* hip_stream);
  * glm), stable, and gathers the 96-byte records into a second context-owned buffer (radixSortGather.glsl).
  * *out_n = number of records sorted. */
 m2s_status m2s_sort_by_depth(m2s_ctx* ctx, const float world_to_view[16], uint64_t* out_n);
+/* A caller that is going to sort what it converts (BASELINE config 5: "final radix sort of the merged splat buffer") says so before
+ * converting: where the conversion kernel can (k_sparse: the scenes of tens of millions of records), it then also leaves the records'
+ * positions behind as a compact 16-byte plane, and the first m2s_sort_by_depth of those records builds its keys from 16 B per record
+ * instead of touching every 128-byte line of the 96-byte records (RadixSortPass.cpp:16-90 sorts every frame; this is the first frame).
+ * Costs the conversion 16 more bytes written per record; changes no record.  Default: off. */
+m2s_status m2s_set_keep_positions(m2s_ctx* ctx, int enabled);
+/* 1 if the position plane of the CURRENT records exists (left by their conversion, or by an earlier m2s_sort_by_depth of them). */
+int m2s_positions_ready(const m2s_ctx* ctx);
 const void* m2s_device_sorted_records(const m2s_ctx* ctx);
 const void* m2s_device_sorted_keys(const m2s_ctx* ctx);      /* uint32[n], ascending: the keys of those records */
 uint64_t m2s_num_sorted(const m2s_ctx* ctx);

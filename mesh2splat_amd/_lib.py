@@ -22,7 +22,7 @@ KERNEL_NAMES = ("count", "scan", "offsets", "emit", "fused")  # M2S_K_*
 # every symbol include/m2s.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "m2s_abi_version", "m2s_create", "m2s_destroy", "m2s_last_error", "m2s_set_triangle_range", "m2s_upload_scene",
-    "m2s_set_max_gaussians", "m2s_convert", "m2s_convert_into", "m2s_convert_submit", "m2s_convert_wait", "m2s_last_pipeline", "m2s_debug_set_launch_counter", "m2s_set_async_lanes", "m2s_num_stored", "m2s_device_records", "m2s_download",
+    "m2s_set_max_gaussians", "m2s_convert", "m2s_convert_into", "m2s_convert_submit", "m2s_convert_wait", "m2s_last_pipeline", "m2s_set_keep_positions", "m2s_positions_ready", "m2s_debug_set_launch_counter", "m2s_set_async_lanes", "m2s_num_stored", "m2s_device_records", "m2s_download",
     "m2s_download_triangle_counts", "m2s_write_ply", "m2s_export_ply", "m2s_set_profiling", "m2s_last_kernel_ms",
     "m2s_num_triangles", "m2s_set_pipeline", "m2s_load_glb", "m2s_free_host_scene", "m2s_host_scene_num_meshes",
     "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
@@ -124,6 +124,8 @@ def load():
         "m2s_download_sorted_quads": (C.c_int, [vp, vp, u64]),
         "m2s_last_sort_prepass_ms": (C.c_float, [vp]),
         "m2s_last_pipeline": (C.c_int, [vp]),
+        "m2s_set_keep_positions": (C.c_int, [vp, C.c_int]),
+        "m2s_positions_ready": (C.c_int, [vp]),
         "m2s_debug_set_launch_counter": (C.c_int, [vp, u32]),
         "m2s_set_async_lanes": (C.c_int, [vp, C.c_int]),
         "m2s_num_stored": (u64, [vp]),

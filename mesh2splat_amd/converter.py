@@ -183,6 +183,15 @@ class Converter:
         current records, zero copy (m2s_set_records)."""
         self._check(self._L.m2s_set_records(self._h, C.c_void_p(device_ptr or None), int(n), int(R)))
 
+    def set_keep_positions(self, on: bool):
+        """Say before converting that the records will be depth-sorted: the sparse kernel then also writes the 16-byte position plane."""
+        self._check(self._L.m2s_set_keep_positions(self._h, 1 if on else 0))
+
+    @property
+    def positions_ready(self) -> bool:
+        """the 16-byte position plane of the current records exists (left by their conversion or by an earlier depth sort)"""
+        return bool(self._L.m2s_positions_ready(self._h))
+
     def sort_by_depth(self, world_to_view, download: bool = True):
         """RadixSortPass: sort the last conversion's records by floatBitsToUint(view-space z); returns them (or, with
         download=False, their number: the sorted records stay on the device).

@@ -63,12 +63,12 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
         if (d_records) { limit = cap ? std::min(cap, capacity_records) : capacity_records; d_out = d_records; }
         else { limit = cap ? cap : c->records_cap; d_out = c->d_records; }
         if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
-        const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
-        if (c->start_cap >= n_start && (multipass_v1() || c->d_setup)) {
+        const uint32_t n_start = emit2_slices(limit);
+        if (c->start_cap >= n_start && c->d_setup) {
             // odd slots of a two-lane context: the second lane, with work buffers of its own — nothing is shared with the
             // conversion before it, so its k_count_scan runs beside that conversion's k_emit2
             bool second_lane = false;
-            if (!d_records && (k & 1u) && c->lanes == 2 && !multipass_v1()) {
+            if (!d_records && (k & 1u) && c->lanes == 2) {
                 { const m2s_status s2 = ensure_second_lane(c); if (s2 != M2S_OK) return s2; }
                 { const m2s_status s2 = ensure_second_lane_multipass(c, n_start); if (s2 != M2S_OK) return s2; }
                 st = c->stream_b;

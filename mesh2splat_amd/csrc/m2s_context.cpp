@@ -248,6 +248,17 @@ m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
 
 int m2s_last_pipeline(const m2s_ctx* c) { return c ? c->last_pipeline : 0; }
 
+int m2s_positions_ready(const m2s_ctx* c) {
+    return c && c->d_pos_plane && c->last_records && c->pos_plane_of == c->last_records && c->pos_plane_n == c->last_stored &&
+           c->pos_plane_epoch == c->records_epoch && c->last_stored ? 1 : 0;
+}
+
+m2s_status m2s_set_keep_positions(m2s_ctx* c, int enabled) {
+    if (!c) return M2S_ERR_INVALID;
+    c->keep_positions = enabled != 0;
+    return M2S_OK;
+}
+
 m2s_status m2s_debug_set_launch_counter(m2s_ctx* c, uint32_t value) {
     if (!c) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");

@@ -144,6 +144,7 @@ struct m2s_ctx {
     void* d_pos_plane = nullptr;
     uint64_t pos_plane_cap = 0, pos_plane_n = 0, pos_plane_epoch = 0;
     const void* pos_plane_of = nullptr;
+    bool keep_positions = false;      // m2s_set_keep_positions: conversions leave the plane behind themselves where their kernel can (k_sparse)
     uint64_t records_epoch = 1;       // advances whenever the records behind last_records may have changed
     // viewer prepass (m2s_prepass): survivors, their depths, the look-back chain of its kernel, a copy of the depth image
     void* d_quads = nullptr;
@@ -213,7 +214,6 @@ bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
 m2s::BatchTable batches_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
-bool multipass_v1();
 m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                              unsigned long long* h_res, hipStream_t st, bool second_lane = false);

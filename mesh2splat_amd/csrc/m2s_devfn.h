@@ -750,12 +750,6 @@ __device__ __forceinline__ void tex_finish(const TexFetch& tf, const TexState& s
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) out[ch] = fma_(f, hi[ch], nf * lo[ch]) * kUnorm8;
 }
-template <int NCH>
-__device__ __forceinline__ void tex_sample(const uint32_t* __restrict__ texels, const TexState& st, float out[NCH]) {
-    TexFetch tf;
-    tex_issue(texels, st, tf);
-    tex_finish<NCH>(tf, st, out);
-}
 
 // ---- combo path -----------------------------------------------------------------------------------
 
@@ -1008,29 +1002,6 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
     rec[3] = make_float4(ox, oy, oz, 0.0f);
     rec[4] = ts.rot;
     rec[5] = make_float4(metal, rough, 0.0f, 1.0f);
-}
-
-// Everything the GS + rasteriser + FS produce for ONE fragment (multi-pass emit: per-triangle part recomputed).
-template <class MP>
-__device__ __forceinline__ void shade_fragment_mp(const SceneDev& sc, uint32_t t, int x, int y, MP mp, uint32_t R, float4 rec[6]) {
-    const TriPlanes& tp = sc.tri;
-    float p[9];
-    load_positions(tp, t, p);
-    const float bmin[3] = { mp->bmin[0], mp->bmin[1], mp->bmin[2] }, bmax[3] = { mp->bmax[0], mp->bmax[1], mp->bmax[2] };
-    Geo g;
-    geo_setup(p, bmin, bmax, g);
-    Raster rs;
-    raster_setup(g, R, rs);
-    TriShade ts;
-    tri_shade_setup(p, g, rs, mp, tp.B0[t], tp.B1[t], ts);
-    shade_from_tri(tp, t, x, y, mp, ts, rec);
-}
-// Two instantiations on purpose (see k_fused): a wave-uniform mesh gets the constant-address-space pointer and with it
-// scalar descriptor loads; otherwise the mesh is looked up per lane.
-__device__ __forceinline__ void shade_fragment(const SceneDev& sc, uint32_t t, int x, int y, uint32_t mesh_hint,
-                                               bool uniform_mesh, uint32_t R, float4 rec[6]) {
-    if (uniform_mesh) shade_fragment_mp(sc, t, x, y, kConstMesh(sc.meshes + mesh_hint), R, rec);
-    else shade_fragment_mp(sc, t, x, y, sc.meshes + find_mesh(sc, sc.tri_first + t), R, rec);
 }
 
 // Record stores are non-temporal: the records are never re-read by the conversion; keeping them out of the 4 MiB L2

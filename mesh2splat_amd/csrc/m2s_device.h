@@ -18,9 +18,9 @@ inline bool debug_on(const char* name) { const char* v = debug_env(name); return
 
 // ---- launch geometry ----------------------------------------------------------------------
 constexpr int kBlock = 256;              // 4 wave64 per workgroup
-constexpr int kTriPerBlock = 1024;       // triangles per workgroup in the count / offsets kernels
-constexpr int kEmitF = 1024;             // output records per workgroup in the emit kernel
-constexpr int kRowsThread = 32;          // k_emit: triangles with more pixel rows are expanded wave-cooperatively
+constexpr int kTriPerBlock = 1024;       // triangles per workgroup in the upload's count kernel
+constexpr int kEmitF = 1024;             // output records per workgroup of k_emit_big
+constexpr int kRowsThread = 32;          // k_emit2: triangles with more pixel rows are expanded wave-cooperatively
 constexpr int kRowsCount = 128;          // k_count: triangles with more pixel rows are counted wave-cooperatively
 constexpr int kStageStride = 7;          // float4 per staged record in LDS (6 + 1 pad: conflict-free b128)
 
@@ -106,12 +106,7 @@ void launch_unit_bases(const uint32_t* cnt, const uint32_t* partials, uint32_t n
 // n_slots = runs rounded up to whole groups of eight (slots past the last run map to themselves: their workgroups exit at once).
 void launch_run_order(const unsigned long long* run_base, uint32_t n_runs, const unsigned long long* total, uint32_t* order, uint32_t n_slots, hipStream_t st);
 inline uint32_t run_order_slots(uint32_t n_units, uint32_t shift) { return ((n_units + (8u << shift) - 1u) / (8u << shift)) * 8u; }
-void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
-                    uint32_t n_start, hipStream_t st);
-void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
-                 const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st);
-
-// second-generation multi-pass pipeline (m2s_emit2.hip): count + scan + offsets in one kernel, wave-granular emit
+// multi-pass pipeline (m2s_emit2.hip): count + scan + offsets in one kernel, wave-granular emit
 uint32_t emit2_slices(uint64_t limit);       // entries of start[] needed for `limit` output records
 uint32_t count_scan_blocks(uint32_t n_tri);  // chain words k_count_scan uses
 size_t setup_bytes(uint32_t n_tri);          // per-triangle TriSetup array + the tall-triangle table behind it
@@ -173,9 +168,10 @@ void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
                    const RunInfo& runs, const BatchTable& batches, hipStream_t st);
 // sparse form of the single-pass kernel (m2s_sparse.hip); `runs` as for launch_fused2, in ITS units (512 triangles)
+// plane (or nullptr): the positions of the records as a compact plane (16 B each, record order): what a depth sort builds its keys from
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
                    unsigned long long* total, uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta,
-                   const RunInfo& runs, hipStream_t st);
+                   const RunInfo& runs, hipStream_t st, float4* plane = nullptr);
 bool sparse_supported(uint32_t n_tri);
 uint32_t sparse_workgroups(uint32_t n_tri);   // workgroups of kSpCand = 512 triangles
 constexpr uint32_t kSparseTrianglesPerWorkgroup = 512;

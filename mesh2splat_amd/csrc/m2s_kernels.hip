@@ -3,13 +3,11 @@
 //   src/shaders/conversion/converterVS.glsl, converterGS.glsl:326-443, converterFS.glsl:44-104
 // driven by ConversionPass::execute (src/renderer/renderPasses/ConversionPass.cpp:9-117).
 //
-// Pipeline (one stream, no host round trip until the final counter read-back):
-//   k_count    1 thread / triangle : GS setup + exact fragment count (closed-form row spans)
-//   k_scan     1 workgroup         : exclusive scan of the per-1024-triangle partial sums
-//   k_offsets  1 thread / triangle : per-triangle output offsets + emit-block start table
-//   k_emit     1 thread / Gaussian : load-balanced expansion (triangle -> pixels) through LDS, full
-//                                    GS+FS math per fragment, 96 B records staged in LDS and
-//                                    written with fully coalesced 16 B/lane stores.
+// What lives here: the upload-time kernels (repack, mips, combo textures, mesh table), the exact count the upload takes
+// (k_count + k_scan_partials: AUTO's decision, run tables, m2s_download_triangle_counts) with its by-products (k_big_share,
+// k_unit_bases, k_run_order), and k_emit_big, the second stage of the single-pass kernels for triangles they defer.  The
+// conversion kernels proper are m2s_fused*.hip, m2s_sparse.hip (single pass) and m2s_emit2.hip (multi-pass); the first-
+// generation multi-pass emission that started here in round 1 (k_offsets, k_emit) was removed in round 6 (tag r5-final has it).
 // Output order is deterministic: (mesh, triangle, pixel row, pixel column) — the reference's order
 // is atomic-arrival order (converterFS.glsl:46), i.e. unspecified.
 //
@@ -281,219 +279,6 @@ __global__ void __launch_bounds__(kBlock) k_run_order(const unsigned long long* 
 void launch_run_order(const unsigned long long* run_base, uint32_t n_runs, const unsigned long long* total, uint32_t* order, uint32_t n_slots, hipStream_t st) {
     if (!n_slots) return;
     hipLaunchKernelGGL(k_run_order, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, st, run_base, n_runs, total, order, n_slots);
-}
-
-// ============================================================================================
-// K_offsets: off[t] = exclusive prefix of cnt; start[m] = triangle that owns output index m*kEmitF
-// ============================================================================================
-__global__ void __launch_bounds__(kBlock) k_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ partials,
-                                                    uint32_t n_tri, uint32_t* __restrict__ off, uint32_t* __restrict__ start,
-                                                    uint32_t n_start) {
-    __shared__ uint32_t wsum[kBlock / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blockBase = blockIdx.x * kTriPerBlock;
-    uint32_t run = partials[blockIdx.x];
-    for (int it = 0; it < kTriPerBlock / kBlock; ++it) {
-        const uint32_t t = blockBase + it * kBlock + threadIdx.x;
-        const uint32_t c = t < n_tri ? cnt[t] : 0;
-        uint32_t incl = wave_incl_scan(c, lane);
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            if (w < wave) woff += wsum[w];
-            tot += wsum[w];
-        }
-        const uint32_t o0 = run + woff + incl - c;
-        if (t < n_tri) {
-            off[t] = o0;
-            if (t == n_tri - 1) off[n_tri] = o0 + c;
-            if (c) {
-                const uint32_t mf = (o0 + kEmitF - 1) / kEmitF, ml = (o0 + c - 1) / kEmitF;
-                for (uint32_t m = mf; m <= ml && m < n_start; ++m) start[m] = t;
-            }
-        }
-        run += tot;
-        __syncthreads();
-    }
-}
-
-void launch_offsets(const uint32_t* cnt, const uint32_t* partials, uint32_t n_tri, uint32_t* off, uint32_t* start,
-                    uint32_t n_start, hipStream_t st) {
-    if (!n_tri) return;
-    hipLaunchKernelGGL(k_offsets, dim3(n_count_blocks(n_tri)), dim3(kBlock), 0, st, cnt, partials, n_tri, off, start,
-                       n_start);
-}
-
-// GS + raster setup + the fragment stage's per-triangle constants of triangle t (mesh looked up per lane)
-__device__ __forceinline__ bool setup_full_for(const SceneDev& sc, uint32_t t, uint32_t R, Raster& rs, TriShade& ts) {
-    float p[9];
-    load_positions(sc.tri, t, p);
-    const uint32_t m = find_mesh(sc, sc.tri_first + t);
-    const MeshParams* mp = sc.meshes + m;
-    Geo g;
-    geo_setup(p, mp->bmin, mp->bmax, g);
-    if (!raster_setup(g, R, rs)) return false;
-    tri_shade_setup(p, g, rs, mp, sc.tri.B0[t], sc.tri.B1[t], ts);
-    ts.mesh |= m;
-    return true;
-}
-
-// ============================================================================================
-// K2: emit.  Workgroup b owns output records [b*kEmitF, (b+1)*kEmitF).
-//
-// The triangles that overlap a workgroup's slice are set up ONCE, in the expansion phase (one thread per
-// triangle), and their fragment constants (TriShade) kept in an LDS table of kEmitTab entries; the fragment
-// phase then runs only the per-fragment code.  With mid-size triangles (tens of fragments each: a coarse mesh
-// at high density) that removes the per-fragment repetition of the whole GS + raster setup, which was more than
-// half of this kernel's instructions.  A slice overlapped by more than kEmitTab triangles (tiny triangles) falls
-// back to per-fragment setup for the whole workgroup — those scenes run the fused kernel anyway.
-// ============================================================================================
-constexpr uint32_t kEmitTab = 128;
-__global__ void __launch_bounds__(kBlock, 3) k_emit(SceneDev sc, uint32_t R, const uint32_t* __restrict__ off,
-                                                 const uint32_t* __restrict__ start,
-                                                 const unsigned long long* __restrict__ total_p, unsigned long long limit,
-                                                 float4* __restrict__ out) {
-    __shared__ uint2 entries[kEmitF];                 // (triangle, table slot << 24 | y << 12 | x)
-    __shared__ float4 stage[kBlock * kStageStride];   // 28 KiB
-    __shared__ uint32_t wrow_off[kBlock / 64][64];
-    __shared__ int wrow_xa[kBlock / 64][64];
-    __shared__ float4 tstab[kEmitTab * 5];            // TriShade of the triangles overlapping this slice (10 KiB)
-    __shared__ uint32_t wact[kBlock / 64];            // active triangles per wave in the current batch
-
-    const unsigned long long total = *total_p;
-    const unsigned long long nw = total < limit ? total : limit;  // records actually stored
-    // XCD-aware mapping: hardware places workgroup b on XCD b % 8 and each XCD has a private 4 MiB L2.
-    // Give every XCD one CONTIGUOUS slice of the output (hence of the mesh surface and of texture
-    // space) instead of every 8th block, so texture / vertex lines are fetched by one L2, not eight.
-    const uint32_t nblk = (uint32_t)((nw + kEmitF - 1) / kEmitF);
-    const uint32_t per_xcd = (nblk + 7) / 8;
-    const uint32_t lblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || lblock >= nblk) return;
-    const unsigned long long base64 = (unsigned long long)lblock * kEmitF;
-    const uint32_t base = (uint32_t)base64;
-    const uint32_t end = (uint32_t)(nw - base64 < (unsigned long long)kEmitF ? nw : base64 + kEmitF);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t T = sc.n_tri;
-
-    // ---- phase A: expand triangles into (triangle, pixel) entries, in canonical order ----
-    const uint32_t t_first = start[lblock];
-    const uint32_t m0 = find_mesh(sc, sc.tri_first + t_first);
-    uint32_t t_last_seen = t_first;
-    uint32_t n_tab = 0;   // triangles set up so far (workgroup-uniform); > kEmitTab = table overflow
-    for (uint32_t tc = t_first;; tc += kBlock) {
-        const uint32_t t = tc + threadIdx.x;
-        uint32_t o0 = 0, o1 = 0;
-        if (t < T) { o0 = off[t]; o1 = off[t + 1]; }
-        const bool active = (o1 > o0) && (o0 < end) && (o1 > base);
-        Raster rs;
-        TriShade ts;
-        bool ok = false;
-        if (active) ok = setup_full_for(sc, t, R, rs, ts);
-        // table slot = rank of this triangle among the slice's triangles
-        const unsigned long long okm = __ballot(ok);
-        if (lane == 0) wact[wave] = (uint32_t)__popcll(okm);
-        __syncthreads();
-        uint32_t slot = n_tab + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) slot += wact[w];
-        n_tab += wact[0] + wact[1] + wact[2] + wact[3];
-        __syncthreads();   // wact is rewritten by the next batch
-        if (ok && slot < kEmitTab) {
-            const float4* src4 = reinterpret_cast<const float4*>(&ts);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) tstab[slot * 5 + k] = src4[k];
-        }
-        const uint32_t stag = (slot & 0xFFu) << 24;
-        const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
-        if (ok && rows <= kRowsThread) {
-            uint32_t k = o0;
-            RowWalker rw;
-            row_walker_init(rs, rs.y0, rw);
-            for (int y = rs.y0; y <= rs.y1 && k < end; ++y) {
-                int xa, xb;
-                row_walker_next(rw, xa, xb);
-                for (int x = xa; x <= xb; ++x, ++k)
-                    if (k >= base && k < end) entries[k - base] = make_uint2(t, stag | ((uint32_t)y << 12) | (uint32_t)x);
-            }
-        }
-        unsigned long long big = __ballot(ok && rows > kRowsThread);
-        while (big) {
-            const int src = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            const Raster b = shfl_raster(rs, src);
-            const uint32_t bt = __shfl(t, src), btag = __shfl(stag, src);
-            uint32_t acc = __shfl(o0, src);
-            for (int yc = b.y0; yc <= b.y1 && acc < end; yc += 64) {
-                const int y = yc + lane;
-                int xa = 0, xb = -1;
-                if (y <= b.y1) row_span(b, y, xa, xb);
-                const uint32_t len = (uint32_t)max(xb - xa + 1, 0);
-                const uint32_t incl = wave_incl_scan(len, lane);
-                const uint32_t chunk = __shfl(incl, 63);
-                if (acc + chunk > base) {
-                    wave_lds_sync();
-                    wrow_off[wave][lane] = incl - len;
-                    wrow_xa[wave][lane] = xa;
-                    wave_lds_sync();
-                    const uint32_t lo = acc < base ? base - acc : 0;
-                    const uint32_t hi = acc + chunk > end ? end - acc : chunk;
-                    for (uint32_t k = lo + lane; k < hi; k += 64) {
-                        int r = 0;  // largest r with wrow_off[r] <= k
-#pragma unroll
-                        for (int step = 32; step >= 1; step >>= 1)
-                            if (wrow_off[wave][r + step] <= k) r += step;
-                        const int x = wrow_xa[wave][r] + (int)(k - wrow_off[wave][r]);
-                        entries[acc + k - base] = make_uint2(bt, btag | ((uint32_t)(yc + r) << 12) | (uint32_t)x);
-                    }
-                }
-                acc += chunk;
-            }
-        }
-        t_last_seen = min(tc + kBlock - 1, T - 1);
-        if (tc + kBlock >= T) break;
-        if (off[tc + kBlock] >= end) break;
-    }
-    const uint32_t m1 = find_mesh(sc, sc.tri_first + t_last_seen);
-    const bool uniform_mesh = (m0 == m1);
-    __syncthreads();
-
-    // ---- phase B: one thread per Gaussian; records staged in LDS, then 16 B/lane coalesced stores ----
-    const uint32_t n_here = end - base;
-    const bool use_tab = n_tab <= kEmitTab;   // workgroup-uniform
-    for (uint32_t e0 = 0; e0 < n_here; e0 += kBlock) {
-        const uint32_t e = e0 + threadIdx.x;
-        if (e < n_here) {
-            const uint2 en = entries[e];
-            const int px = (int)(en.y & 0xFFFu), py = (int)((en.y >> 12) & 0xFFFu);
-            float4 rec[6];
-            if (use_tab) {
-                const TriShade& tsr = *reinterpret_cast<const TriShade*>(&tstab[(en.y >> 24) * 5]);
-                if (uniform_mesh) shade_from_tri(sc.tri, en.x, px, py, kConstMesh(sc.meshes + m0), tsr, rec);
-                else shade_from_tri(sc.tri, en.x, px, py, sc.meshes + (tsr.mesh & 0xFFFFFFu), tsr, rec);
-            } else {
-                shade_fragment(sc, en.x, px, py, m0, uniform_mesh, R, rec);
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) stage[threadIdx.x * kStageStride + k] = rec[k];
-        }
-        __syncthreads();
-        const uint32_t nrec = min((uint32_t)kBlock, n_here - e0);
-        float4* __restrict__ dst = out + ((size_t)base + e0) * 6;
-        for (uint32_t q = threadIdx.x; q < nrec * 6; q += kBlock) {
-            const uint32_t r = q / 6, k = q - r * 6;
-            nt_store(&dst[q], stage[r * kStageStride + k]);
-        }
-        __syncthreads();
-    }
-}
-
-void launch_emit(const SceneDev& sc, uint32_t R, const uint32_t* off, const uint32_t* start,
-                 const unsigned long long* total, uint64_t limit, float4* out, uint32_t n_blocks, hipStream_t st) {
-    if (!n_blocks || !sc.n_tri) return;
-    n_blocks = (n_blocks + 7u) & ~7u;  // the XCD swizzle needs whole groups of 8
-    hipLaunchKernelGGL(k_emit, dim3(n_blocks), dim3(kBlock), 0, st, sc, R, off, start, total,
-                       (unsigned long long)limit, out);
 }
 
 // ============================================================================================

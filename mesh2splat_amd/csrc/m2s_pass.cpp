@@ -224,15 +224,11 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
 }
 }  // namespace m2s_host
 
-// Multi-pass pipeline: handles every triangle size, output-balanced.  Second generation (m2s_emit2.hip): k_count_scan
-// (count + offsets + per-triangle setup records, one kernel) -> k_emit2 (wave-granular).  M2S_MULTIPASS_V1=1 selects the
-// first generation (count -> scan -> offsets -> emit, m2s_kernels.hip) for A/B measurements.
-namespace m2s_host {
-bool multipass_v1() { static const bool v1 = debug_env("M2S_MULTIPASS_V1") != nullptr; return v1; }
-}
+// Multi-pass pipeline: handles every triangle size, output-balanced (m2s_emit2.hip): k_count_scan (count + offsets + per-triangle
+// setup records, one kernel) -> k_emit2 (wave-granular).
 
 static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
-    const uint32_t n_start = multipass_v1() ? (uint32_t)((limit + kEmitF - 1) / kEmitF) : emit2_slices(limit);
+    const uint32_t n_start = emit2_slices(limit);
     if (c->start_cap < n_start) {
         drain_in_flight(c);
         if (c->d_start) { (void)hipFree(c->d_start); c->d_start = nullptr; c->start_cap = 0; }
@@ -240,7 +236,7 @@ static m2s_status ensure_multipass_buffers(m2s_ctx* c, uint64_t limit) {
         HIPCHK(c, hipMalloc((void**)&c->d_start, want * sizeof(uint32_t)));
         c->start_cap = want;
     }
-    if (!multipass_v1() && !c->d_setup) {
+    if (!c->d_setup) {
         HIPCHK(c, hipMalloc(&c->d_setup, setup_bytes(c->scene.n_tri)));
         HIPCHK(c, hipMemsetAsync((char*)c->d_setup + setup_tall_offset(c->scene.n_tri), 0, 16, c->stream));   // the tall-triangle table's slot counter
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -308,30 +304,16 @@ m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t lim
         HIPCHK(c, hipGetLastError());
         return M2S_OK;
     }
-    if (multipass_v1()) {
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-        launch_count(sc, R, c->d_cnt, c->d_partials, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
-        launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
-        const uint32_t n_blocks = (uint32_t)((limit + kEmitF - 1) / kEmitF);
-        launch_offsets(c->d_cnt, c->d_partials, sc.n_tri, c->d_off, c->d_start, n_blocks, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
-        launch_emit(sc, R, c->d_off, c->d_start, c->d_total, limit, d_out, n_blocks, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-    } else {
-        uint32_t epoch;
-        HIPCHK(c, next_epoch(c, &epoch));
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
-        launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
-                          reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
-        if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
-        launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
-        if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
-    }
+    uint32_t epoch;
+    HIPCHK(c, next_epoch(c, &epoch));
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_count_scan(sc, R, c->d_off, c->d_start, emit2_slices(limit), c->d_chain, epoch, c->d_total, c->d_setup,
+                      reinterpret_cast<uint32_t*>(&h_res[1]), &h_res[0], st);
+    if (prof) { HIPCHK(c, hipEventRecord(c->ev[1], st)); HIPCHK(c, hipEventRecord(c->ev[3], st)); }
+    launch_emit2(sc, R, c->d_off, c->d_start, c->d_total, limit, c->d_setup, d_out, st);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[4], st));
     HIPCHK(c, hipGetLastError());
-    // (second generation: k_count_scan's last workgroup has written the counter to *h_res itself — no copy behind the pipeline)
-    if (multipass_v1()) HIPCHK(c, hipMemcpyAsync(&h_res[0], c->d_total, 8, hipMemcpyDeviceToHost, st));
+    // (k_count_scan's last workgroup has written the counter to *h_res itself — no copy behind the pipeline)
     return M2S_OK;
 }
 }
@@ -344,11 +326,8 @@ static m2s_status run_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t 
     HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
     if (c->h_total[1] >> 32) return fail(c, M2S_ERR_HIP, "multi-pass pipeline: look-back chain timed out");
     if (prof) {
-        if (multipass_v1()) { for (int k = 0; k < 4; ++k) HIPCHK(c, hipEventElapsedTime(&c->last_ms[k], c->ev[k], c->ev[k + 1])); }
-        else {
-            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_COUNT], c->ev[0], c->ev[1]));
-            HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
-        }
+        HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_COUNT], c->ev[0], c->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_EMIT], c->ev[3], c->ev[4]));
     }
     return M2S_OK;
 }
@@ -411,6 +390,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     }
     if (limit > 0xFFFFFFFFull) limit = 0xFFFFFFFFull;
 
+    bool wrote_plane = false;      // the last single-pass launch also wrote the position plane (k_sparse, m2s_set_keep_positions)
     for (int round = 0; round < 2; ++round) {
     // ---- run ---------------------------------------------------------------------------------------
     bool done = false;
@@ -420,6 +400,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         // counter and its two status words straight into pinned host memory.
         uint32_t any_big = 0, err = 0;
         bool wrote_bands = false;
+        wrote_plane = false;
         for (int attempt = 0; attempt < 4; ++attempt) {
             const bool sparse = use_sparse(c, ri);
             const bool team = !sparse && use_team(c, ri);
@@ -431,8 +412,20 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
             const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
             const RunInfo runs = (sparse || team) ? bands_for(c, ri, unit, true, &wrote_bands) : RunInfo{ nullptr, nullptr, 0u, nullptr };
+            // m2s_set_keep_positions: the sparse kernel — the one that runs on scenes of tens of millions of records, where a depth sort
+            // is worth preparing for — also writes the records' positions as a 16-byte plane (the context's, grown here if need be)
+            float4* plane = nullptr;
+            if (sparse && c->keep_positions && st == c->stream) {
+                if (c->pos_plane_cap < limit) {
+                    if (c->d_pos_plane) { (void)hipFree(c->d_pos_plane); c->d_pos_plane = nullptr; c->pos_plane_cap = 0; }
+                    if (hipMalloc(&c->d_pos_plane, limit * 16) == hipSuccess) c->pos_plane_cap = limit; else (void)hipGetLastError();
+                }
+                c->pos_plane_n = 0;
+                plane = (float4*)c->d_pos_plane;
+            }
+            wrote_plane = plane != nullptr;
             if (sparse) launch_sparse(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                      c->d_biglist, c->d_bigmeta, runs, st);
+                                      c->d_biglist, c->d_bigmeta, runs, st, plane);
             else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
             else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
@@ -542,6 +535,10 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
     c->last_stored = std::min(total, limit);
     c->last_records = d_out;
     ++c->records_epoch;
+    // the plane is these records' if the sparse kernel wrote every one of them (no deferred triangle went to k_emit_big, no fallback ran)
+    if (wrote_plane && c->last_pipeline == M2S_PIPELINE_SPARSE && !c->h_total[1] && c->d_pos_plane) {
+        c->pos_plane_of = d_out; c->pos_plane_n = c->last_stored; c->pos_plane_epoch = c->records_epoch;
+    }
     if (!d_user) { if (c->buf_R[0] != R) { c->buf_R[0] = R; ++c->buf_gen[0]; } }
     if (out_total) *out_total = total;
     return M2S_OK;

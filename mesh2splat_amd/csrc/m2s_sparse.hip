@@ -188,7 +188,8 @@ __device__ __forceinline__ bool sp_get_base(SpLds& S, const unsigned long long* 
 __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain, unsigned long long limit,
                                                          float4* __restrict__ out, unsigned long long* __restrict__ total_out,
                                                          uint32_t* __restrict__ status /* [0]=any big, [1]=error */, uint32_t epoch,
-                                                         BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta, RunInfo runs) {
+                                                         BigItem* __restrict__ biglist, uint32_t* __restrict__ bigmeta, RunInfo runs,
+                                                         float4* __restrict__ plane /* or nullptr: positions of the records, 16 B each (m2s_set_keep_positions) */) {
     __shared__ SpLds S;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -576,6 +577,9 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
                 if (o0 >= limit) nvalid = 0;
                 else if (limit - o0 < nvalid) nvalid = (uint32_t)(limit - o0);
             }
+            // the caller is going to sort these records by depth: their positions also go to a compact plane (one coalesced 1 KB store
+            // per strip) — the sort's key pass then reads 16 B per record instead of every 128-byte line of the 96-byte records
+            if (plane != nullptr && (uint32_t)lane < nvalid) nt_store(&plane[o0 + (uint32_t)lane], rec[0]);
 #pragma unroll 1
             for (int part = 0; part < 64 / kSpStage; ++part) {
                 if (have && (lane / kSpStage) == part) {
@@ -599,6 +603,7 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
                 float4* __restrict__ dsto = out + oidx * 6;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) nt_store(&dsto[k], rec[k]);
+                if (plane != nullptr) nt_store(&plane[oidx], rec[0]);
             }
         }
     }
@@ -637,14 +642,14 @@ __global__ void __launch_bounds__(kSpThreads, 3) k_sparse(SceneDev sc, uint32_t 
 }
 
 void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out, unsigned long long* total,
-                   uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, const RunInfo& runs, hipStream_t st) {
+                   uint32_t* status, uint32_t epoch, BigItem* biglist, uint32_t* bigmeta, const RunInfo& runs, hipStream_t st, float4* plane) {
     if (!sc.n_tri) return;
     const uint32_t n_wg = sparse_workgroups(sc.n_tri);
     uint32_t nb = (n_wg + 7u) & ~7u;
     RunInfo r = runs;
     if (r.base) { nb = ((n_wg + (8u << r.shift) - 1u) / (8u << r.shift)) * (8u << r.shift); r.out = nullptr; }
     hipLaunchKernelGGL(k_sparse, dim3(nb), dim3(kSpThreads), 0, st, sc, R, chain, (unsigned long long)limit, out, total, status,
-                       epoch & 0xFFFFu, biglist, bigmeta, r);
+                       epoch & 0xFFFFu, biglist, bigmeta, r, plane);
 }
 
 bool sparse_supported(uint32_t n_tri) { return fused_tpw(n_tri) == 64u; }

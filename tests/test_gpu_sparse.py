@@ -207,3 +207,49 @@ def test_bands_of_equal_work_on_uneven_density(hiplib, oracle, pipeline):
         ototal, orec, _ = oracle.convert(scene, 300, cap=0, n_threads=8)
         assert first == ototal
         assert_records_match(rec1, orec, f"uneven density, {pipeline}")
+
+
+def test_positions_left_behind_for_the_depth_sort(hiplib, oracle):
+    """m2s_set_keep_positions (BASELINE config 5: conversion, then "final radix sort of the merged splat buffer"): k_sparse also writes the
+    records' positions as a 16-byte plane, the first m2s_sort_by_depth builds its keys from it — same records, same sorted order as
+    without; a capped conversion keeps the first `cap` positions; a conversion with deferred (big) triangles does not claim the plane."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import camera
+    view = camera.look_at((1.6, 1.1, 2.3), (0.1, 0.0, -0.1))
+
+    def run(scene, R, cap, keep):
+        c = Converter(0)
+        c.set_pipeline("sparse")
+        c.set_keep_positions(keep)
+        c.upload_scene(scene)
+        c.set_max_gaussians(cap)
+        total = c.convert(R)
+        ready = c.positions_ready
+        rec = c.download()
+        srt = c.sort_by_depth(view)
+        after = c.positions_ready
+        t2 = c.convert(R - 6)
+        ready2 = c.positions_ready
+        ran = c.last_pipeline
+        c.close()
+        return total, rec, srt, ready, after, ready2, ran, t2
+
+    scene = synth.cube_sphere(128, tex_size=64)
+    for cap in (0, 50_000):
+        t0, rec0, srt0, ready0, after0, ready0b, ran0, _ = run(scene, 256, cap, False)
+        t1, rec1, srt1, ready1, after1, ready1b, ran1, _ = run(scene, 256, cap, True)
+        assert ran0 == ran1 == "sparse" and t0 == t1 and (cap == 0 or len(rec1) == cap)
+        assert not ready0 and after0 and not ready0b        # without: the plane is the first SORT's by-product and a new conversion invalidates it
+        assert ready1 and after1 and ready1b                # with: every conversion leaves it behind
+        assert np.array_equal(rec0.view(np.uint32), rec1.view(np.uint32)) and np.array_equal(srt0.view(np.uint32), srt1.view(np.uint32))
+    # deferred triangles go through k_emit_big, which does not write the plane: not claimed (the sort builds it as before)
+    soup = synth.random_soup(190_000, seed=21, tri_size=0.003).meshes[0].vertices
+    quad = synth.unit_quad(stride=12).meshes[0].vertices.copy()
+    quad[:, 0:2] = quad[:, 0:2] * 0.3 + 0.2
+    mix = Scene([Mesh(name="mix", vertices=np.concatenate([soup[:300_000], quad, soup[300_000:]], 0), base_color=(1, 1, 1, 1), textures={})])
+    t0, rec0, srt0, ready0, _, _, ran0, _ = run(mix, 400, 0, False)
+    t1, rec1, srt1, ready1, after1, _, ran1, _ = run(mix, 400, 0, True)
+    assert ran1 == "sparse" and not ready1 and after1 and t0 == t1
+    assert np.array_equal(rec0.view(np.uint32), rec1.view(np.uint32)) and np.array_equal(srt0.view(np.uint32), srt1.view(np.uint32))
