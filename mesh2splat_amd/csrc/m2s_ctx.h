@@ -80,6 +80,7 @@ struct m2s_ctx {
     bool warm_mismatch_seen = false;        // a launch in runs disagreed with that count once (run_pass): not retried again
     uint32_t hint_R = 0;                    // m2s_set_resolution_hint: the R the next upload prepares for (0: the last R converted at, else 1024)
     uint32_t warm_R = 0;                    // the R the resident scene was prepared for
+    uint32_t warm_spec_unit = 0, warm_spec_shift = 0;   // run table + dispatch order enqueued with the upload's count, for units of this many triangles (0: none)
     unsigned long long* d_bands = nullptr;  // kBandSlots run tables of run_table_words words each (RunInfo, m2s_device.h)
     size_t run_table_words = 0;
     uint32_t* d_run_order = nullptr;        // dispatch order of the runs (launch_run_order), built by warm_scene from the exact counts ...
@@ -214,7 +215,8 @@ bool use_sparse(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 m2s::RunInfo bands_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri, uint32_t unit, bool may_write, bool* writes);
 m2s::BatchTable batches_for(const m2s_ctx* c, const m2s_ctx::RInfo& ri);
 uint64_t resolve_cap(const m2s_ctx* c, uint32_t R);
-m2s_status warm_scene(m2s_ctx* c, uint32_t R);   // called by m2s_upload_scene once the scene is resident
+m2s_status warm_scene(m2s_ctx* c, uint32_t R, bool counted = false);   // called by m2s_upload_scene once the scene is resident
+m2s_status warm_count_enqueue(m2s_ctx* c, uint32_t R);                  // ... its exact count, enqueued earlier (in front of the texture copies)
 m2s_status enqueue_multipass(m2s_ctx* c, uint32_t R, float4* d_out, uint64_t limit, bool prof,
                              unsigned long long* h_res, hipStream_t st, bool second_lane = false);
 m2s_status ensure_second_lane(m2s_ctx* c);                       // stream, chain and record buffer of the second lane

@@ -119,15 +119,45 @@ namespace m2s_host {
 // RenderContext's current resolutionTarget (guiRendererConcreteMediator.cpp:11-29), never twice at one (scene, R): its first
 // conversion is the one that counts.  Left behind: the scene's fragments / R^2 (AUTO's decision and the pool size at ANY R
 // without touching the device), and for R itself the decision, the XCD run table from the exact counts (k_unit_bases), the batch table of one-generation scenes, the multi-pass work buffers, the record pool.
-m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
+// The count itself, enqueued by m2s_upload_scene behind the geometry and in front of the texture copies: exact fragments per triangle
+// (d_cnt), their scanned partial sums, the total on its way to pinned memory.  warm_scene(counted = true) picks it up after the
+// upload's own synchronisation.
+m2s_status warm_count_enqueue(m2s_ctx* c, uint32_t R) {
     const SceneDev& sc = c->scene;
-    if (!sc.n_tri || R == 0 || R > 4096) return M2S_OK;
+    if (!sc.n_tri || R == 0 || R > 4096) return M2S_ERR_INVALID;
     hipStream_t st = c->stream;
     launch_count(sc, R, c->d_cnt, c->d_partials, st);
     launch_scan_partials(c->d_partials, n_count_blocks(sc.n_tri), c->d_total, st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    // ... and, on the expectation that AUTO will take the team kernel (units of 256 triangles) — the common case —, the run table and
+    // the dispatch order of its first launch at R, which depend on the counts only: if the decision turns out otherwise, warm_scene
+    // builds what it needs as before
+    c->warm_spec_unit = 0;
+    if (!debug_on("M2S_NO_WARM_BANDS")) {
+        m2s_ctx::RInfo& ri = rinfo_for(c, R);
+        bool writes = false;
+        const RunInfo table = bands_for(c, ri, 256u, true, &writes);
+        if (writes) {
+            const uint32_t n_units = band_workgroups(c, 256u);
+            launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, 256u, table.shift, table.out, st);
+            launch_run_order(table.out, n_runs(n_units, table.shift), c->d_total, c->d_run_order, run_order_slots(n_units, table.shift), st);
+            HIPCHK(c, hipGetLastError());
+            c->warm_spec_unit = 256u; c->warm_spec_shift = table.shift;
+        }
+    }
+    return M2S_OK;
+}
+
+m2s_status warm_scene(m2s_ctx* c, uint32_t R, bool counted) {
+    const SceneDev& sc = c->scene;
+    if (!sc.n_tri || R == 0 || R > 4096) return M2S_OK;
+    hipStream_t st = c->stream;
+    if (!counted) {
+        const m2s_status s = warm_count_enqueue(c, R);
+        if (s != M2S_OK) return s;
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     const uint64_t total = c->h_total[0];
     c->frag_per_R2 = (double)total / ((double)R * (double)R);
     c->warm_R = R;
@@ -199,12 +229,15 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R) {
         bool writes = false;
         const RunInfo table = bands_for(c, ri, unit, true, &writes);
         if (writes) {
-            launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, table.shift, table.out, st);
-            const uint32_t n_units = band_workgroups(c, unit);
-            launch_run_order(table.out, n_runs(n_units, table.shift), c->d_total, c->d_run_order, run_order_slots(n_units, table.shift), st);
+            // (already there if the count was enqueued by the upload and the expectation — units of 256 triangles — held)
+            if (!(counted && c->warm_spec_unit == unit && c->warm_spec_shift == table.shift)) {
+                launch_unit_bases(c->d_cnt, c->d_partials, sc.n_tri, unit, table.shift, table.out, st);
+                const uint32_t n_units = band_workgroups(c, unit);
+                launch_run_order(table.out, n_runs(n_units, table.shift), c->d_total, c->d_run_order, run_order_slots(n_units, table.shift), st);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(st));
+            }
             c->run_order_unit = unit; c->run_order_shift = table.shift;
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(st));
             ri.bands_ready = true; ri.bands_unit = unit;
         }
     }

@@ -226,26 +226,14 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     }
     c->last_upload_ms[1] = ms_since(t_geo);
 
-    // ---- textures: level 0 through the same staging, levels 1..4 on the device (glUtils.cpp:292-313) -----------------
     const auto t_tex = std::chrono::steady_clock::now();
-    for (TexPlan& p : tex_plan) {
-        uint32_t* mem = (uint32_t*)(A + p.arena_off);
-        p.d.texels = mem;
-        const m2s_status st = staged_h2d(c, (const char*)p.src, (size_t)p.d.w * p.d.h * 4, kStageChunk, (char*)mem, turn,
-                                         [](char*, size_t, size_t) {});
-        if (st != M2S_OK) return st;
-        for (uint32_t l = 1; l < p.d.n_levels; ++l)
-            launch_mip_level(mem + p.d.off[l - 1], std::max(1u, p.d.w >> (l - 1)), std::max(1u, p.d.h >> (l - 1)),
-                             mem + p.d.off[l], std::max(1u, p.d.w >> l), std::max(1u, p.d.h >> l), c->stream);
-    }
-    for (ComboPlan& cp : combo_plan) {
-        uint32_t* mem = (uint32_t*)(A + cp.arena_off);
-        cp.d.texels = mem;
-        const TexDesc &ta = tex_plan[cp.ia].d, &tn = tex_plan[cp.in].d, &tm = tex_plan[cp.im].d;
-        for (uint32_t l = 0; l < ta.n_levels; ++l)
-            launch_combo_level(ta.texels + ta.off[l], tn.texels + tn.off[l], tm.texels + tm.off[l], std::max(1u, ta.w >> l),
-                               std::max(1u, ta.h >> l), mem + cp.d.coff[l], c->stream);
-    }
+    // ---- mesh table, work buffers, and the upload's exact count — BEFORE the textures ------------------------------------------------
+    // The count (warm_scene) needs the geometry and the meshes' bounding boxes, not the texels: enqueued here, it runs as soon as the
+    // last geometry chunk has been repacked, and its result is on the host when the texture copies behind it have finished — the
+    // upload's one synchronisation serves both (until round 6 the count started after that synchronisation and cost
+    // the upload a second round trip, 0.15 ms of the "warm" share).  The texel pointers are addresses inside the arena: known already.
+    for (TexPlan& p : tex_plan) p.d.texels = (uint32_t*)(A + p.arena_off);
+    for (ComboPlan& cp : combo_plan) cp.d.texels = (uint32_t*)(A + cp.arena_off);
     std::vector<MeshParams> mp(n_mp);
     memset(mp.data(), 0, mp.size() * sizeof(MeshParams));
     for (uint32_t i = 0; i < n_meshes; ++i) {
@@ -286,14 +274,36 @@ m2s_status m2s_upload_scene(m2s_ctx* c, const m2s_mesh* meshes, uint32_t n_meshe
     c->chain_words = chain_words;
     HIPCHK(c, hipMemsetAsync(c->d_chain, 0, chain_words * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), c->stream));
+    const uint32_t warm_R = c->hint_R ? c->hint_R : c->last_R ? c->last_R : 1024u;
+    const bool warm = !debug_on("M2S_NO_WARM");
+    bool counted = false;
+    if (warm && !debug_on("M2S_NO_WARM_OVERLAP")) counted = warm_count_enqueue(c, warm_R) == M2S_OK;
+
+    // ---- textures: level 0 through the same staging, levels 1..4 on the device (glUtils.cpp:292-313) -----------------
+    for (TexPlan& p : tex_plan) {
+        uint32_t* mem = (uint32_t*)(A + p.arena_off);
+        const m2s_status st = staged_h2d(c, (const char*)p.src, (size_t)p.d.w * p.d.h * 4, kStageChunk, (char*)mem, turn,
+                                         [](char*, size_t, size_t) {});
+        if (st != M2S_OK) return st;
+        for (uint32_t l = 1; l < p.d.n_levels; ++l)
+            launch_mip_level(mem + p.d.off[l - 1], std::max(1u, p.d.w >> (l - 1)), std::max(1u, p.d.h >> (l - 1)),
+                             mem + p.d.off[l], std::max(1u, p.d.w >> l), std::max(1u, p.d.h >> l), c->stream);
+    }
+    for (ComboPlan& cp : combo_plan) {
+        uint32_t* mem = (uint32_t*)(A + cp.arena_off);
+        const TexDesc &ta = tex_plan[cp.ia].d, &tn = tex_plan[cp.in].d, &tm = tex_plan[cp.im].d;
+        for (uint32_t l = 0; l < ta.n_levels; ++l)
+            launch_combo_level(ta.texels + ta.off[l], tn.texels + tn.off[l], tm.texels + tm.off[l], std::max(1u, ta.w >> l),
+                               std::max(1u, ta.h >> l), mem + cp.d.coff[l], c->stream);
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // mp / mesh_first are host temporaries; the caller's buffers are released
     HIPCHK(c, hipGetLastError());
     c->last_upload_ms[2] = ms_since(t_tex);
     c->has_scene = true;
     // what the first conversion would otherwise have to find out inside its own call (see warm_scene)
     const auto t_warm = std::chrono::steady_clock::now();
-    if (!debug_on("M2S_NO_WARM")) {
-        const m2s_status ws = warm_scene(c, c->hint_R ? c->hint_R : c->last_R ? c->last_R : 1024u);
+    if (warm) {
+        const m2s_status ws = warm_scene(c, warm_R, counted);
         if (ws != M2S_OK) { c->has_scene = false; return ws; }
     }
     c->last_upload_ms[4] = ms_since(t_warm);
