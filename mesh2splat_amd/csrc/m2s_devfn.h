@@ -3,6 +3,7 @@
 // and converterFS.glsl:44-104 with software trilinear sampling (shade_from_tri).
 #pragma once
 #include "m2s_device.h"
+#include "m2s_exact.h"
 
 #pragma clang fp contract(off)
 
@@ -12,6 +13,14 @@ namespace m2s {
 // small helpers
 // ============================================================================================
 __device__ __forceinline__ float len3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+__device__ __forceinline__ float len3sq(float x, float y, float z) { return (x * x + y * y) + z * z; }     // len3 = sqrt of this, same order
+// 1.0f / len3(x, y, z), both operations correctly rounded (m2s_exact.h: the short sequences inside their proven range, the
+// compiler's IEEE expansion elsewhere; the choice is wave-uniform)
+__device__ __forceinline__ float inv_len3(float x, float y, float z) {
+    const float q = len3sq(x, y, z);
+    if (wave_all(in_sqrt_range(q))) return rcp_rn(sqrt_rn(q));
+    return 1.0f / sqrtf(q);
+}
 
 // Inclusive prefix sum across the 64 lanes of a wave in six DPP adds (no LDS round trips: the shuffle-based version
 // costs six ds_bpermute latencies): Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without a
@@ -66,19 +75,30 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
     float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
     float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
     float e3x = p[6] - p[3], e3y = p[7] - p[4], e3z = p[8] - p[5];
-    float l1 = len3(e1x, e1y, e1z), l2 = len3(e2x, e2y, e2z), l3 = len3(e3x, e3y, e3z);
+    // the three edge lengths; the length of the edge the swap below selects is one of them (same operands, same value): the
+    // shader's fourth square root (normalize(edge1), GS:345) is not recomputed
+    const float q1 = len3sq(e1x, e1y, e1z), q2 = len3sq(e2x, e2y, e2z), q3 = len3sq(e3x, e3y, e3z);
+    const bool fast_len = wave_all(in_sqrt_range3(q1, q2, q3));
+    float l1, l2, l3;
+    if (fast_len) { l1 = sqrt_rn(q1); l2 = sqrt_rn(q2); l3 = sqrt_rn(q3); }
+    else { l1 = sqrtf(q1); l2 = sqrtf(q2); l3 = sqrtf(q3); }
+    float ls = l1;
     // GS:333-342: strict >, else-if; second branch leaves edge2 untouched
     if (l2 > l1 && l2 > l3) {
         float tx = e1x, ty = e1y, tz = e1z;
         e1x = e2x; e1y = e2y; e1z = e2z;
         e2x = tx; e2y = ty; e2z = tz;
+        ls = l2;
     } else if (l3 > l1 && l3 > l2) {
         e1x = e3x; e1y = e3y; e1z = e3z;
+        ls = l3;
     }
-    float inv = 1.0f / len3(e1x, e1y, e1z);
+    float inv;
+    if (fast_len) inv = rcp_rn(ls);     // ls in [2^-48, 2^50]
+    else inv = 1.0f / ls;
     g.xx = e1x * inv; g.xy = e1y * inv; g.xz = e1z * inv;
     float cx = g.xy * e2z - g.xz * e2y, cy = g.xz * e2x - g.xx * e2z, cz = g.xx * e2y - g.xy * e2x;
-    inv = 1.0f / len3(cx, cy, cz);
+    inv = inv_len3(cx, cy, cz);
     g.nx = cx * inv; g.ny = cy * inv; g.nz = cz * inv;
     float ax = fabsf(g.nx), ay = fabsf(g.ny), az = fabsf(g.nz);
     // GS:360-396: (y,z) | (x,z) | (x,y) with strict compares and fall-through on ties
@@ -92,13 +112,26 @@ __device__ __forceinline__ void geo_setup(const float p[9], const float* __restr
     // u = rel / range: correctly rounded IEEE divisions, as the shader writes them (GS:362-363,375-376,388-389)
     // and as the oracle, which is checked bit for bit against the reference's GLSL run through glm, evaluates
     // them.  (rel * (1/range) differs in the last place for ~15 % of the vertices, and the UV->3D Jacobian of a
-    // thin triangle amplifies that to 1e-3 in Scale.)
+    // thin triangle amplifies that to 1e-3 in Scale.)  The six quotients share their divisor: one correctly rounded
+    // reciprocal, then RN(rel / range) in three instructions each (div_rn, m2s_exact.h) where every operand lies in
+    // the proven range — else, for the whole wave, the compiler's IEEE division.
+    float ra[3], rb[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        float pa = useY_asA ? p[3 * i + 1] : p[3 * i + 0];
-        float pb = useY_asB ? p[3 * i + 1] : p[3 * i + 2];
-        g.ou[i] = (pa - bminA) / range;
-        g.ov[i] = (pb - bminB) / range;
+        const float pa = useY_asA ? p[3 * i + 1] : p[3 * i + 0];
+        const float pb = useY_asB ? p[3 * i + 1] : p[3 * i + 2];
+        ra[i] = pa - bminA;
+        rb[i] = pb - bminB;
+    }
+    const float lo = fminf(fminf(fminf(fabsf(ra[0]), fabsf(ra[1])), fabsf(ra[2])), fminf(fminf(fabsf(rb[0]), fabsf(rb[1])), fminf(fabsf(rb[2]), range)));
+    const float hi = fmaxf(fmaxf(fmaxf(fabsf(ra[0]), fabsf(ra[1])), fabsf(ra[2])), fmaxf(fmaxf(fabsf(rb[0]), fabsf(rb[1])), fmaxf(fabsf(rb[2]), range)));
+    if (wave_all(lo >= kDivLo && hi <= kDivHi)) {
+        const float y = rcp_rn(range);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { g.ou[i] = div_rn(ra[i], range, y); g.ov[i] = div_rn(rb[i], range, y); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { g.ou[i] = ra[i] / range; g.ov[i] = rb[i] / range; }
     }
 }
 
@@ -142,7 +175,7 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 __device__ __forceinline__ void geo_flat(const float p[9], const Geo& g, float& sx, float& sy, float4& rot) {
     // yAxis = normalize(cross(normal, xAxis)): exact, because the quat_cast branch below is a decision
     float cx = g.ny * g.xz - g.nz * g.xy, cy = g.nz * g.xx - g.nx * g.xz, cz = g.nx * g.xy - g.ny * g.xx;
-    float inv = 1.0f / len3(cx, cy, cz);
+    const float inv = inv_len3(cx, cy, cz);
     float yx = cx * inv, yy = cy * inv, yz = cz * inv;
     // m[c][r]: columns x, y, n
     const float m00 = g.xx, m01 = g.xy, m02 = g.xz;
@@ -639,7 +672,7 @@ __device__ __forceinline__ void tri_shade_setup(const float p[9], const Geo& g, 
     // lambda_i = float(E_i) * (1 / float(area2)) with exact integer E_i (DECISION-class arithmetic).
     {
 #pragma clang fp contract(off)
-        ts.inva = 1.0f / (float)rs.area2;
+        ts.inva = rcp_rn((float)rs.area2);     // = 1.0f / (float)area2 (m2s_exact.h): 1 <= area2 < 2^63, inside rcp_rn's range
     }
     const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
     ts.a1 = rs.a[1]; ts.b1 = rs.b[1]; ts.a2 = rs.a[2]; ts.b2 = rs.b[2];
@@ -656,7 +689,7 @@ __device__ __forceinline__ void tri_shade_small(const float p[9], const Geo& g, 
                                                 uint32_t m, TriShadeS& c) {
     {
 #pragma clang fp contract(off)
-        c.inva = 1.0f / (float)rs.area2;     // area2 <= 2304^2 < 2^24: the conversion is exact, like (float)(long long) of the same value
+        c.inva = rcp_rn((float)rs.area2);    // = 1.0f / (float)area2 (m2s_exact.h); 1 <= area2 <= 2304^2 < 2^24: the conversion is exact, like (float)(long long) of the same value
     }
     c.a1 = (short)rs.a[1]; c.b1 = (short)rs.b[1]; c.a2 = (short)rs.a[2]; c.b2 = (short)rs.b[2];
     c.e1 = rs.e[1]; c.e2 = rs.e[2];
