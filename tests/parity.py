@@ -55,7 +55,9 @@ def error_report(gpu: np.ndarray, ref: np.ndarray) -> dict:
                               component that happens to be ~0, e.g. one coordinate of a unit normal)
       max_rel_to_vector       max |gpu - ref| / max|ref vector| (the rule used for position / normal / quaternion)
       max_abs                 max |gpu - ref|
-      frac_within_1e-4_component   fraction of floats with |gpu - ref| <= 1e-4 |ref| + 1e-7, strictly per component
+      frac_within_1e-4_component   fraction of floats with |gpu - ref| <= 1e-4 |ref| + eps, strictly per component; eps = 1e-7, and
+                              5e-7 (four fp32 ulps of 1) for the components of the UNIT vectors (normal, quaternion): a component of a unit
+                              normal that is ~0 carries the rounding error of the whole vector, ~1e-7 absolute, not 1e-4 of itself
       frac_bit_identical
     and a histogram of the per-component relative error (decades)."""
     out = {}
@@ -70,7 +72,7 @@ def error_report(gpu: np.ndarray, ref: np.ndarray) -> dict:
         edges = [0.0, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, np.inf]
         hist, _ = np.histogram(rel[big], bins=edges)
         out[name] = {"max_rel_component": float(rel.max()), "max_rel_to_vector": float(relv.max()), "max_abs": float(d.max()),
-                     "frac_within_1e-4_component": float((d <= 1e-4 * np.abs(r) + 1e-7)[fin].mean()),
+                     "frac_within_1e-4_component": float((d <= 1e-4 * np.abs(r) + (5e-7 if name in ("normal", "rotation") else 1e-7))[fin].mean()),
                      "frac_bit_identical": float((gpu[:, sl].view(np.uint32) == ref[:, sl].view(np.uint32)).mean()),
                      "rel_error_histogram": {f"<{e:g}": int(h) for e, h in zip(edges[1:], hist)}}
     return out
@@ -80,19 +82,41 @@ def error_report(gpu: np.ndarray, ref: np.ndarray) -> dict:
 # libraries of rounds 2 and 3; gpurun_out/parity_*.json -> profiles/), with a factor 4 of room: the guard of the full-size tests.
 # The 1e-4 rule above is what north_star allows; a regression that moved 0.1 % of the floats to 1e-3 would pass it on most
 # fields — it does not pass this.  `frac` = required fraction of floats within 1e-4 of THEMSELVES (strictly per component):
-# everything, except components of a unit normal that happen to be ~1e-3 (see the module docstring).
+# everything (unit-vector components with an absolute 5e-7, see error_report).
 # field: (bound on max |gpu - ref|, required fraction within 1e-4 of the component itself)
 ACHIEVED = {
     # config 3 (unit sphere at the origin): achieved 6.0e-8 / 3.6e-7 / 1.2e-6 / 4.8e-7 / 1.2e-7 / 3.6e-7 (profiles/r04/parity_c3.json)
-    "c3": {"position": (2.4e-7, 1.0), "color": (1.5e-6, 1.0), "scale": (5e-6, 1.0), "normal": (2e-6, 0.9999), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
+    "c3": {"position": (2.4e-7, 1.0), "color": (1.5e-6, 1.0), "scale": (5e-6, 1.0), "normal": (2e-6, 1.0), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
     # config 4 stand-in (coordinates up to ~3): achieved 2.4e-7 / 3.0e-7 / 1.4e-6 / 4.8e-7 / 1.2e-7 / 3.0e-7 (parity_c4.json)
-    "c4": {"position": (1e-6, 1.0), "color": (1.5e-6, 1.0), "scale": (6e-6, 1.0), "normal": (2e-6, 0.9999), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
+    "c4": {"position": (1e-6, 1.0), "color": (1.5e-6, 1.0), "scale": (6e-6, 1.0), "normal": (2e-6, 1.0), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
     # config 5 (coordinates up to ~8, Jacobians of sub-pixel triangles): achieved 9.5e-7 / 2.4e-7 / 3.8e-6 / 3.6e-7 / 1.2e-7 / 2.4e-7 (parity_c5.json)
-    # synth.sponza_like (coordinates in [0, 1]; axis-aligned planes and cloth: one or two components of most normals are ~0, where "within
-    # 1e-4 of the component itself" is not meaningful, hence 0.999): achieved 1.2e-7 / 3.0e-7 / 4.8e-7 / 3.9e-7 / 1.2e-7 / 3.0e-7, normal 0.99943
-    "hetero": {"position": (5e-7, 1.0), "color": (1.5e-6, 1.0), "scale": (2e-6, 1.0), "normal": (2e-6, 0.999), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
-    "c5": {"position": (4e-6, 1.0), "color": (1.5e-6, 1.0), "scale": (1.6e-5, 1.0), "normal": (2e-6, 0.9999), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
+    # synth.sponza_like (coordinates in [0, 1]; axis-aligned planes and cloth: one or two components of most normals are ~0):
+    # achieved 1.2e-7 / 3.0e-7 / 4.8e-7 / 3.9e-7 / 1.2e-7 / 3.0e-7
+    "hetero": {"position": (5e-7, 1.0), "color": (1.5e-6, 1.0), "scale": (2e-6, 1.0), "normal": (2e-6, 1.0), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
+    "c5": {"position": (4e-6, 1.0), "color": (1.5e-6, 1.0), "scale": (1.6e-5, 1.0), "normal": (2e-6, 1.0), "rotation": (5e-7, 1.0), "pbr": (1.5e-6, 1.0)},
 }
+
+
+# The same guard for the randomised scenes of tests/test_gpu_fuzz.py (the vector-relative rule of
+# assert_records_match is looser than a literal per-component 1e-4; the guard on the ACHIEVED absolute errors is the real one).
+# Bounds on max |gpu - ref| per field over a whole fuzz run, 4x what the 200-case run achieves (gpurun_out/parity_fuzz.json:
+# "max_abs_error"); scale is relative to the Gaussian's own scale (sub-pixel slivers of the soups have Jacobians of 1e-3 ... 1e3).
+# achieved (200 cases, 39.9 M Gaussians, round 6): 2.4e-7 / 3.0e-7 / 4.3e-6 / 6.9e-6 (unnormalised normals of scenes without a normal map) / 1.2e-7 / 3.0e-7
+FUZZ_ACHIEVED = {"position": 1e-6, "color": 1.2e-6, "scale_rel": 1.7e-5, "normal": 2.8e-5, "rotation": 5e-7, "pbr": 1.2e-6}
+
+
+def fuzz_errors(gpu: np.ndarray, ref: np.ndarray) -> dict:
+    """max |gpu - ref| per field of one fuzz case (scale: relative to the reference value, finite records only)."""
+    out = {}
+    for name, sl in FIELD_NAMES:
+        g, r = gpu[:, sl].astype(np.float64), ref[:, sl].astype(np.float64)
+        fin = np.isfinite(g) & np.isfinite(r)
+        d = np.where(fin, np.abs(g - r), 0.0)
+        if name == "scale":
+            d = d / np.maximum(np.abs(np.where(fin, r, 1.0)), 1e-30)
+            name = "scale_rel"
+        out[name] = float(d.max()) if d.size else 0.0
+    return out
 
 
 def assert_achieved(gpu: np.ndarray, ref: np.ndarray, what: str, out_json: str = None, config: str = "c3") -> dict:
