@@ -47,13 +47,31 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// exact floor(num/den), den > 0, |num| < 2^52: fp64 quotient + one integer correction step
-__device__ __forceinline__ long long floordiv_pos(long long num, long long den) {
-    long long q = (long long)floor((double)num / (double)den);
+// exact floor(num/den), den > 0, |num| < 2^52, |num / den| < 2^44: an APPROXIMATE fp64 quotient + one integer correction step.
+// Round 6: the quotient is num * (1/den) with the reciprocal from v_rcp_f64 and two Newton steps (relative error <= 2^-50 whatever
+// the seed's accuracy from 2^-14 up), not an IEEE division (v_div_scale / v_div_fmas / v_div_fixup: ~60 issue slots of half-rate fp64
+// each, six to twelve per triangle in the row walkers): |num y - num/den| <= 2^44 2^-50 = 2^-6 < 1, so floor() of it is the true
+// floor or one off, and the remainder test below — exact integer arithmetic — settles which (tests/test_round6_math.py enumerates
+// the argument with reciprocals perturbed far beyond that).  Divisions that share their divisor share the reciprocal (floordivmod_by).
+__device__ __forceinline__ double rcp_f64(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(e, y, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(e, y, y);
+}
+// floor(num / den) and the remainder num - q den in [0, den), y = rcp_f64((double)den)
+__device__ __forceinline__ long long floordivmod_by(long long num, long long den, double y, long long& rem) {
+    long long q = (long long)floor((double)num * y);
     long long r = num - q * den;
-    if (r < 0) q -= 1;
-    else if (r >= den) q += 1;
+    if (r < 0) { q -= 1; r += den; }
+    else if (r >= den) { q += 1; r -= den; }
+    rem = r;
     return q;
+}
+__device__ __forceinline__ long long floordiv_pos(long long num, long long den) {
+    long long r;
+    return floordivmod_by(num, den, rcp_f64((double)den), r);
 }
 
 // ============================================================================================
@@ -387,6 +405,20 @@ struct RowWalker {
     int lower;           // bit i: edge i bounds x from below (a > 0)
     int x0, x1;
 };
+// One edge of a walker: quotient / remainder of the row's numerator and of the per-row step, both by D = 256 |a| — ONE reciprocal,
+// one code path for lower and upper bounds (the two used to be the sides of a divergent branch with two fp64 divisions each).
+__device__ __forceinline__ void walker_edge(long long alpha, long long beta, long long bs, long long& q, uint32_t& r, int& sq, uint32_t& sr, uint32_t& D) {
+    const bool pos = alpha > 0;
+    const long long d = pos ? alpha : -alpha;             // 256 |a| < 2^31; 0: horizontal edge (handled through beta by the walkers)
+    D = (uint32_t)d;
+    const long long dd = d ? d : 1;
+    const double y = rcp_f64((double)(uint32_t)dd);
+    const long long n = pos ? alpha - beta : beta - 1;    // x >= floor((alpha - beta) / alpha)  |  x <= floor((beta - 1) / -alpha)
+    const long long st = pos ? -bs : bs;
+    long long r1, r2;
+    const long long q1 = floordivmod_by(n, dd, y, r1), q2 = floordivmod_by(st, dd, y, r2);
+    q = d ? q1 : 0; r = d ? (uint32_t)r1 : 0u; sq = d ? (int)q2 : 0; sr = d ? (uint32_t)r2 : 0u;
+}
 __device__ __forceinline__ void row_walker_init(const Raster& s, int y, RowWalker& w) {
     const long long Py = 256ll * y + 128;
     w.lower = 0;
@@ -398,29 +430,8 @@ __device__ __forceinline__ void row_walker_init(const Raster& s, int y, RowWalke
         const int bs = 256 * s.b[i];
         w.beta[i] = beta;
         w.bstep[i] = bs;
-        if (alpha > 0) {          // x >= floor((alpha - beta) / alpha)
-            w.lower |= 1 << i;
-            w.D[i] = (uint32_t)alpha;
-            const long long n = alpha - beta;
-            w.q[i] = floordiv_pos(n, alpha);
-            w.r[i] = (uint32_t)(n - w.q[i] * alpha);
-            const long long st = -(long long)bs;
-            const long long fq = floordiv_pos(st, alpha);
-            w.sq[i] = (int)fq;
-            w.sr[i] = (uint32_t)(st - fq * alpha);
-        } else if (alpha < 0) {   // x <= floor((beta - 1) / -alpha)
-            const long long d = -alpha;
-            w.D[i] = (uint32_t)d;
-            const long long n = beta - 1;
-            w.q[i] = floordiv_pos(n, d);
-            w.r[i] = (uint32_t)(n - w.q[i] * d);
-            const long long st = (long long)bs;
-            const long long fq = floordiv_pos(st, d);
-            w.sq[i] = (int)fq;
-            w.sr[i] = (uint32_t)(st - fq * d);
-        } else {
-            w.D[i] = 0; w.q[i] = 0; w.r[i] = 0; w.sq[i] = 0; w.sr[i] = 0;
-        }
+        if (alpha > 0) w.lower |= 1 << i;
+        walker_edge(alpha, beta, (long long)bs, w.q[i], w.r[i], w.sq[i], w.sr[i], w.D[i]);
     }
 }
 // The same walker for loops that visit every S-th row (the wave-cooperative paths: lane l walks rows y0 + l, y0 + l + 64, ...: one
@@ -449,27 +460,8 @@ __device__ __forceinline__ void row_walker_init_strided(const Raster& s, int y, 
         const long long bs = 256ll * s.b[i] * stride;
         w.beta[i] = beta;
         w.bstep[i] = bs;
-        if (alpha > 0) {          // x >= floor((alpha - beta) / alpha)
-            w.lower |= 1 << i;
-            w.D[i] = (uint32_t)alpha;
-            const long long n = alpha - beta;
-            w.q[i] = floordiv_pos(n, alpha);
-            w.r[i] = (uint32_t)(n - w.q[i] * alpha);
-            const long long fq = floordiv_pos(-bs, alpha);
-            w.sq[i] = (int)fq;
-            w.sr[i] = (uint32_t)(-bs - fq * alpha);
-        } else if (alpha < 0) {   // x <= floor((beta - 1) / -alpha)
-            const long long d = -alpha;
-            w.D[i] = (uint32_t)d;
-            const long long n = beta - 1;
-            w.q[i] = floordiv_pos(n, d);
-            w.r[i] = (uint32_t)(n - w.q[i] * d);
-            const long long fq = floordiv_pos(bs, d);
-            w.sq[i] = (int)fq;
-            w.sr[i] = (uint32_t)(bs - fq * d);
-        } else {
-            w.D[i] = 0; w.q[i] = 0; w.r[i] = 0; w.sq[i] = 0; w.sr[i] = 0;
-        }
+        if (alpha > 0) w.lower |= 1 << i;
+        walker_edge(alpha, beta, bs, w.q[i], w.r[i], w.sq[i], w.sr[i], w.D[i]);
     }
 }
 // span of the current row, then advance to the next one

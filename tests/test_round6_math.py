@@ -77,3 +77,29 @@ def test_the_on_device_check_includes_the_shipped_header_not_a_copy():
     for fn in ("rcp_rn", "sqrt_rn", "div_rn"):
         assert len(re.findall(r"float " + fn + r"\(", chk)) == 0, fn       # used, never redefined
         assert fn + "(" in chk
+
+
+def test_floor_division_by_an_approximate_reciprocal_plus_one_integer_correction_is_exact():
+    """floordivmod_by (m2s_devfn.h): q0 = floor(fp64(num) * y), y ~ 1/den, then ONE correction step on the exact remainder.  Claim: exact
+    for |num| < 2^52, 256 <= den < 2^31, |num / den| < 2^44, as long as y's relative error is at most 2^-50.  Enumerated here with
+    reciprocals perturbed by up to 2^-46 (16x the bound the two Newton steps guarantee), on random operands and on the adversarial
+    ones — numerators within a few units of a multiple of the divisor, where floor() of an approximate quotient lands on the wrong side."""
+    rng = np.random.default_rng(0xF100D)
+    n_cases = 400_000
+    den = np.concatenate([rng.integers(256, 1 << 31, n_cases // 2), 256 * rng.integers(1, 1 << 23, n_cases // 2)]).astype(np.int64)
+    k = rng.integers(-(1 << 43), 1 << 43, n_cases).astype(np.int64)
+    k = np.clip(k, -((1 << 52) - 1) // den, ((1 << 52) - 1) // den)
+    num = k * den + rng.integers(-3, 4, n_cases)                    # multiples of the divisor, a few units either side
+    num[: n_cases // 4] = rng.integers(-(1 << 52) + 1, 1 << 52, n_cases // 4)
+    num[n_cases // 4: n_cases // 2] = rng.integers(-(1 << 31), 1 << 31, n_cases // 4)   # the walkers' per-row steps (|256 b| < 2^31, x 64: < 2^37)
+    num = np.clip(num, -(1 << 52) + 1, (1 << 52) - 1)
+    want = np.array([int(a) // int(b) for a, b in zip(num, den)], dtype=np.int64)
+    for rel in (0.0, 2.0 ** -50, -(2.0 ** -50), 2.0 ** -46, -(2.0 ** -46)):
+        y = (1.0 / den.astype(np.float64)) * (1.0 + rel)
+        q = np.floor(num.astype(np.float64) * y).astype(np.int64)
+        assert np.abs(q - want).max() <= 1                                             # the approximate floor is never more than one off ...
+        r = num - q * den
+        q = np.where(r < 0, q - 1, np.where(r >= den, q + 1, q))                      # ... which one correction step repairs
+        assert np.array_equal(q, want), rel
+        r = num - q * den
+        assert ((r >= 0) & (r < den)).all()
