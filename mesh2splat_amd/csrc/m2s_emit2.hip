@@ -56,6 +56,9 @@ constexpr int kCountBlock = 256;       // triangles per workgroup in k_count_sca
 #ifndef M2S_COUNT_WAVES
 #define M2S_COUNT_WAVES 4
 #endif
+#ifndef M2S_COUNT_ROWS
+#define M2S_COUNT_ROWS kRowsCount   // k_count_scan: triangles of more pixel rows are counted by the whole wave, 64 rows at a time (A/B switch)
+#endif
 #ifndef M2S_EMIT2_WAVES
 #define M2S_EMIT2_WAVES 4   // round 3: 122 VGPRs since both mip levels are read without a branch: four waves per SIMD, no scratch
 #endif
@@ -78,7 +81,7 @@ static_assert(sizeof(TriSetup) == 112, "TriSetup must be seven float4");
 // that starts deep inside the triangle (the floor of a Sponza-like scene: half a million fragments, a thousand slices, a
 // thousand rows) then begins at the 64-row chunk that holds its first record instead of walking every chunk above it.  A
 // conversion with more tall triangles than slots leaves the rest without one: they are walked from the top, as before.
-constexpr uint32_t kTallCap = 4096;
+constexpr uint32_t kTallCap = 16384;
 constexpr uint32_t kTallChunks = 64;          // 4096 rows / 64
 __device__ __forceinline__ uint32_t* tall_header(const float4* setup, uint32_t n_tri) {
     return reinterpret_cast<uint32_t*>(const_cast<float4*>(setup) + (size_t)max(n_tri, 1u) * 7);
@@ -143,28 +146,42 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         ok = raster_setup(g, R, rs);
     }
     const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
-    uint32_t c = 0;
-    if (ok && rows <= kRowsCount) {
+    uint32_t c = 0, c64 = 0;
+    if (ok && rows <= M2S_COUNT_ROWS) {
         RowWalker rw;
         row_walker_init(rs, rs.y0, rw);
         for (int y = rs.y0; y <= rs.y1; ++y) {
             int xa, xb;
             row_walker_next(rw, xa, xb);
+            if (y == rs.y0 + 64) c64 = c;      // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
             c += (uint32_t)max(xb - xa + 1, 0);
         }
     }
     uint32_t tall_slot = 0;
     {   // triangles spanning more rows: the whole wave counts one triangle, 64 rows at a time, one row per lane — and leaves the
-        // running sums in the tall-triangle table (see kTallCap) for k_emit2
-        unsigned long long big = __ballot(ok && rows > kRowsCount);
+        // running sums in the tall-triangle table (see kTallCap) for k_emit2.  Triangles of 65 .. M2S_COUNT_ROWS rows, counted by
+        // their own lanes above, get a table entry as well (two chunks: 0 and the sum after 64 rows): a slice of k_emit2 that
+        // starts in their lower half skips the upper one.
+        unsigned long long big = __ballot(ok && rows > M2S_COUNT_ROWS);
+        const bool two = ok && rows > 64 && rows <= M2S_COUNT_ROWS && c != 0;
+        const unsigned long long twos = __ballot(two);
         uint32_t* const hdr = tall_header(setup, sc.n_tri);
-        while (big) {
+        // the wave's table slots in ONE atomic (one global round trip per wave, not one per tall triangle in front of its count)
+        uint32_t slot = 0;
+        if ((big | twos) != 0ull && lane == 0) slot = atomicAdd(&hdr[0], (uint32_t)(__popcll(big) + __popcll(twos)));
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (two) {
+            const uint32_t mine = slot + (uint32_t)__popcll(big) + (uint32_t)__popcll(twos & ((1ull << lane) - 1ull));
+            if (mine < kTallCap) {
+                uint32_t* const row = hdr + 4 + (size_t)mine * kTallChunks;
+                row[0] = 0; row[1] = c64;
+                tall_slot = mine + 1u;
+            }
+        }
+        for (; big; ++slot) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
             const Raster b = shfl_raster(rs, src);
-            uint32_t slot = 0;
-            if (lane == 0) slot = atomicAdd(&hdr[0], 1u);
-            slot = __builtin_amdgcn_readfirstlane(slot);
             const bool listed = slot < kTallCap;
             uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
             uint32_t run = 0, ci = 0;
