@@ -78,7 +78,7 @@ def parse():
                          "SCALE record (scale_record) and says dry_scale: true.  Not a measurement of a transport")
     ap.add_argument("--one-device", action="store_true",
                     help="tests: every rank on device 0 (several processes share one GPU; needs an RCCL stand-in that allows it: M2S_RCCL_PATH)")
-    ap.add_argument("--pipeline", default=None, choices=["auto", "multipass", "wave", "team", "sparse", "lean"],
+    ap.add_argument("--pipeline", default=None, choices=["auto", "multipass", "team", "sparse", "lean"],
                     help="A/B: force a pipeline setting for the headline workload (default: the library's AUTO)")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed region (each: EXACTLY --steps conversions between barrier + synchronize); ms_per_step / value "
@@ -916,7 +916,7 @@ def main():
     res = None
     if rank == 0:
         dom = "fused" if kms["fused"] > 0 else "emit"     # the dominant kernel of the pipeline that ran
-        kname = {"team": "k_fused2", "lean": "k_fused3", "wave": "k_fused", "sparse": "k_sparse"}.get(last_pipeline, "k_emit2")
+        kname = {"team": "k_fused2", "lean": "k_fused3", "sparse": "k_sparse"}.get(last_pipeline, "k_emit2")
         emit_ms = kms[dom]
         # algorithmic bytes of one launch of the dominant kernel: 96 B per Gaussian STORED + 144 B per triangle read
         # (B_alg = 96 N + 144 T); textures, offsets and the entry list are not credited.

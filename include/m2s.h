@@ -367,8 +367,8 @@ const char* m2s_io_last_error(void);
 
 /* ---- pipeline selection ------------------------------------------------------------------------ */
 /* AUTO (default) decides once per (scene, R), from an exact fragment count taken at the first conversion:
- *   - fewer than 11 fragments per triangle on average: the SINGLE-PASS kernel (k_fused2; k_fused where a workgroup's
- *     fragments do not fit k_fused2's LDS stream).  It emits every triangle of <= 16 pixel rows and <= 96 fragments
+ *   - fewer than 11 fragments per triangle on average: the SINGLE-PASS kernel (k_fused2 / its lean form k_fused3; the multi-pass
+ *     pipeline from an R on at which a workgroup's fragments do not fit the kernel's LDS stream).  It emits every triangle of <= 16 pixel rows and <= 96 fragments
  *     itself; larger triangles only reserve their slice of the ordered output there and are emitted by a second
  *     kernel (k_emit_big, one workgroup per 1024-fragment chunk); a scene DOMINATED by such triangles falls through
  *     to the multi-pass pipeline;
@@ -377,20 +377,20 @@ const char* m2s_io_last_error(void);
  *     in a scene of at least 2 M triangles, fewer than 0.5 in a smaller one (measured crossovers): the SPARSE form of the
  *     single-pass kernel (k_sparse): a cheap conservative test drops the triangles that cannot cover a pixel centre before
  *     the exact per-triangle phase runs on the survivors; k_fused2 where a workgroup does not fit.
- * MULTIPASS forces the multi-pass pipeline, WAVE / TEAM / SPARSE force the single-pass kernel in one of its forms.  Every
+ * MULTIPASS forces the multi-pass pipeline, TEAM / LEAN / SPARSE force the single-pass kernel in one of its forms.  Every
  * setting produces bit-identical output.  Changing the setting forgets the remembered decisions. */
 enum { M2S_PIPELINE_AUTO = 0, M2S_PIPELINE_MULTIPASS = 1,
-       M2S_PIPELINE_WAVE = 2 /* always the single-pass kernel, one-wave-per-batch form (k_fused); multi-pass only if it hands off */,
-       M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2), k_fused where a workgroup
-                                does not fit its LDS stream */,
+       /* 2: the one-wave-per-batch kernel of rounds 1-5 (k_fused), removed in round 6: m2s_set_pipeline rejects the value */
+       M2S_PIPELINE_TEAM = 3 /* always the single-pass kernel, workgroup-cooperative form (k_fused2); the multi-pass pipeline where a
+                                workgroup does not fit its LDS stream */,
        M2S_PIPELINE_SPARSE = 4 /* always the sparse form of the single-pass kernel (k_sparse) where the scene is large enough for
-                                  it (>= ~172 k triangles), k_fused2 / k_fused where a workgroup does not fit its LDS stream */,
+                                  it (>= ~172 k triangles), k_fused2 / the multi-pass pipeline where a workgroup does not fit its LDS stream */,
        M2S_PIPELINE_LEAN = 5 /* the team kernel in its lean form (k_fused3: four waves per SIMD; shades triangles of at most 8 x 8
                                 pixels itself and defers the rest to k_emit_big) where the scene allows it — every mesh samples
                                 three equally sized maps or none —, else as TEAM.  AUTO prefers it to k_fused2 under the same
                                 condition and returns to k_fused2 at an R where many triangles were deferred */ };
 m2s_status m2s_set_pipeline(m2s_ctx* ctx, int pipeline);
-/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _WAVE (k_fused), _TEAM (k_fused2), _LEAN (k_fused3) or _SPARSE (k_sparse); 0 before any. */
+/* Which pipeline the last conversion actually ran: M2S_PIPELINE_MULTIPASS, _TEAM (k_fused2), _LEAN (k_fused3) or _SPARSE (k_sparse); 0 before any. */
 int m2s_last_pipeline(const m2s_ctx* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------------- */

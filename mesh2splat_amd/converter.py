@@ -282,8 +282,8 @@ class Converter:
 
     def set_pipeline(self, name: str):
         """'auto' (single-pass kernel or multi-pass pipeline, chosen per scene and R), 'multipass', or the single-pass
-        kernel forced, in one of its two forms: 'wave' (k_fused) / 'team' (k_fused2, workgroup-cooperative)."""
-        self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1, "wave": 2, "team": 3, "sparse": 4, "lean": 5}[name]))
+        kernel forced in one of its forms: 'team' (k_fused2, workgroup-cooperative), 'lean' (k_fused3), 'sparse' (k_sparse)."""
+        self._check(self._L.m2s_set_pipeline(self._h, {"auto": 0, "multipass": 1, "team": 3, "sparse": 4, "lean": 5}[name]))
 
     def set_async_lanes(self, lanes: int):
         """2: context-owned submissions alternate between two streams / chains / record buffers and overlap."""
@@ -291,8 +291,8 @@ class Converter:
 
     @property
     def last_pipeline(self) -> str:
-        """What the last conversion ran: 'multipass', 'wave' (k_fused) or 'team' (k_fused2)."""
-        return {0: "none", 1: "multipass", 2: "wave", 3: "team", 4: "sparse", 5: "lean"}[self._L.m2s_last_pipeline(self._h)]
+        """What the last conversion ran: 'multipass', 'team' (k_fused2), 'lean' (k_fused3) or 'sparse' (k_sparse)."""
+        return {0: "none", 1: "multipass", 3: "team", 4: "sparse", 5: "lean"}[self._L.m2s_last_pipeline(self._h)]
 
     # -- measurement --------------------------------------------------------------------------------
     def set_profiling(self, on: bool):

@@ -147,18 +147,15 @@ m2s_status m2s_convert_submit(m2s_ctx* c, uint32_t R, void* d_records, uint64_t 
     HIPCHK(c, next_epoch(c, &epoch));
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t0, st));
     const bool sparse = use_sparse(c, ri);
-    const bool team = !sparse && use_team(c, ri);
-    const bool lean = team && use_lean(c, ri);
-    c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
+    const bool lean = !sparse && use_lean(c, ri);
+    c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : M2S_PIPELINE_TEAM;
     sl.bands_unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
     if (sparse) launch_sparse(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                               c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), st);
     else if (lean) launch_fused3(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
                             c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c, ri), st);
-    else if (team) launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                            c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c, ri), st);
-    else launch_fused(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
-                      c->d_biglist, c->d_bigmeta, st);
+    else launch_fused2(c->scene, R, chain, limit, (float4*)d_out, &res[0], reinterpret_cast<uint32_t*>(&res[1]), epoch,
+                       c->d_biglist, c->d_bigmeta, bands_for(c, ri, sl.bands_unit, !second_lane && c->lanes == 1, &sl.wrote_bands), batches_for(c, ri), st);
     if (sl.prof) HIPCHK(c, hipEventRecord(sl.t1, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(sl.done, st));

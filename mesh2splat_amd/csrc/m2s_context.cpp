@@ -61,6 +61,7 @@ m2s_ctx::RInfo& rinfo_for(m2s_ctx* c, uint32_t R) {
     ri.band_slot = (int)c->rinfo.size();
     ri.sparse_off = R >= c->sparse_off_R;
     ri.team_off = R >= c->team_off_R;
+    if (ri.team_off) ri.multipass = true;       // (decide() keeps it; a forced single-pass setting hands such an R to the multi-pass pipeline)
     ri.lean_off = R >= c->lean_off_R;
     return c->rinfo.emplace(R, ri).first->second;
 }
@@ -237,6 +238,7 @@ m2s_status m2s_set_profiling(m2s_ctx* c, int enabled) {
 m2s_status m2s_set_pipeline(m2s_ctx* c, int pipeline) {
     if (!c) return M2S_ERR_INVALID;
     if (pipeline < M2S_PIPELINE_AUTO || pipeline > M2S_PIPELINE_LEAN) return fail(c, M2S_ERR_INVALID, "unknown pipeline");
+    if (pipeline == 2) return fail(c, M2S_ERR_INVALID, "pipeline 2 (the one-wave-per-batch kernel of rounds 1-5) no longer exists: use M2S_PIPELINE_TEAM");
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (c->pipeline != pipeline) {   // what was remembered about this scene under the old setting no longer applies
         c->rinfo.clear();

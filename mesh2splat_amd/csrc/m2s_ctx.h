@@ -59,7 +59,7 @@ struct m2s_ctx {
         bool multipass = false;    // ... and it was "multi-pass"
         bool sparse = false;       // AUTO: fewer fragments than triangles, the sparse form of the single-pass kernel (k_sparse)
         bool sparse_off = false;   // k_sparse reported a workgroup that did not fit its LDS stream: use k_fused2
-        bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: use k_fused
+        bool team_off = false;     // k_fused2 reported a workgroup that did not fit its LDS stream: the multi-pass pipeline from this R on
         uint32_t tpw = 0;          // AUTO: k_fused2 in batches of this many triangles (0: fused_tpw) — the 11-18 fragments-per-triangle band
         bool lean_off = false;     // k_fused3 overflowed its LDS stream or deferred many triangles at this R: use k_fused2
         bool async_ok = false;     // a completed conversion needed no host decision between kernels

@@ -1030,7 +1030,7 @@ __device__ __forceinline__ void shade_from_tri(const TriPlanes& tp, uint32_t t, 
 }
 
 // Record stores are non-temporal: the records are never re-read by the conversion; keeping them out of the 4 MiB L2
-// leaves it to the texture / vertex lines (measured on k_fused: 0.236 -> 0.200 ms).
+// leaves it to the texture / vertex lines (measured on the first single-pass kernel, round 1: 0.236 -> 0.200 ms).
 __device__ __forceinline__ void nt_store(float4* p, float4 v) {
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // merged into one dwordx4 nt

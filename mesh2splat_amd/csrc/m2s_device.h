@@ -7,13 +7,18 @@
 
 namespace m2s {
 
-// Debug / A-B switches of the library (M2S_NO_BANDS, M2S_BAND_COST, M2S_EMIT2_RUN, ...) are environment variables that are only
-// looked at when M2S_DEBUG is set in the environment (decided once per process): a stray variable cannot change what a
-// production process does, and the conversion path of a production process reads no environment at all.
+// Debug / A-B switches of the library (M2S_NO_BANDS, M2S_NO_LEAN, M2S_NO_WARM, ...) exist only in a DEBUG BUILD (`make EXTRA=-DM2S_DEBUG_BUILD
+// OUT=../_build_debug`: what tools/first_call_probe.py, tools/mp_probe.py and the A/B scripts under tools/ab/ load through M2S_LIB_PATH), and
+// even there they are only looked at when M2S_DEBUG is set in the environment.  In the library that ships every debug_on() is the constant
+// false: the conversion path reads no environment and carries no switch (round 6).
+#ifdef M2S_DEBUG_BUILD
 inline const char* debug_env(const char* name) {
     static const bool enabled = std::getenv("M2S_DEBUG") != nullptr;
     return enabled ? std::getenv(name) : nullptr;
 }
+#else
+inline const char* debug_env(const char*) { return nullptr; }
+#endif
 inline bool debug_on(const char* name) { const char* v = debug_env(name); return v && *v && *v != '0'; }
 
 // ---- launch geometry ----------------------------------------------------------------------
@@ -175,9 +180,6 @@ void launch_sparse(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
 bool sparse_supported(uint32_t n_tri);
 uint32_t sparse_workgroups(uint32_t n_tri);   // workgroups of kSpCand = 512 triangles
 constexpr uint32_t kSparseTrianglesPerWorkgroup = 512;
-void launch_fused(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
-                  unsigned long long* total, uint32_t* status /* [0]=any big [1]=error */, uint32_t epoch, BigItem* biglist,
-                  uint32_t* bigmeta /* [0]=count [1]=max fragments [2]=sum of fragments */, hipStream_t st);
 void launch_emit_big(const SceneDev& sc, uint32_t R, const BigItem* biglist, uint32_t n_big, uint32_t max_cnt, uint64_t limit,
                      float4* out, hipStream_t st);
 
@@ -223,7 +225,6 @@ void launch_lower_bounds(const uint32_t* keys, uint64_t n, const unsigned long l
 hipError_t preload_fused2();
 hipError_t preload_fused3();
 hipError_t preload_sparse();
-hipError_t preload_fused();
 hipError_t preload_multipass();
 void launch_scratch_warm(hipStream_t st);   // the queue's scratch memory set up now, not inside the first multi-pass conversion (m2s_emit2.hip)
 hipError_t preload_export();

@@ -1,10 +1,10 @@
 // m2s_fused2.hip — single-pass conversion kernel, workgroup-cooperative ("team") form (gfx950).
 //
-// Same work and same output as k_fused (m2s_fused.hip).  There, every WAVE runs alone: triangle phase for its 64
+// Its predecessor (k_fused, rounds 1-5, removed in round 6) ran every WAVE alone: triangle phase for its 64
 // triangles, look-back, then strips of 64 of ITS OWN fragments — and the last strip of every wave is partial: on
 // the C3 workload 64 triangles give 9..452 fragments, so only 85 % of the fragment lanes do useful work, and every
 // wave pays its own look-back round trip.  Here the four waves of a workgroup still run the triangle phase
-// independently (one batch of 64 triangles each, aggregates published as early as in k_fused), but their fragments go
+// independently (one batch of 64 triangles each, aggregates published as early as possible), but their fragments go
 // into ONE entry stream for the workgroup (LDS), in canonical order, and the fragment phase takes strips of 64 from
 // that stream (an LDS atomic hands them out): only the workgroup's last strip is partial (96 % useful lanes), the
 // look-back is needed once per workgroup — record index = workgroup base + stream position — and a wave whose batch
@@ -14,7 +14,7 @@
 // loads); a wave waits for the COUNTS of the waves before it (to know where its entries go) and, per strip, for the
 // EXPANSION of the waves whose entries the strip contains.  No __syncthreads.  Every wait is bounded and raises the
 // error flag instead of hanging; so does a workgroup whose fragments do not fit the LDS stream (kEntries) — the host
-// then repeats the conversion with k_fused (m2s_pass.cpp, run_pass) and remembers that for the scene and R.
+// then repeats the conversion with the multi-pass pipeline (m2s_pass.cpp, run_pass) and remembers that for the scene and R.
 #include "m2s_fused_common.h"
 #include <cstdio>
 
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kTeamThreads, M2S_FUSED2_WAVES) k_fused2(Scene
     const bool has_batch = wave < nb_here;
     const unsigned long long band_base = band_first ? C.base : 0ull;     // (of the unit's run)
 
-    // ======================= triangle phase: one batch per wave (as in k_fused) =======================
+    // ======================= triangle phase: one batch per wave =======================
     uint32_t t0 = b * tpw, nt = tpw;
     if (bt.first && has_batch) {
         const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)bt.first;

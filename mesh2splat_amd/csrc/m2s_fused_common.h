@@ -1,4 +1,4 @@
-// m2s_fused_common.h — pieces shared by the single-pass kernels (m2s_fused.hip, m2s_fused2.hip): triangle classes,
+// m2s_fused_common.h — pieces shared by the single-pass kernels (m2s_fused2.hip, m2s_fused3.hip, m2s_sparse.hip): triangle classes,
 // the look-back chain (word format, loads/stores, the look-back itself) and the rare medium-triangle expansion.
 #pragma once
 #include "m2s_devfn.h"

@@ -32,10 +32,12 @@ static uint32_t band_workgroups(const m2s_ctx* c, uint32_t unit) {
 }  // namespace
 
 namespace m2s_host {
-// Which form of the single-pass kernel (see m2s_fused2.hip)?  The workgroup-cooperative one unless a workgroup's
-// fragments did not fit its LDS stream at this R before.
-bool use_team(const m2s_ctx* c, const m2s_ctx::RInfo& ri) {
-    return !(c->pipeline == M2S_PIPELINE_WAVE || ri.team_off);
+// The single-pass kernel is the workgroup-cooperative one (m2s_fused2.hip / its lean and sparse forms).  A scene whose workgroups did
+// not fit its LDS stream at this R (team_off) belongs to the multi-pass pipeline from then on (rinfo_for / decide set ri.multipass):
+// the one-wave-per-batch form that used to answer such scenes (k_fused, rounds 1-5) was slower there than the multi-pass pipeline
+// and is gone (round 6).
+bool use_team(const m2s_ctx*, const m2s_ctx::RInfo& ri) {
+    return !ri.team_off;
 }
 // the team kernel in its lean form (m2s_fused3.hip): LEAN uses it where the scene allows it (m2s_ctx::lean_ok) unless a launch at
 // this R overflowed its LDS stream; AUTO only for scenes of more than one generation of workgroups (64 triangles per wave: a fourth
@@ -97,7 +99,7 @@ uint64_t resolve_cap(const m2s_ctx* c, uint32_t R) {
 // because it mixes planes with foliage (synth.sponza_like: 16 per triangle) belongs to the multi-pass pipeline and its fine blocks.
 static void decide(const m2s_ctx* c, m2s_ctx::RInfo& ri, double frags, uint32_t R) {
     ri.decided = true;
-    ri.multipass = frags >= 11.0 * (double)c->scene.n_tri;
+    ri.multipass = frags >= 11.0 * (double)c->scene.n_tri || ri.team_off;
     ri.tpw = 0;
     if (ri.multipass && frags < 13.0 * (double)c->scene.n_tri && R == c->warm_R && c->warm_total > 0 && c->warm_big * 8ull < c->warm_total &&
         fused_tpw(c->scene.n_tri) == 64u && !c->n_batch_tab && c->team_off_R > R && !debug_on("M2S_NO_BAND_TPW")) {
@@ -219,8 +221,7 @@ m2s_status warm_scene(m2s_ctx* c, uint32_t R, bool counted) {
         if (!single) { (void)preload_multipass(); if (!debug_on("M2S_NO_SCRATCH_WARM")) launch_scratch_warm(st); }
         else if (use_sparse(c, ri)) { (void)preload_sparse(); (void)preload_fused2(); }   // (the sparse form falls back to the team on a stream overflow)
         else if (use_lean(c, ri)) { (void)preload_fused3(); }
-        else if (use_team(c, ri)) { (void)preload_fused2(); }
-        else { (void)preload_fused(); }
+        else { (void)preload_fused2(); }
         (void)hipGetLastError();
     }
     if (single && (use_sparse(c, ri) || use_team(c, ri)) && !debug_on("M2S_NO_WARM_BANDS")) {
@@ -436,7 +437,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
         wrote_plane = false;
         for (int attempt = 0; attempt < 4; ++attempt) {
             const bool sparse = use_sparse(c, ri);
-            const bool team = !sparse && use_team(c, ri);
+            const bool team = !sparse;
             const bool lean = team && use_lean(c, ri);
             c->h_total[0] = 0;
             c->h_total[1] = 0;
@@ -444,7 +445,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
             HIPCHK(c, next_epoch(c, &epoch));
             if (prof) HIPCHK(c, hipEventRecord(c->ev[5], st));
             const uint32_t unit = sparse ? kSparseTrianglesPerWorkgroup : 256u;
-            const RunInfo runs = (sparse || team) ? bands_for(c, ri, unit, true, &wrote_bands) : RunInfo{ nullptr, nullptr, 0u, nullptr };
+            const RunInfo runs = bands_for(c, ri, unit, true, &wrote_bands);
             // m2s_set_keep_positions: the sparse kernel — the one that runs on scenes of tens of millions of records, where a depth sort
             // is worth preparing for — also writes the records' positions as a 16-byte plane (the context's, grown here if need be)
             float4* plane = nullptr;
@@ -461,18 +462,16 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
                                       c->d_biglist, c->d_bigmeta, runs, st, plane);
             else if (lean) launch_fused3(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
                                     c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
-            else if (team) launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                                    c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
-            else launch_fused(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
-                              c->d_biglist, c->d_bigmeta, st);
+            else launch_fused2(sc, R, c->d_chain, limit, d_out, &c->h_total[0], reinterpret_cast<uint32_t*>(&c->h_total[1]), epoch,
+                               c->d_biglist, c->d_bigmeta, runs, batches_for(c, ri), st);
             if (prof) HIPCHK(c, hipEventRecord(c->ev[6], st));
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, wait_stream(st));  // glFinish + counter read-back (ConversionPass.cpp:54-59)
             if (prof) HIPCHK(c, hipEventElapsedTime(&c->last_ms[M2S_K_FUSED], c->ev[5], c->ev[6]));
             any_big = (uint32_t)(c->h_total[1] & 0xFFFFFFFFull);
             err = (uint32_t)(c->h_total[1] >> 32);
-            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : team ? M2S_PIPELINE_TEAM : M2S_PIPELINE_WAVE;
-            if ((team || sparse) && !err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
+            c->last_pipeline = sparse ? M2S_PIPELINE_SPARSE : lean ? M2S_PIPELINE_LEAN : M2S_PIPELINE_TEAM;
+            if (!err && wrote_bands) { ri.bands_ready = true; ri.bands_unit = unit; }
             // A launch in runs trusts the run table: at the R the scene was counted at (warm_scene), that table comes from k_count's
             // counts, not from a launch of this kernel.  The two must agree on every triangle; if the totals ever differ, the table is
             // dropped and the conversion repeated in plain order (until now only the parity tests guarded this)
@@ -485,7 +484,7 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
                 continue;
             }
             if (err && debug_on("M2S_DEBUG"))
-                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : lean ? "lean" : team ? "team" : "wave", err, R);
+                fprintf(stderr, "[m2s] single-pass kernel (%s) reported 0x%x at R = %u: trying the next form\n", sparse ? "sparse" : lean ? "lean" : "team", err, R);
             if (lean && !err && any_big && c->pipeline == M2S_PIPELINE_AUTO) {
                 // k_fused3 shades only triangles of at most 8 x 8 pixels itself.  A few deferred ones are what k_emit_big is for;
                 // MANY mean the scene at this R belongs to k_fused2, which expands triangles of up to 16 pixel rows in the
@@ -500,23 +499,23 @@ m2s_status run_pass(m2s_ctx* c, uint32_t R, void* d_user, uint64_t user_cap, hip
                     continue;
                 }
             }
-            if (!(err && (team || sparse))) break;
+            if (!err) break;
             if (team && ri.tpw) { ri.tpw = 0; break; }   // a scene of the 11-18 band whose workgroups overflow even in small batches: multi-pass (below)
-            // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team -> the
-            // one-wave-per-batch form, which has no such limit.  Remember it for this scene and R, forget what the aborted
-            // launch listed, try again.
+            // a workgroup's fragments did not fit the kernel's LDS stream (or a wait timed out): sparse -> team, lean -> team,
+            // team -> the multi-pass pipeline, which has no such limit (below: err != 0).  Remember it for this scene and R, forget
+            // what the aborted launch listed, try again.
             // (error value 2 = "entries do not fit": true of every larger R as well)
             if (sparse) { ri.sparse_off = true; if ((err & 0xFu) == 2u) c->sparse_off_R = std::min(c->sparse_off_R, R); }
             else if (lean) { ri.lean_off = true; if ((err & 0xFu) == 2u) c->lean_off_R = std::min(c->lean_off_R, R); }
-            else { ri.team_off = true; if ((err & 0xFu) == 2u) c->team_off_R = std::min(c->team_off_R, R); }
+            else { ri.team_off = true; if ((err & 0xFu) == 2u) c->team_off_R = std::min(c->team_off_R, R); break; }
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
         }
         done = true;
         // a clean single-kernel conversion: the same scene at the same R can be submitted asynchronously from now on
         ri.async_ok = !err && !any_big;
         if (err) {
-            // The bounded look-back spin gave up (never observed; would need a dispatcher that starves earlier
-            // workgroups).  Degrade to the multi-pass pipeline, which has no inter-workgroup dependency.
+            // The team kernel's workgroups do not fit their LDS stream at this R, or the bounded look-back spin gave up (never
+            // observed; would need a dispatcher that starves earlier workgroups): the multi-pass pipeline, which has neither limit.
             HIPCHK(c, hipMemsetAsync(c->d_bigmeta, 0, 4 * sizeof(uint32_t), st));
             ri.multipass = true;
             done = false;

@@ -322,7 +322,7 @@ m2s_status m2s_prepare(m2s_ctx* c, uint32_t flags) {
         for (int k = 0; k < 2; ++k)
             if (!c->h_export[k]) HIPCHK(c, hipHostMalloc((void**)&c->h_export[k], m2s_ply::kChunkRows * sizeof(m2s_gaussian), hipHostMallocDefault));
     if ((flags & M2S_PREPARE_KERNELS) && !debug_on("M2S_NO_PRELOAD")) {
-        HIPCHK(c, preload_fused2()); HIPCHK(c, preload_fused3()); HIPCHK(c, preload_sparse()); HIPCHK(c, preload_fused()); HIPCHK(c, preload_multipass());
+        HIPCHK(c, preload_fused2()); HIPCHK(c, preload_fused3()); HIPCHK(c, preload_sparse()); HIPCHK(c, preload_multipass());
         HIPCHK(c, preload_export()); HIPCHK(c, preload_prepass()); HIPCHK(c, preload_sort());
     }
     return M2S_OK;

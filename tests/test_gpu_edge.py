@@ -45,7 +45,7 @@ def test_nonfinite_and_out_of_range_geometry(hiplib, oracle):
     v[6:9, 0:3] *= 1e6          # far outside the bbox -> guard band
     v[9:12, 0:3] += 3.0         # outside the bbox but inside the guard band: clipped to the viewport
     scene = Scene([Mesh("m", v, bbox_min=np.float32([-1, -1, -1]), bbox_max=np.float32([1, 1, 1]))])
-    for pipe in ("auto", "multipass", "wave", "team"):
+    for pipe in ("auto", "multipass", "team"):
         assert both(oracle, scene, 64, pipeline=pipe) > 0
 
 
@@ -73,7 +73,7 @@ def test_many_small_meshes_straddling_waves(hiplib, oracle):
         m.base_color = (0.2 + 0.02 * k, 0.5, 1.0 - 0.02 * k, 1.0)
         meshes.append(m)
     scene = Scene(meshes)
-    for pipe in ("auto", "multipass", "wave", "team"):
+    for pipe in ("auto", "multipass", "team"):
         both(oracle, scene, 200, pipeline=pipe)
 
 
@@ -131,7 +131,7 @@ def test_convert_into_user_buffer_and_capacity(hiplib, oracle):
 def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, oracle):
     """k_fused2 keeps a workgroup's fragments in a 4096-entry LDS stream.  A scene whose AVERAGE is small (AUTO picks the
     single-pass kernel) but that has a cluster of 256 consecutive triangles with ~80 fragments each overflows it: the
-    host must repeat the conversion with k_fused, return the right answer and remember the decision."""
+    host must repeat the conversion with the multi-pass pipeline, return the right answer and remember the decision."""
     import numpy as np
     from mesh2splat_amd import synth
     from mesh2splat_amd.converter import Converter
@@ -161,8 +161,8 @@ def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, or
     c.set_pipeline("team")                                    # k_fused2 expands the cluster in the workgroup: that overflows
     for _ in range(2):
         assert c.convert(R) == ototal
-        assert c.last_pipeline == "wave"                      # the team form gave up, the wave form answered
-    assert_records_match(c.download(), orec, "fallback to k_fused")
+        assert c.last_pipeline == "multipass"                 # the team form gave up, the multi-pass pipeline answered (and is remembered)
+    assert_records_match(c.download(), orec, "fallback to the multi-pass pipeline")
     c.set_pipeline("auto")
     # an ordinary scene runs the team form, several meshes included
     grid = synth.colocated_spheres(3, 150, 64)
@@ -177,8 +177,8 @@ def test_team_kernel_falls_back_when_a_workgroup_overflows_its_stream(hiplib, or
 
 
 def test_chain_tag_wrap_between_the_two_single_pass_forms(hiplib, oracle):
-    """Look-back chain words are tagged with the low 16 bits of a launch counter instead of being cleared.  The wave form
-    uses more chain words than the team form, so words it wrote keep their tag while only the team form runs; when the
+    """Look-back chain words are tagged with the low 16 bits of a launch counter instead of being cleared.  The team kernel
+    (one word per 64 triangles) uses more chain words than k_count_scan (one per 256), so words it wrote keep their tag while only the multi-pass pipeline runs; when the
     counter comes round to the same tag 65 536 launches later they must not read as fresh.  Walk the counter across
     the wrap with the test hook and alternate the forms around it."""
     scene = synth.cube_sphere(60, tex_size=32)
@@ -195,7 +195,7 @@ def test_chain_tag_wrap_between_the_two_single_pass_forms(hiplib, oracle):
         assert c.last_pipeline == form
         assert_records_match(c.download(), orec, "tag wrap, %s" % form)
 
-    for first, second in (("wave", "team"), ("team", "wave")):
+    for first, second in (("team", "multipass"), ("multipass", "team")):
         assert L.m2s_debug_set_launch_counter(c._h, 0x10000 - 2) == 0
         run(first)                    # tag 0xFFFF
         run(second)                   # tag 0x0000: chains cleared

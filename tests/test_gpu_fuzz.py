@@ -1,6 +1,6 @@
 """-m gpu: randomised differential parity.  Seeded random scenes (triangle soups of random size classes, cube-spheres, multi-mesh
 grids; with / without textures; 12- and 17-float vertices), random densities, random caps and triangle ranges — every pipeline
-(auto / team / lean / wave / multipass / sparse) must give the SAME BYTES, and those bytes the oracle's records within tolerance and the
+(auto / team / lean / multipass / sparse) must give the SAME BYTES, and those bytes the oracle's records within tolerance and the
 oracle's counter exactly.  M2S_FUZZ_CASES (default 200) scales it; the report goes to gpurun_out/parity_fuzz.json."""
 import json
 import os
@@ -16,7 +16,7 @@ from parity import FUZZ_ACHIEVED, assert_records_match, fuzz_errors
 
 pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("M2S_FUZZ_CASES", "200"))
-PIPELINES = ("auto", "team", "lean", "wave", "multipass", "sparse")
+PIPELINES = ("auto", "team", "lean", "multipass", "sparse")
 
 
 def make_case(k: int):
@@ -92,7 +92,7 @@ def test_random_scenes_all_pipelines_same_bytes_and_oracle(hiplib, oracle):
         with open(out, "w") as fh:
             json.dump({"cases": len(report), "seconds": time.time() - t0, "library_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16],
                        "gaussians_total": int(sum(r["gaussians"] for r in report)),
-                       "auto_ran": {p: sum(1 for r in report if r["ran"]["auto"] == p) for p in ("team", "lean", "wave", "multipass", "sparse")},
+                       "auto_ran": {p: sum(1 for r in report if r["ran"]["auto"] == p) for p in ("team", "lean", "multipass", "sparse")},
                        "forced_sparse_ran_sparse": sum(1 for r in report if r["ran"]["sparse"] == "sparse"),
                        "forced_lean_ran_lean": sum(1 for r in report if r["ran"]["lean"] == "lean"),
                        "max_abs_error": {f: {"value": v, "case": kk, "guard": FUZZ_ACHIEVED[f]} for f, (v, kk) in worst.items()},

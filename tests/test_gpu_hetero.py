@@ -37,7 +37,7 @@ def test_sponza_like_full_size_against_the_oracle(hiplib, oracle, hetero):
     assert_achieved(rec, orec, "sponza_like", os.path.join(OUT_DIR, "parity_hetero.json"), config="hetero")
     assert np.array_equal(conv.download_triangle_counts(), cnt.astype(np.uint32))
     # every setting: the same bytes (forced single-pass kernels defer the planes to k_emit_big or hand the scene to the multi-pass pipeline)
-    for name in ("multipass", "team", "wave", "sparse", "lean"):
+    for name in ("multipass", "team", "sparse", "lean"):
         c2 = Converter(0)
         c2.set_pipeline(name)
         c2.upload_scene(hetero)

@@ -10,7 +10,7 @@ from parity import assert_records_match
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "multipass", "wave", "team"])
+@pytest.fixture(scope="module", params=["auto", "multipass", "team"])
 def conv(hiplib, request):
     """Every parity test runs through both pipelines: the fused single-pass kernel (with its multi-pass
     fallback for big triangles) and the forced multi-pass pipeline."""

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host")
 
 
-@pytest.mark.parametrize("pipeline", ["auto", "multipass", "wave", "team"])
+@pytest.mark.parametrize("pipeline", ["auto", "multipass", "team"])
 @pytest.mark.parametrize("name,R", [("mixed_trs", 16), ("soup", 32)])
 def test_hip_matches_reference_pipeline_golden(tmp_path, hiplib, name, R, pipeline):
     with open(os.path.join(GOLD, f"pipe_{name}_R{R}.records.bin"), "rb") as f:

@@ -1,5 +1,5 @@
 """What the FIRST conversion of a freshly uploaded scene costs (blocking m2s_convert, wall clock), against repeated ones:
-python tools/first_call_probe.py [n=289] [R=1024] [reps=6].  With M2S_DEBUG=1: M2S_NO_WARM=1 (round 3's behaviour: count inside the
+python tools/first_call_probe.py [n=289] [R=1024] [reps=6].  With a debug build of the library (make EXTRA=-DM2S_DEBUG_BUILD OUT=../_build_debug; M2S_LIB_PATH) and M2S_DEBUG=1: M2S_NO_WARM=1 (round 3's behaviour: count inside the
 first call), M2S_NO_WARM_BANDS=1, M2S_NO_WARM_TOUCH=1 switch the parts of the upload-time preparation off."""
 import json
 import os
