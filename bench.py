@@ -37,6 +37,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the host driver only supports dmabuf IPC: without this RCCL's multi-process bring-up fails with `hipIpcGetMemHandle: invalid argument`.
+# Set before any HIP runtime is loaded, whoever launched this rank (the driver's torchrun exports it already; a bare launcher may not).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -399,6 +399,9 @@ int convert_batch(const Options& o) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    // --gpus N: one process per GPU over RCCL.  The host driver only supports dmabuf IPC; say so before any HIP runtime call of this
+    // process or its forks (without it RCCL's bring-up fails with `hipIpcGetMemHandle: invalid argument`).  Never overrides the caller's value.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     Options o;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
