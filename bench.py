@@ -208,12 +208,38 @@ def reference_baseline(scene_one_mesh, R, expect_total):
     return out
 
 
-def viewer_extra(conv, R, total):
-    """GaussiansPrepass + RadixSortPass on the records of the last conversion: kernel ms (HIP events), algorithmic bytes
-    96*n read + 100*visible written, fraction of the HBM peak."""
+def frame_passes(conv, p, n_records, reps=6):
+    """One viewer frame on the context's records, two ways (wall clock of the blocking calls, ms; median of `reps` after a first one):
+      two_calls  m2s_prepass (input order) + m2s_sort_prepass  == GaussiansPrepass::execute + RadixSortPass::execute (keys, sort, 96-byte gather)
+      fused      m2s_prepass_sorted: the depth sort first, as a permutation; the prepass through it — same bytes out (tests/test_gpu_prepass.py)."""
+    import numpy as np
+    from dataclasses import replace
+    p = replace(p, arrival_order=False)
+    two, fused, st2, stf = [], [], [], []
+    for k in range(reps + 1):
+        t0 = time.perf_counter()
+        vis = conv.prepass(p, download=False)
+        t1 = time.perf_counter()
+        conv.sort_prepass(download=False)
+        t2 = time.perf_counter()
+        two.append((t2 - t0) * 1e3)
+        st2.append({"prepass_kernel": conv.last_prepass_ms, "sort_prepass": conv.last_sort_prepass_ms, "prepass_call": (t1 - t0) * 1e3})
+        t0 = time.perf_counter()
+        vis_f = conv.prepass_sorted(p, download=False)
+        fused.append((time.perf_counter() - t0) * 1e3)
+        s_ = conv.last_sort_stage_ms
+        stf.append({"keys": s_["keys"], "radix_sort": s_["radix_sort"], "prepass_through_permutation": s_["gather"]})
+        assert vis_f == vis
+    med = lambda xs: float(np.median(xs[1:]))
+    a, b = med(two), med(fused)
+    return {"records": int(n_records), "visible": int(vis), "two_calls_ms": a, "fused_ms": b, "fused_over_two_calls": b / a,
+            "two_calls_stages_ms": {k: med([x[k] for x in st2]) for k in st2[0]}, "fused_stages_ms": {k: med([x[k] for x in stf]) for k in stf[0]},
+            "what": "m2s_prepass + m2s_sort_prepass against m2s_prepass_sorted (one pass over the records), blocking calls, wall clock"}
+
+
+def viewer_camera():
     import math
     import numpy as np
-    from mesh2splat_amd.prepass import PrepassParams
 
     def look_at(eye, center):
         eye, center, up = np.asarray(eye, float), np.asarray(center, float), np.array([0.0, 1.0, 0.0])
@@ -233,6 +259,15 @@ def viewer_extra(conv, R, total):
     proj = np.zeros((4, 4), np.float32)
     proj[0, 0], proj[1, 1] = 1 / (16 / 9 * t), 1 / t
     proj[2, 2], proj[2, 3], proj[3, 2] = -(100 + 0.01) / (100 - 0.01), -1.0, -(2 * 100 * 0.01) / (100 - 0.01)
+    return look_at, proj
+
+
+def viewer_extra(conv, R, total):
+    """GaussiansPrepass + RadixSortPass on the records of the last conversion: kernel ms (HIP events), algorithmic bytes
+    96*n read + 100*visible written, fraction of the HBM peak."""
+    import numpy as np
+    from mesh2splat_amd.prepass import PrepassParams
+    look_at, proj = viewer_camera()
     conv.convert(R)                                  # a blocking conversion: the context's records are the input
     out = {"camera": "perspective 45 deg 16:9, eye (1.6,1.1,2.3) -> (0.1,0,-0.1), 1920x1080", "records": int(total)}
     conv.set_profiling(True)
@@ -259,6 +294,10 @@ def viewer_extra(conv, R, total):
         conv.sort_prepass(download=False)
         sms.append(conv.last_sort_prepass_ms)
     out["sort_prepass_ms"] = float(np.median(sms[1:]))
+    try:
+        out["frame"] = frame_passes(conv, p, total)
+    except Exception as e:  # noqa: BLE001
+        out["frame"] = {"error": str(e)}
     conv.set_profiling(False)
     return out
 
@@ -635,6 +674,14 @@ def c5_workload(torch, local_rank, steps=8):
                              "sort_core": "rocPRIM radix_sort_pairs (library); key and gather kernels are this repository's"}
     except Exception as e:  # noqa: BLE001
         res["depth_sort"] = {"error": str(e)}
+    # ... and one viewer frame over the same 24.3 M records (prepass + depth sort of its output), two calls against the fused pass
+    try:
+        from mesh2splat_amd.prepass import PrepassParams
+        look_at, proj = viewer_camera()
+        pv = PrepassParams(view_mat=look_at((3.75, 3.0, 12.0), (3.75, 0.0, 0.0)), proj_mat=proj, renderer_resolution=(1920, 1080), resolution_target=2048)
+        res["frame"] = frame_passes(conv, pv, conv.num_stored, reps=4)
+    except Exception as e:  # noqa: BLE001
+        res["frame"] = {"error": str(e)}
     conv.close()
     return res
 

@@ -344,6 +344,15 @@ const void* m2s_device_sorted_quads(const m2s_ctx* ctx);     /* m2s_quad[n]  (pe
 m2s_status m2s_download_sorted_quads(m2s_ctx* ctx, m2s_quad* dst, uint64_t capacity);
 /* Duration (ms) of the last profiled m2s_sort_prepass (radix sort + gather). */
 float m2s_last_sort_prepass_ms(const m2s_ctx* ctx);
+/* One frame's GaussiansPrepass::execute + RadixSortPass::execute (GaussiansPrepass.cpp:8-56, RadixSortPass.cpp:8-90) as ONE pass over the
+ * records of the context (its last conversion, or m2s_set_records / m2s_upload_records): the depth sort is taken FIRST — keys = the bits of
+ * the view-space depth the prepass is about to store (from the 16-byte position plane the context keeps of its current records), stable
+ * radix sort of (key, record index) — and the prepass then reads the records THROUGH that permutation and appends its survivors in that
+ * order: the 96-byte gather of RadixSortPass::gatherPost (radixSortGather.glsl:30-49) and the prepass's own read become one pass.
+ * Result: m2s_device_sorted_quads / m2s_download_sorted_quads hold exactly what m2s_prepass (input order) followed by m2s_sort_prepass
+ * leaves there, byte for byte; *out_visible = their number.  params->arrival_order is ignored (the order IS the result); the unsorted quads
+ * of m2s_prepass are not produced.  m2s_last_sort_stage_ms: [0] keys, [1] radix sort, [2] the prepass through the permutation. */
+m2s_status m2s_prepass_sorted(m2s_ctx* ctx, const m2s_prepass_params* params, uint64_t* out_visible);
 
 /* ---- scene I/O == SceneManager::loadModel (minus GL) and parsers::loadPlyFile ------------------------ */
 /* Host-side scene loaded from a binary glTF file: scene-graph transforms applied, de-indexed 17-float

@@ -28,7 +28,7 @@ EXPORTS = (
     "m2s_host_scene_meshes", "m2s_host_scene_mesh_name", "m2s_host_scene_warnings", "m2s_read_ply", "m2s_free_records",
     "m2s_io_last_error", "m2s_sort_by_depth", "m2s_device_sorted_records", "m2s_download_sorted", "m2s_last_sort_ms",
     "m2s_upload_records", "m2s_prepass", "m2s_device_quads", "m2s_device_prepass_depths", "m2s_download_prepass", "m2s_last_prepass_ms",
-    "m2s_sort_prepass", "m2s_device_sorted_quads", "m2s_download_sorted_quads", "m2s_last_sort_prepass_ms",
+    "m2s_sort_prepass", "m2s_prepass_sorted", "m2s_device_sorted_quads", "m2s_download_sorted_quads", "m2s_last_sort_prepass_ms",
     "m2s_last_upload_ms", "m2s_write_ply_slice", "m2s_export_ply_slice",
     "m2s_dist_unique_id", "m2s_dist_create", "m2s_dist_destroy", "m2s_dist_rank", "m2s_dist_world", "m2s_dist_last_error",
     "m2s_dist_shard_ranges", "m2s_dist_all_gather_counts", "m2s_dist_publish_count", "m2s_dist_collect_counts",
@@ -120,6 +120,7 @@ def load():
         "m2s_download_prepass": (C.c_int, [vp, vp, vp, u64]),
         "m2s_last_prepass_ms": (C.c_float, [vp]),
         "m2s_sort_prepass": (C.c_int, [vp, C.POINTER(u64)]),
+        "m2s_prepass_sorted": (C.c_int, [vp, vp, C.POINTER(u64)]),
         "m2s_device_sorted_quads": (vp, [vp]),
         "m2s_download_sorted_quads": (C.c_int, [vp, vp, u64]),
         "m2s_last_sort_prepass_ms": (C.c_float, [vp]),

@@ -276,6 +276,21 @@ class Converter:
         self._check(self._L.m2s_download_sorted_quads(self._h, out.ctypes.data, n.value))
         return out
 
+    def prepass_sorted(self, params, download: bool = True):
+        """GaussiansPrepass + RadixSortPass of one frame in one pass over the context's records (m2s_prepass_sorted): the depth sort first,
+        as a permutation; the prepass through it.  -> (visible, 24) float32 quads in depth order == prepass() then sort_prepass(), byte
+        for byte; or just `visible` with download=False."""
+        from . import prepass as _pp
+        pc, keep = _pp.to_c(params)
+        vis = C.c_uint64()
+        self._check(self._L.m2s_prepass_sorted(self._h, C.byref(pc), C.byref(vis)))
+        del keep
+        if not download:
+            return vis.value
+        out = np.empty((vis.value, 24), np.float32)
+        self._check(self._L.m2s_download_sorted_quads(self._h, out.ctypes.data, vis.value))
+        return out
+
     @property
     def last_sort_prepass_ms(self) -> float:
         return float(self._L.m2s_last_sort_prepass_ms(self._h))

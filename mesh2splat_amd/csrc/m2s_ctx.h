@@ -44,9 +44,10 @@ struct m2s_ctx {
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;  // pinned, kPinnedWords words: [0] = fragment counter, [1] = status words of the fused kernel,
                                             // [2 + 2k], [3 + 2k] = the same of in-flight slot k, then one word each for the prepass and the depth sort
-    static constexpr int kPinnedPrepass = 2 + 2 * M2S_MAX_IN_FLIGHT;   // m2s_prepass: survivors
-    static constexpr int kPinnedSortMM = 3 + 2 * M2S_MAX_IN_FLIGHT;    // m2s_sort_by_depth: {min, max} of the keys (two 32-bit words)
-    static constexpr int kPinnedWords = 4 + 2 * M2S_MAX_IN_FLIGHT;
+    static constexpr int kPinnedPrepass = 2 + 2 * M2S_MAX_IN_FLIGHT;   // m2s_prepass: TWO words — survivors, then the status words of its look-back
+    static constexpr int kPinnedSortMM = 4 + 2 * M2S_MAX_IN_FLIGHT;    // the depth sorts: {min, max} of the keys (two 32-bit words); NOT the prepass's second word —
+                                                                       // m2s_prepass_sorted uses both inside one call
+    static constexpr int kPinnedWords = 5 + 2 * M2S_MAX_IN_FLIGHT;
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
     m2s::BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions
@@ -150,7 +151,7 @@ struct m2s_ctx {
     // viewer prepass (m2s_prepass): survivors, their depths, the look-back chain of its kernel, a copy of the depth image
     void* d_quads = nullptr;
     float* d_pp_depths = nullptr;
-    uint64_t pp_cap = 0, pp_visible = 0;
+    uint64_t pp_cap = 0, pp_depths_cap = 0, pp_visible = 0;
     unsigned long long* d_pp_chain = nullptr;
     uint64_t pp_chain_words = 0;
     uint32_t pp_epoch = 0;

@@ -213,7 +213,7 @@ constexpr uint32_t kPPTile = kPPWaves * 64u * kPPRec;   // records per workgroup
 __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
                                                     float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
                                                     unsigned long long* __restrict__ counter, unsigned long long* __restrict__ total,
-                                                    uint32_t* __restrict__ status) {
+                                                    uint32_t* __restrict__ status, const uint32_t* __restrict__ perm) {
     __shared__ float4 s_rec[kPPWaves][64 * 6];   // survivors of ONE 64-record group, staged for contiguous stores
     __shared__ float s_depth[kPPWaves][64];
     __shared__ uint32_t s_cnt[kPPWaves];
@@ -226,13 +226,17 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     // contiguous, so every fetched line is fully used — 8 % faster than 1 KiB-coalesced loads transposed through LDS).  All
     // groups' loads are issued before the first math: kPPRec x 96 bytes in flight per lane.  The survivors of group 0 go to
     // the staging area at once; those of the later groups wait in registers until group 0 has been written out.
+    // With a permutation (m2s_prepass_sorted: the depth sort was taken first) position i holds record perm[i]: the same six 16-byte
+    // loads per lane, from a 96-byte record anywhere in the buffer — the gather of the sort and the prepass's read in one pass.
     float4 g[kPPRec][6];
     bool valid[kPPRec];
+    uint32_t src[kPPRec];
 #pragma unroll
     for (int r = 0; r < kPPRec; ++r) {
         const uint32_t gid = first + (uint32_t)r * 64u + (uint32_t)lane;
         valid[r] = gid < n;
-        const float4* gsrc = rec + (size_t)(valid[r] ? gid : 0u) * 6;
+        src[r] = valid[r] ? (perm ? perm[gid] : gid) : 0u;
+        const float4* gsrc = rec + (size_t)src[r] * 6;
 #pragma unroll
         for (int j = 0; j < 6; ++j) g[r][j] = gsrc[j];
     }
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     uint32_t cnt[kPPRec], rank[kPPRec], wcnt = 0;
 #pragma unroll
     for (int r = 0; r < kPPRec; ++r) {
-        vis[r] = prepass_one(k, g[r], first + (uint32_t)r * 64u + (uint32_t)lane, valid[r], q[r], dvs[r]);
+        vis[r] = prepass_one(k, g[r], perm ? src[r] : first + (uint32_t)r * 64u + (uint32_t)lane, valid[r], q[r], dvs[r]);   // (gid = the RECORD's index)
         const unsigned long long mask = __ballot(vis[r]);
         cnt[r] = (uint32_t)__popcll(mask);
         rank[r] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -318,9 +322,10 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
 }
 
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
-                          uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st) {
+                          uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st,
+                          const uint32_t* perm) {
     const uint32_t nb = (n + kPPTile - 1u) / kPPTile;
-    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status);
+    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status, perm);
     return hipGetLastError();
 }
 

@@ -26,6 +26,17 @@ __device__ __forceinline__ uint32_t depth_key(float4 p, float v02, float v12, fl
     const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;
     return __float_as_uint(z);
 }
+// The key the viewer's own sort uses (RadixSortPass.cpp:16-45): the raw bits of gaussianDepthPostFiltering = the prepass's view-space z,
+// vs = u_worldToView * (u_modelToWorld * vec4(P, 1)) with mat4 * vec4 as (m0 x + m1 y) + (m2 z + m3 w) — m2s_prepass.hip's m4_mul,
+// operation for operation, so that sorting BEFORE the prepass (sort_prepass_permutation) orders by exactly the bits the prepass will store.
+struct DepthMV { float M[16], V[16]; };
+__device__ __forceinline__ uint32_t depth_key_mv(float4 p, const DepthMV& x) {
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (x.M[0 + i] * p.x + x.M[4 + i] * p.y) + (x.M[8 + i] * p.z + x.M[12 + i] * 1.0f);
+    const float z = (x.V[2] * w[0] + x.V[6] * w[1]) + (x.V[10] * w[2] + x.V[14] * w[3]);
+    return __float_as_uint(z);
+}
 // Both key kernels also leave the smallest and the largest key of every WAVE behind (wave_mm[wave] = {min, max}: one 8-byte store per 64
 // records) and k_reduce_minmax folds those into minmax[0] / [1]: view-space depths of a bounded scene share their sign and most of their
 // exponent, so the keys differ only in their low 20-25 bits — sort_by_depth sorts `key - min` over exactly the bits that differ and saves a
@@ -77,6 +88,20 @@ __global__ void __launch_bounds__(kBlock) k_depth_keys_from_plane(const float4* 
     reduce_minmax(kmin, kmax, minmax);
 }
 
+__global__ void __launch_bounds__(kBlock) k_depth_keys_mv(const float4* __restrict__ rec, const float4* __restrict__ plane_in, uint32_t n, DepthMV x,
+                                                          uint32_t* __restrict__ key, float4* __restrict__ plane_out, uint2* __restrict__ minmax) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (i < n) {
+        const float4 p = plane_in ? plane_in[i] : rec[(size_t)i * 6];
+        const uint32_t k = depth_key_mv(p, x);
+        key[i] = k;
+        if (plane_out) plane_out[i] = p;
+        kmin = kmax = k;
+    }
+    reduce_minmax(kmin, kmax, minmax);
+}
+
 __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restrict__ src, const uint32_t* __restrict__ val,
                                                            uint32_t n, float4* __restrict__ dst) {
     const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -113,14 +138,15 @@ size_t sort_temp_bytes(uint32_t n) {
     return (((bytes > bytes_t ? bytes : bytes_t) + 15) & ~(size_t)15) + 16 + (size_t)sort_grid_waves(n) * 8;
 }
 
-// plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  stage_ev (or nullptr): four
-// events recorded around the three stages (keys | radix sort | gather).  The values are the record indices: they come from a
-// counting iterator, not from memory.
-hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out,
-                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st,
-                         uint32_t* key_offset_out, uint32_t* pinned_mm) {
-    if (key_offset_out) *key_offset_out = 0;
-    if (!n) return hipSuccess;
+// Keys of the n records + their stable radix sort: vals_out = the permutation (record index of every sorted position), keys_out = the
+// sorted keys (minus *key_offset when the sort ran over the bits in which the keys differ).  mv == nullptr: key = view-space z by the
+// row view[2], view[6], view[10], view[14] (m2s_sort_by_depth); else the prepass's own depth bits (depth_key_mv).
+// plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  ev (or nullptr): events around the
+// key stage and the radix sort (ev[0], ev[1], ev[2]).  The values are the record indices: they come from a counting iterator, not from memory.
+static hipError_t keys_and_sort(const float4* rec, uint32_t n, const float view[16], const DepthMV* mv, uint32_t* keys_in, uint32_t* keys_out,
+                                uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid, hipEvent_t* ev, hipStream_t st,
+                                uint32_t* key_offset, uint32_t* pinned_mm) {
+    *key_offset = 0;
     const uint32_t n_waves = sort_grid_waves(n);       // (idle waves of the last workgroup store {0xFFFFFFFF, 0}: neutral for the fold)
     const size_t tail = 16 + (size_t)n_waves * 8;
     if (temp_bytes < tail + 16) return hipErrorInvalidValue;
@@ -131,11 +157,14 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
     hipError_t e = hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
     const dim3 grid((n + kBlock - 1) / kBlock);
-    if (stage_ev) (void)hipEventRecord(stage_ev[0], st);
-    if (plane && plane_valid) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in, wave_mm);
+    if (ev) (void)hipEventRecord(ev[0], st);
+    const bool from_plane = plane && plane_valid;
+    if (mv) hipLaunchKernelGGL(k_depth_keys_mv, grid, dim3(kBlock), 0, st, rec, from_plane ? (const float4*)plane : (const float4*)nullptr, n, *mv, keys_in,
+                               from_plane ? (float4*)nullptr : plane, wave_mm);
+    else if (from_plane) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in, wave_mm);
     else hipLaunchKernelGGL(k_depth_keys, grid, dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in, plane, wave_mm);
     hipLaunchKernelGGL(k_reduce_minmax, dim3(std::min<uint32_t>((n_waves + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, st, wave_mm, n_waves, minmax);
-    if (stage_ev) (void)hipEventRecord(stage_ev[1], st);
+    if (ev) (void)hipEventRecord(ev[1], st);
     // the keys' range decides how many radix passes the library makes: 8 bytes come back to the host (one sync, ~15 us of a ~1.7 ms call)
     uint32_t mm_local[2] = { 0u, 0xFFFFFFFFu };
     uint32_t* mm = pinned_mm ? pinned_mm : mm_local;          // (pinned: the copy is a DMA the sync waits for, not a staged pageable copy)
@@ -145,22 +174,49 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
     const uint32_t range = mm[1] >= mm[0] ? mm[1] - mm[0] : 0xFFFFFFFFu;
     int bits = 1;
     while (bits < 32 && (range >> bits) != 0u) ++bits;
-    uint32_t key_offset = 0;
     if ((bits + 7) / 8 < 4) {   // fewer 8-bit passes than the full 32-bit sort: sort key - min over `bits` bits (same order, same stability)
-        key_offset = mm[0];
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractKey{ key_offset }), keys_out,
+        *key_offset = mm[0];
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractKey{ *key_offset }), keys_out,
                                       rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, bits, st);
     } else {
         e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
     }
     if (e != hipSuccess) return e;
-    if (stage_ev) (void)hipEventRecord(stage_ev[2], st);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    return hipSuccess;
+}
+
+// stage_ev (or nullptr): four events recorded around the three stages (keys | radix sort | gather).
+hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out,
+                         void* temp, size_t temp_bytes, float4* sorted, float4* plane, bool plane_valid, hipEvent_t* stage_ev, hipStream_t st,
+                         uint32_t* key_offset_out, uint32_t* pinned_mm) {
+    if (key_offset_out) *key_offset_out = 0;
+    if (!n) return hipSuccess;
+    uint32_t key_offset = 0;
+    hipError_t e = keys_and_sort(rec, n, view, nullptr, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, stage_ev, st, &key_offset, pinned_mm);
+    if (e != hipSuccess) return e;
     const size_t nq = (size_t)n * 6;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
     if (stage_ev) (void)hipEventRecord(stage_ev[3], st);
     if (key_offset_out) *key_offset_out = key_offset;            // keys_out holds key - offset (m2s_device_sorted_keys puts it back on demand)
     else launch_add_to_keys(keys_out, n, key_offset, st);
     return hipGetLastError();
+}
+
+// The viewer's depth sort taken BEFORE its prepass (m2s_prepass_sorted, m2s_viewer.cpp): the permutation that orders the records by the
+// depth the prepass is going to store (model = u_modelToWorld, view = u_worldToView, both column-major), no gather — the prepass reads the
+// records through it and appends its survivors in that order, so the 96-byte gather of RadixSortPass::gatherPost (radixSortGather.glsl)
+// and the prepass's own read of the records become ONE pass over them.
+hipError_t sort_prepass_permutation(const float4* rec, uint32_t n, const float model[16], const float view[16], uint32_t* keys_in, uint32_t* keys_out,
+                                    uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid, hipEvent_t* ev, hipStream_t st,
+                                    uint32_t* pinned_mm) {
+    if (!n) return hipSuccess;
+    DepthMV mv;
+    memcpy(mv.M, model, sizeof mv.M);
+    memcpy(mv.V, view, sizeof mv.V);
+    uint32_t key_offset = 0;
+    const hipError_t e = keys_and_sort(rec, n, view, &mv, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, ev, st, &key_offset, pinned_mm);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 // RadixSortPass::execute proper (RadixSortPass.cpp:8-90), on the prepass output: keys are the raw bits of

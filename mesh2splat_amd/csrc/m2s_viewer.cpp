@@ -103,7 +103,9 @@ m2s_status m2s_last_sort_stage_ms(const m2s_ctx* c, float out_ms[3]) {
 }
 
 // GaussiansPrepass::execute (GaussiansPrepass.cpp:8-56) + the counter read-back that follows it (RadixSortPass.cpp:18-22).
-m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {
+// sorted = m2s_prepass_sorted: the depth sort of RadixSortPass::execute taken FIRST, as a permutation of the records by the depth bits this
+// prepass stores; the prepass then reads the records through it and appends its survivors in that order, straight into the sorted-quads buffer.
+static m2s_status prepass_impl(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible, bool sorted) {
     if (!c || !p) return M2S_ERR_INVALID;
     if (c->slot_count) return fail(c, M2S_ERR_STATE, "conversions are still in flight: m2s_convert_wait first");
     if (!d_records) {
@@ -121,13 +123,43 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     c->sq_n = 0;
     if (out_visible) *out_visible = 0;
     if (!n) return M2S_OK;
-    if (c->pp_cap < n) {
+    if (!sorted && c->pp_cap < n) {
         if (c->d_quads) { (void)hipFree(c->d_quads); c->d_quads = nullptr; }
-        if (c->d_pp_depths) { (void)hipFree(c->d_pp_depths); c->d_pp_depths = nullptr; }
         c->pp_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_quads, n * sizeof(m2s_quad)));
-        HIPCHK(c, hipMalloc((void**)&c->d_pp_depths, n * sizeof(float)));
         c->pp_cap = n;
+    }
+    if (c->pp_depths_cap < n) {
+        if (c->d_pp_depths) { (void)hipFree(c->d_pp_depths); c->d_pp_depths = nullptr; }
+        c->pp_depths_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_pp_depths, n * sizeof(float)));
+        c->pp_depths_cap = n;
+    }
+    const uint32_t* perm = nullptr;
+    if (sorted) {   // room for the sorted survivors, the keys / permutation, the radix sort's work area and the position plane
+        if (c->sq_cap < n) {
+            if (c->d_sorted_quads) { (void)hipFree(c->d_sorted_quads); c->d_sorted_quads = nullptr; c->sq_cap = 0; }
+            HIPCHK(c, hipMalloc(&c->d_sorted_quads, n * sizeof(m2s_quad)));
+            c->sq_cap = n;
+        }
+        if (c->sort_u32_cap < n) {
+            if (c->d_sort_u32) { (void)hipFree(c->d_sort_u32); c->d_sort_u32 = nullptr; c->sort_u32_cap = 0; }
+            HIPCHK(c, hipMalloc((void**)&c->d_sort_u32, n * 4 * sizeof(uint32_t)));
+            c->sort_u32_cap = n;
+        }
+        const size_t tb = sort_temp_bytes((uint32_t)n);
+        if (c->sort_temp_cap < tb) {
+            if (c->d_sort_temp) { (void)hipFree(c->d_sort_temp); c->d_sort_temp = nullptr; c->sort_temp_cap = 0; }
+            HIPCHK(c, hipMalloc(&c->d_sort_temp, std::max<size_t>(tb, 256)));
+            c->sort_temp_cap = tb;
+        }
+        if (c->pos_plane_cap < n) {
+            if (c->d_pos_plane) { (void)hipFree(c->d_pos_plane); c->d_pos_plane = nullptr; c->pos_plane_cap = 0; }
+            c->pos_plane_n = 0;
+            if (hipMalloc(&c->d_pos_plane, n * 16) == hipSuccess) c->pos_plane_cap = n;   // (without it every frame's keys read the records: slower, not wrong)
+            else (void)hipGetLastError();
+        }
+        c->sorted_n = 0;          // (the key / permutation words are shared with m2s_sort_by_depth: its sorted keys are gone)
     }
     const uint64_t words = (n + 63) / 64 + 1;          // [0] = the arrival-order counter, [1..] = the look-back chain
     // the chain is tagged with the low 16 bits of a launch counter instead of being cleared per launch; cleared when
@@ -144,6 +176,7 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
         HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, c->pp_chain_words * sizeof(unsigned long long), c->stream));
     PrepassK k;
     prepass_prepare(*p, n, &k);
+    if (sorted) k.arrival_order = 0;            // the order of the survivors IS the result
     if (p->depth_test_mesh == 1 && p->format == 0) {
         if (p->depth_on_device) k.depth = p->depth;
         else {
@@ -160,17 +193,43 @@ m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_re
     unsigned long long* res = &c->h_total[m2s_ctx::kPinnedPrepass];
     res[0] = 0; res[1] = 0;
     if (k.arrival_order) HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, sizeof(unsigned long long), c->stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)c->d_quads, c->d_pp_depths, c->d_pp_chain + 1, epoch,
-                             c->d_pp_chain, &res[0], reinterpret_cast<uint32_t*>(&res[1]), c->stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (sorted) {
+        const bool plane_valid = c->d_pos_plane && c->pos_plane_of == c->last_records && c->pos_plane_n == n && c->pos_plane_epoch == c->records_epoch;
+        uint32_t* u = c->d_sort_u32;     // keys_in | (unused) | keys_out | vals_out = the permutation
+        HIPCHK(c, sort_prepass_permutation((const float4*)d_records, (uint32_t)n, k.M, k.V, u, u + 2 * n, u + 3 * n, c->d_sort_temp, c->sort_temp_cap,
+                                           (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream,
+                                           reinterpret_cast<uint32_t*>(&c->h_total[m2s_ctx::kPinnedSortMM])));
+        if (c->d_pos_plane) { c->pos_plane_of = c->last_records; c->pos_plane_n = n; c->pos_plane_epoch = c->records_epoch; }
+        perm = u + 3 * n;
+    }
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)(sorted ? c->d_sorted_quads : c->d_quads), c->d_pp_depths, c->d_pp_chain + 1,
+                             epoch, c->d_pp_chain, &res[0], reinterpret_cast<uint32_t*>(&res[1]), c->stream, perm));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     if (k.arrival_order) HIPCHK(c, hipMemcpyAsync(&res[0], c->d_pp_chain, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->profiling) HIPCHK(c, hipEventElapsedTime(&c->last_prepass_ms, c->ev[0], c->ev[1]));
+    if (c->profiling) {
+        HIPCHK(c, hipEventElapsedTime(&c->last_prepass_ms, c->ev[3], c->ev[4]));
+        if (sorted) {
+            for (int j = 0; j < 2; ++j) HIPCHK(c, hipEventElapsedTime(&c->last_sort_stage_ms[j], c->ev[j], c->ev[j + 1]));
+            c->last_sort_stage_ms[2] = c->last_prepass_ms;
+            HIPCHK(c, hipEventElapsedTime(&c->last_sort_ms, c->ev[0], c->ev[4]));
+        }
+    }
     if (reinterpret_cast<uint32_t*>(&res[1])[1]) return fail(c, M2S_ERR_HIP, "prepass: look-back chain timed out");
-    c->pp_visible = res[0];
+    if (sorted) c->sq_n = res[0]; else c->pp_visible = res[0];
     if (out_visible) *out_visible = res[0];
     return M2S_OK;
+}
+
+m2s_status m2s_prepass(m2s_ctx* c, const m2s_prepass_params* p, const void* d_records, uint64_t n, uint64_t* out_visible) {
+    return prepass_impl(c, p, d_records, n, out_visible, false);
+}
+
+// GaussiansPrepass::execute + RadixSortPass::execute (GaussiansPrepass.cpp:8-56, RadixSortPass.cpp:8-90) of one frame as ONE pass over the
+// records: == m2s_prepass (input order) followed by m2s_sort_prepass, byte for byte, in m2s_device_sorted_quads.
+m2s_status m2s_prepass_sorted(m2s_ctx* c, const m2s_prepass_params* p, uint64_t* out_visible) {
+    return prepass_impl(c, p, nullptr, 0, out_visible, true);
 }
 
 const void* m2s_device_quads(const m2s_ctx* c) { return c && c->pp_visible ? c->d_quads : nullptr; }

@@ -270,3 +270,47 @@ def test_the_last_cull_test_is_reproduced_on_needles(conv, oracle):
     assert only_early[0] + 10000 < want[0] < only_early[0] + 19000          # most needles survive, thousands fail the last test
     got = conv.prepass(p, records=torch.from_numpy(rec).cuda())
     assert_prepass_matches(got, want, p.render_mode, "needles")
+
+
+@pytest.mark.parametrize("name", ["colour", "ply_classic"])
+def test_prepass_sorted_is_prepass_then_radix_sort_in_one_pass(conv, oracle, name):
+    """m2s_prepass_sorted: the frame's depth sort taken FIRST (permutation by the depth bits the prepass is going to store), the prepass
+    through it — against m2s_prepass + m2s_sort_prepass on the same records (byte for byte) and against the oracle's prepass ordered by
+    numpy's stable argsort.  Duplicated records (equal keys: stability), hostile records (NaN / huge / culled), a model matrix that is
+    not the identity, a second frame from another camera (the position plane of the first is reused), new records (it is not)."""
+    from dataclasses import replace
+    p = dict(CASES)[name]
+    rec = np.concatenate([prepass_cases.base_records(oracle, 20, 96), prepass_cases.hostile_records(4096)])
+    rec = np.concatenate([rec, rec[:5000]])
+    if name == "ply_classic":
+        rec = rec.copy()
+    conv.upload_records(rec)
+    for frame in range(2):
+        if frame == 1:           # another camera and a model matrix with rotation + non-uniform scale + translation
+            view, proj = prepass_cases.default_camera((800, 450))
+            model = np.array([[0.0, 1.3, 0.0, 0.0], [-0.7, 0.0, 0.0, 0.0], [0.0, 0.0, 1.1, 0.0], [0.05, -0.1, 0.2, 1.0]], np.float32)   # column-major rows = columns
+            p = replace(p, view_mat=view, proj_mat=proj, model_mat=model, renderer_resolution=(800, 450))
+        wk, wq, wd = oracle.prepass(p, rec)
+        want = wq[np.argsort(wd.view(np.uint32), kind="stable")]
+        gk, _, _ = conv.prepass(p)
+        two_calls = conv.sort_prepass()
+        assert gk == wk and same_bits(two_calls, want).all()
+        conv.set_profiling(True)
+        fused = conv.prepass_sorted(p)
+        conv.set_profiling(False)
+        assert fused.shape == (wk, 24), (frame, fused.shape, wk)
+        assert np.array_equal(bits(fused), bits(two_calls)), (frame, np.argwhere(bits(fused) != bits(two_calls))[:4].tolist())
+        st = conv.last_sort_stage_ms          # keys | radix sort | (here) the prepass through the permutation
+        assert st["keys"] > 0 and st["radix_sort"] > 0 and st["gather"] > 0
+    # new records: the cached position plane belongs to the old ones and must not be used
+    rec2 = rec[::-1].copy()
+    rec2[:, 0:3] *= np.float32(0.5)
+    conv.upload_records(rec2)
+    wk, wq, wd = oracle.prepass(p, rec2)
+    fused = conv.prepass_sorted(p)
+    assert fused.shape == (wk, 24) and same_bits(fused, wq[np.argsort(wd.view(np.uint32), kind="stable")]).all()
+    # nothing visible -> nothing sorted
+    far = rec.copy()
+    far[:, 0:3] = 1e6
+    conv.upload_records(far)
+    assert conv.prepass_sorted(p, download=False) == 0
