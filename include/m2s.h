@@ -348,7 +348,9 @@ float m2s_last_sort_prepass_ms(const m2s_ctx* ctx);
  * records of the context (its last conversion, or m2s_set_records / m2s_upload_records): the depth sort is taken FIRST — keys = the bits of
  * the view-space depth the prepass is about to store (from the 16-byte position plane the context keeps of its current records), stable
  * radix sort of (key, record index) — and the prepass then reads the records THROUGH that permutation and appends its survivors in that
- * order: the 96-byte gather of RadixSortPass::gatherPost (radixSortGather.glsl:30-49) and the prepass's own read become one pass.
+ * order: the 96-byte gather of RadixSortPass::gatherPost (radixSortGather.glsl:30-49) and the prepass's own read become one pass.  Without a depth
+ * image (depth_test_mesh == 0, or format != 0) the sort applies the prepass's frustum test itself — it depends on the position alone — and the
+ * prepass runs over the survivors only.
  * Result: m2s_device_sorted_quads / m2s_download_sorted_quads hold exactly what m2s_prepass (input order) followed by m2s_sort_prepass
  * leaves there, byte for byte; *out_visible = their number.  params->arrival_order is ignored (the order IS the result); the unsorted quads
  * of m2s_prepass are not produced.  m2s_last_sort_stage_ms: [0] keys, [1] radix sort, [2] the prepass through the permutation. */

@@ -47,7 +47,7 @@ struct m2s_ctx {
     static constexpr int kPinnedPrepass = 2 + 2 * M2S_MAX_IN_FLIGHT;   // m2s_prepass: TWO words — survivors, then the status words of its look-back
     static constexpr int kPinnedSortMM = 4 + 2 * M2S_MAX_IN_FLIGHT;    // the depth sorts: {min, max} of the keys (two 32-bit words); NOT the prepass's second word —
                                                                        // m2s_prepass_sorted uses both inside one call
-    static constexpr int kPinnedWords = 5 + 2 * M2S_MAX_IN_FLIGHT;
+    static constexpr int kPinnedWords = 6 + 2 * M2S_MAX_IN_FLIGHT;                  // (the sorts' word and the one behind it: {min, max}, {survivors, clash})
     unsigned long long* d_chain = nullptr;  // look-back chain of the fused kernel, one word per wave
     m2s::BigItem* d_biglist = nullptr;           // triangles deferred by the fused kernel (capacity: triangles in range)
     uint32_t* d_bigmeta = nullptr;          // [0] entries in d_biglist, [1] largest, [2] total fragment count; zero between conversions

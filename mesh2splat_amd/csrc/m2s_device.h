@@ -201,10 +201,11 @@ struct PrepassK {
 struct m2s_prepass_params;
 namespace m2s {
 void prepass_prepare(const m2s_prepass_params& p, uint64_t n, PrepassK* out);
-// perm (or nullptr): record index of every position — the prepass then reads record perm[i] at position i (m2s_prepass_sorted)
+// perm (or nullptr): record index of every position — the prepass then reads record perm[i] at position i (m2s_prepass_sorted);
+// dense: every one of the n positions is known to survive (the sort in front applied the frustum test): written at its own position, no append
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
                           uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st,
-                          const uint32_t* perm = nullptr);
+                          const uint32_t* perm = nullptr, bool dense = false);
 
 size_t sort_prepass_temp_bytes(uint32_t n);
 hipError_t sort_prepass(const float* depths, const float4* quads, uint32_t n, uint32_t* keys_out, uint32_t* vals_out, void* temp,
@@ -217,9 +218,10 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
                          uint32_t* key_offset_out, uint32_t* pinned_mm /* two pinned host words for the key range, or NULL */);
 void launch_add_to_keys(uint32_t* keys, uint32_t n, uint32_t offset, hipStream_t st);
 // keys = the depth bits the PREPASS stores (model, view as in PrepassK), stable radix sort, no gather: vals_out = the permutation
-hipError_t sort_prepass_permutation(const float4* rec, uint32_t n, const float model[16], const float view[16], uint32_t* keys_in, uint32_t* keys_out,
-                                    uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid, hipEvent_t* ev, hipStream_t st,
-                                    uint32_t* pinned_mm);
+// cull: the prepass's frustum test applied to the keys (survivors first: *n_visible of them; *clash: call again without cull); pinned_mm4: FOUR words
+hipError_t sort_prepass_permutation(const float4* rec, uint32_t n, const float model[16], const float view[16], const float proj[16], bool cull,
+                                    uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid,
+                                    hipEvent_t* ev, hipStream_t st, uint32_t* pinned_mm4, uint32_t* n_visible, bool* clash);
 
 // sample sort across ranks (m2s_dist.cpp): evenly spaced samples of sorted keys; split points of sorted keys
 void launch_pick_samples(const uint32_t* keys, uint64_t n, uint32_t s, unsigned long long* out, hipStream_t st);

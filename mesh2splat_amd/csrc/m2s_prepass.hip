@@ -21,6 +21,7 @@
 //            order — with one atomic per workgroup: no wait at all, the kernel then runs at the device's copy rate.
 #include "../../include/m2s.h"
 #include "m2s_fused_common.h"
+#include "m2s_viewmath.h"
 
 #include <cmath>
 #include <cstring>
@@ -50,13 +51,7 @@ __device__ __forceinline__ M3 m3_transpose(const M3& a) {
         for (int i = 0; i < 3; ++i) r.c[c][i] = a.c[i][c];
     return r;
 }
-// mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*w)
-__device__ __forceinline__ float4 m4_mul(const float* m, float x, float y, float z, float w) {
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (m[0 + i] * x + m[4 + i] * y) + (m[8 + i] * z + m[12 + i] * w);
-    return make_float4(r[0], r[1], r[2], r[3]);
-}
+// (mat4 * vec4 and the projection + frustum test of :67-77: m2s_viewmath.h, shared with the depth sort's key kernel)
 __device__ __forceinline__ float min_glsl(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float max_glsl(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float clamp01(float x) { return min_glsl(max_glsl(x, 0.0f), 1.0f); }
@@ -78,11 +73,8 @@ __device__ __forceinline__ bool prepass_one(const PrepassK& k, const float4 (&g)
     const float4 gpos = g[0], gcol = g[1], gscl = g[2], gnrm = g[3], grot = g[4], gpbr = g[5];
     // ---- the shader ------------------------------------------------------------------------------------------
     bool vis = valid;
-    const float4 ws = m4_mul(k.M, gpos.x, gpos.y, gpos.z, 1.0f);                 // :67
-    const float4 vs = m4_mul(k.V, ws.x, ws.y, ws.z, 1.0f);                       // :69
-    float4 pos2d = m4_mul(k.P, vs.x, vs.y, vs.z, vs.w);                          // :71
-    const float clip = 1.05f * pos2d.w;                                          // :73
-    if (pos2d.z < -clip || pos2d.x < -clip || pos2d.x > clip || pos2d.y < -clip || pos2d.y > clip) vis = false;   // :75-77
+    float4 ws, vs, pos2d;
+    if (!view_project(k.M, k.V, k.P, gpos.x, gpos.y, gpos.z, ws, vs, pos2d)) vis = false;   // :67-77
 
     if (k.depth_test == 1u && gcol.w > .95f && k.format == 0u && vis) {          // :80-92
         const float u = (pos2d.x / pos2d.w) * 0.5f + 0.5f, v = (pos2d.y / pos2d.w) * 0.5f + 0.5f;
@@ -213,7 +205,7 @@ constexpr uint32_t kPPTile = kPPWaves * 64u * kPPRec;   // records per workgroup
 __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, const float4* __restrict__ rec, uint32_t n, float4* __restrict__ quads,
                                                     float* __restrict__ depths, unsigned long long* __restrict__ chain, uint32_t epoch,
                                                     unsigned long long* __restrict__ counter, unsigned long long* __restrict__ total,
-                                                    uint32_t* __restrict__ status, const uint32_t* __restrict__ perm) {
+                                                    uint32_t* __restrict__ status, const uint32_t* __restrict__ perm, uint32_t dense) {
     __shared__ float4 s_rec[kPPWaves][64 * 6];   // survivors of ONE 64-record group, staged for contiguous stores
     __shared__ float s_depth[kPPWaves][64];
     __shared__ uint32_t s_cnt[kPPWaves];
@@ -247,6 +239,12 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
 #pragma unroll
     for (int r = 0; r < kPPRec; ++r) {
         vis[r] = prepass_one(k, g[r], perm ? src[r] : first + (uint32_t)r * 64u + (uint32_t)lane, valid[r], q[r], dvs[r]);   // (gid = the RECORD's index)
+        if (dense) {
+            // the sort in front of this launch already applied the frustum test (same function: m2s_viewmath.h) and put the survivors first:
+            // every one of the n positions survives, position i is written at i.  A disagreement would be a bug: reported, never silent.
+            if (valid[r] && !vis[r]) __hip_atomic_store(&status[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            vis[r] = valid[r];
+        }
         const unsigned long long mask = __ballot(vis[r]);
         cnt[r] = (uint32_t)__popcll(mask);
         rank[r] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -261,6 +259,10 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
     const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     if (lane == 0) s_cnt[wave] = wcnt;
     __syncthreads();
+    if (dense) {
+        // no append: the workgroup's first position is its base, and the total is known to the host
+        if (wave == 0 && lane == 0) s_base = (unsigned long long)blockIdx.x * kPPTile;
+    } else
     if (wave == 0) {
         const uint32_t bid = blockIdx.x, last = gridDim.x - 1u;
         uint32_t tot = 0;
@@ -323,9 +325,10 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
 
 hipError_t launch_prepass(const PrepassK& k, const float4* rec, uint32_t n, float4* quads, float* depths, unsigned long long* chain,
                           uint32_t epoch, unsigned long long* counter, unsigned long long* total, uint32_t* status, hipStream_t st,
-                          const uint32_t* perm) {
+                          const uint32_t* perm, bool dense) {
     const uint32_t nb = (n + kPPTile - 1u) / kPPTile;
-    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status, perm);
+    hipLaunchKernelGGL(k_prepass, dim3(nb), dim3(kPPWaves * 64), 0, st, k, rec, n, quads, depths, chain, epoch & 0xFFFFu, counter, total, status, perm,
+                       dense ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "m2s_device.h"
+#include "m2s_viewmath.h"
 
 #pragma clang fp contract(off)
 
@@ -26,17 +27,12 @@ __device__ __forceinline__ uint32_t depth_key(float4 p, float v02, float v12, fl
     const float z = ((v02 * p.x + v12 * p.y) + v22 * p.z) + v32;
     return __float_as_uint(z);
 }
-// The key the viewer's own sort uses (RadixSortPass.cpp:16-45): the raw bits of gaussianDepthPostFiltering = the prepass's view-space z,
-// vs = u_worldToView * (u_modelToWorld * vec4(P, 1)) with mat4 * vec4 as (m0 x + m1 y) + (m2 z + m3 w) — m2s_prepass.hip's m4_mul,
-// operation for operation, so that sorting BEFORE the prepass (sort_prepass_permutation) orders by exactly the bits the prepass will store.
-struct DepthMV { float M[16], V[16]; };
-__device__ __forceinline__ uint32_t depth_key_mv(float4 p, const DepthMV& x) {
-    float w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (x.M[0 + i] * p.x + x.M[4 + i] * p.y) + (x.M[8 + i] * p.z + x.M[12 + i] * 1.0f);
-    const float z = (x.V[2] * w[0] + x.V[6] * w[1]) + (x.V[10] * w[2] + x.V[14] * w[3]);
-    return __float_as_uint(z);
-}
+// The key the viewer's own sort uses (RadixSortPass.cpp:16-45): the raw bits of gaussianDepthPostFiltering = the prepass's view-space z — taken
+// from m2s_viewmath.h's view_project, the very function k_prepass calls, so that sorting BEFORE the prepass (sort_prepass_permutation) orders by
+// exactly the bits the prepass will store.  cull: records the prepass's frustum test rejects get the key kCulledKey and sort behind every
+// survivor (they are counted; min / max are taken over the survivors only): the prepass then runs over the first `visible` positions alone.
+struct DepthMVP { float M[16], V[16], P[16]; uint32_t cull; };
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu;
 // Both key kernels also leave the smallest and the largest key of every WAVE behind (wave_mm[wave] = {min, max}: one 8-byte store per 64
 // records) and k_reduce_minmax folds those into minmax[0] / [1]: view-space depths of a bounded scene share their sign and most of their
 // exponent, so the keys differ only in their low 20-25 bits — sort_by_depth sorts `key - min` over exactly the bits that differ and saves a
@@ -88,18 +84,42 @@ __global__ void __launch_bounds__(kBlock) k_depth_keys_from_plane(const float4* 
     reduce_minmax(kmin, kmax, minmax);
 }
 
-__global__ void __launch_bounds__(kBlock) k_depth_keys_mv(const float4* __restrict__ rec, const float4* __restrict__ plane_in, uint32_t n, DepthMV x,
-                                                          uint32_t* __restrict__ key, float4* __restrict__ plane_out, uint2* __restrict__ minmax) {
+// wave_cnt (cull mode): survivors of every wave; bit 31 set if one of them has the key kCulledKey itself (a NaN depth with that payload:
+// the caller then falls back to the prepass's own compaction)
+__global__ void __launch_bounds__(kBlock) k_depth_keys_mv(const float4* __restrict__ rec, const float4* __restrict__ plane_in, uint32_t n, DepthMVP x,
+                                                          uint32_t* __restrict__ key, float4* __restrict__ plane_out, uint2* __restrict__ minmax,
+                                                          uint32_t* __restrict__ wave_cnt) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    bool vis = false, clash = false;
     if (i < n) {
         const float4 p = plane_in ? plane_in[i] : rec[(size_t)i * 6];
-        const uint32_t k = depth_key_mv(p, x);
+        float4 ws, vs, pos2d;
+        vis = view_project(x.M, x.V, x.P, p.x, p.y, p.z, ws, vs, pos2d) || !x.cull;
+        uint32_t k = __float_as_uint(vs.z);
+        clash = vis && x.cull && k == kCulledKey;
+        if (!vis) k = kCulledKey;
         key[i] = k;
         if (plane_out) plane_out[i] = p;
-        kmin = kmax = k;
+        if (vis) kmin = kmax = k;
+    }
+    if (x.cull) {
+        const unsigned long long m = __ballot(vis);
+        const unsigned long long c = __ballot(clash);
+        if ((threadIdx.x & 63) == 0) wave_cnt[(blockIdx.x * kBlock + threadIdx.x) >> 6] = (uint32_t)__popcll(m) | (c ? 0x80000000u : 0u);
     }
     reduce_minmax(kmin, kmax, minmax);
+}
+// minmax[2] += survivors, minmax[3] |= clash flag
+__global__ void __launch_bounds__(kBlock) k_reduce_counts(const uint32_t* __restrict__ wave_cnt, uint32_t n_waves, uint32_t* __restrict__ minmax) {
+    uint32_t sum = 0, flag = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_waves; i += gridDim.x * kBlock) {
+        const uint32_t v = wave_cnt[i];
+        sum += v & 0x7FFFFFFFu; flag |= v >> 31;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, d); flag |= (uint32_t)__shfl_xor((int)flag, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&minmax[2], sum); if (flag) atomicOr(&minmax[3], 1u); }
 }
 
 __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restrict__ src, const uint32_t* __restrict__ val,
@@ -125,9 +145,14 @@ struct SubtractKey {
     uint32_t m;
     __host__ __device__ uint32_t operator()(uint32_t k) const { return k - m; }
 };
+// cull mode: survivors' keys minus the smallest one; the culled ones (kCulledKey) all become `behind` = one more than the largest survivor
+struct SubtractOrBehind {
+    uint32_t m, behind;
+    __host__ __device__ uint32_t operator()(uint32_t k) const { return k == kCulledKey ? behind : k - m; }
+};
 
 size_t sort_temp_bytes(uint32_t n) {
-    size_t bytes = 0, bytes_t = 0;
+    size_t bytes = 0, bytes_t = 0, bytes_c = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 32,
                                     (hipStream_t)0);
     (void)rocprim::radix_sort_pairs(nullptr, bytes_t, rocprim::make_transform_iterator((uint32_t*)nullptr, SubtractKey{ 0u }), (uint32_t*)nullptr,
@@ -135,7 +160,11 @@ size_t sort_temp_bytes(uint32_t n) {
     // + the two words of the key range and the per-wave {min, max} table of the key kernels (at the end of the buffer): one entry for
     // EVERY wave of the key kernels' grid, the idle waves of the last workgroup included ((n + 63) / 64 entries were up to
     // three short of what the grid writes)
-    return (((bytes > bytes_t ? bytes : bytes_t) + 15) & ~(size_t)15) + 16 + (size_t)sort_grid_waves(n) * 8;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes_c, rocprim::make_transform_iterator((uint32_t*)nullptr, SubtractOrBehind{ 0u, 0u }), (uint32_t*)nullptr,
+                                    rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, n, 0, 24, (hipStream_t)0);
+    const size_t lib = std::max(bytes, std::max(bytes_t, bytes_c));
+    // (... and one survivor count per wave behind that table: m2s_prepass_sorted's cull mode)
+    return ((lib + 15) & ~(size_t)15) + 16 + (size_t)sort_grid_waves(n) * 12;
 }
 
 // Keys of the n records + their stable radix sort: vals_out = the permutation (record index of every sorted position), keys_out = the
@@ -143,43 +172,63 @@ size_t sort_temp_bytes(uint32_t n) {
 // row view[2], view[6], view[10], view[14] (m2s_sort_by_depth); else the prepass's own depth bits (depth_key_mv).
 // plane: room for n float4 or nullptr; plane_valid: it already holds the positions of these records.  ev (or nullptr): events around the
 // key stage and the radix sort (ev[0], ev[1], ev[2]).  The values are the record indices: they come from a counting iterator, not from memory.
-static hipError_t keys_and_sort(const float4* rec, uint32_t n, const float view[16], const DepthMV* mv, uint32_t* keys_in, uint32_t* keys_out,
+static hipError_t keys_and_sort(const float4* rec, uint32_t n, const float view[16], const DepthMVP* mv, uint32_t* keys_in, uint32_t* keys_out,
                                 uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid, hipEvent_t* ev, hipStream_t st,
-                                uint32_t* key_offset, uint32_t* pinned_mm) {
+                                uint32_t* key_offset, uint32_t* pinned_mm /* mv && mv->cull: FOUR pinned words */, uint32_t* n_visible, bool* clash) {
     *key_offset = 0;
+    if (n_visible) *n_visible = n;
+    if (clash) *clash = false;
+    const bool cull = mv && mv->cull;
     const uint32_t n_waves = sort_grid_waves(n);       // (idle waves of the last workgroup store {0xFFFFFFFF, 0}: neutral for the fold)
-    const size_t tail = 16 + (size_t)n_waves * 8;
+    const size_t tail = 16 + (size_t)n_waves * 12;
     if (temp_bytes < tail + 16) return hipErrorInvalidValue;
     temp_bytes = (temp_bytes - tail) & ~(size_t)15;
-    uint32_t* minmax = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + temp_bytes);
+    uint32_t* minmax = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + temp_bytes);     // {min, max, survivors, clash}
     uint2* wave_mm = reinterpret_cast<uint2*>(minmax + 4);
-    const uint32_t init[2] = { 0xFFFFFFFFu, 0u };
+    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(wave_mm + n_waves);
+    const uint32_t init[4] = { 0xFFFFFFFFu, 0u, 0u, 0u };
     hipError_t e = hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
     const dim3 grid((n + kBlock - 1) / kBlock);
     if (ev) (void)hipEventRecord(ev[0], st);
     const bool from_plane = plane && plane_valid;
     if (mv) hipLaunchKernelGGL(k_depth_keys_mv, grid, dim3(kBlock), 0, st, rec, from_plane ? (const float4*)plane : (const float4*)nullptr, n, *mv, keys_in,
-                               from_plane ? (float4*)nullptr : plane, wave_mm);
+                               from_plane ? (float4*)nullptr : plane, wave_mm, wave_cnt);
     else if (from_plane) hipLaunchKernelGGL(k_depth_keys_from_plane, grid, dim3(kBlock), 0, st, plane, n, view[2], view[6], view[10], view[14], keys_in, wave_mm);
     else hipLaunchKernelGGL(k_depth_keys, grid, dim3(kBlock), 0, st, rec, n, view[2], view[6], view[10], view[14], keys_in, plane, wave_mm);
-    hipLaunchKernelGGL(k_reduce_minmax, dim3(std::min<uint32_t>((n_waves + kBlock - 1) / kBlock, 256u)), dim3(kBlock), 0, st, wave_mm, n_waves, minmax);
+    const dim3 fold(std::min<uint32_t>((n_waves + kBlock - 1) / kBlock, 256u));
+    hipLaunchKernelGGL(k_reduce_minmax, fold, dim3(kBlock), 0, st, wave_mm, n_waves, minmax);
+    if (cull) hipLaunchKernelGGL(k_reduce_counts, fold, dim3(kBlock), 0, st, wave_cnt, n_waves, minmax);
     if (ev) (void)hipEventRecord(ev[1], st);
-    // the keys' range decides how many radix passes the library makes: 8 bytes come back to the host (one sync, ~15 us of a ~1.7 ms call)
-    uint32_t mm_local[2] = { 0u, 0xFFFFFFFFu };
+    // the keys' range decides how many radix passes the library makes: 8 (16) bytes come back to the host (one sync, ~15 us of a ~1.7 ms call)
+    uint32_t mm_local[4] = { 0u, 0xFFFFFFFFu, n, 0u };
     uint32_t* mm = pinned_mm ? pinned_mm : mm_local;          // (pinned: the copy is a DMA the sync waits for, not a staged pageable copy)
-    e = hipMemcpyAsync(mm, minmax, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    e = hipMemcpyAsync(mm, minmax, (cull ? 4 : 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
+    if (cull) {
+        if (n_visible) *n_visible = mm[2];
+        if (clash) *clash = mm[3] != 0u;
+        if (mm[2] == 0u) { if (ev) (void)hipEventRecord(ev[2], st); return hipSuccess; }      // nothing survives: nothing to sort
+    }
     const uint32_t range = mm[1] >= mm[0] ? mm[1] - mm[0] : 0xFFFFFFFFu;
-    int bits = 1;
-    while (bits < 32 && (range >> bits) != 0u) ++bits;
-    if ((bits + 7) / 8 < 4) {   // fewer 8-bit passes than the full 32-bit sort: sort key - min over `bits` bits (same order, same stability)
+    if (cull && range != 0xFFFFFFFFu) {
+        // survivors: key - min in [0, range]; the culled records: range + 1 — behind all of them, in input order among themselves
+        int bits = 1;
+        while (bits < 32 && ((range + 1u) >> bits) != 0u) ++bits;
         *key_offset = mm[0];
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractKey{ *key_offset }), keys_out,
+        e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractOrBehind{ mm[0], range + 1u }), keys_out,
                                       rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, bits, st);
     } else {
-        e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
+        int bits = 1;
+        while (bits < 32 && (range >> bits) != 0u) ++bits;
+        if ((bits + 7) / 8 < 4) {   // fewer 8-bit passes than the full 32-bit sort: sort key - min over `bits` bits (same order, same stability)
+            *key_offset = mm[0];
+            e = rocprim::radix_sort_pairs(temp, temp_bytes, rocprim::make_transform_iterator(keys_in, SubtractKey{ *key_offset }), keys_out,
+                                          rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, bits, st);
+        } else {
+            e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<uint32_t>(0), vals_out, n, 0, 32, st);
+        }
     }
     if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[2], st);
@@ -193,7 +242,8 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
     if (key_offset_out) *key_offset_out = 0;
     if (!n) return hipSuccess;
     uint32_t key_offset = 0;
-    hipError_t e = keys_and_sort(rec, n, view, nullptr, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, stage_ev, st, &key_offset, pinned_mm);
+    hipError_t e = keys_and_sort(rec, n, view, nullptr, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, stage_ev, st, &key_offset, pinned_mm,
+                                 nullptr, nullptr);
     if (e != hipSuccess) return e;
     const size_t nq = (size_t)n * 6;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rec, vals_out, n, sorted);
@@ -207,15 +257,23 @@ hipError_t sort_by_depth(const float4* rec, uint32_t n, const float view[16], ui
 // depth the prepass is going to store (model = u_modelToWorld, view = u_worldToView, both column-major), no gather — the prepass reads the
 // records through it and appends its survivors in that order, so the 96-byte gather of RadixSortPass::gatherPost (radixSortGather.glsl)
 // and the prepass's own read of the records become ONE pass over them.
-hipError_t sort_prepass_permutation(const float4* rec, uint32_t n, const float model[16], const float view[16], uint32_t* keys_in, uint32_t* keys_out,
-                                    uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid, hipEvent_t* ev, hipStream_t st,
-                                    uint32_t* pinned_mm) {
+// cull: the prepass's frustum test is applied here (it depends on the position alone; NOT to be used when the prepass also tests against a
+// depth image, which needs the record's alpha): *n_visible = survivors, and they occupy the first *n_visible positions of the permutation.
+// *clash: a survivor's own key equals the marker of the culled ones (a NaN depth with an all-ones payload): call again without cull.
+hipError_t sort_prepass_permutation(const float4* rec, uint32_t n, const float model[16], const float view[16], const float proj[16], bool cull,
+                                    uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, void* temp, size_t temp_bytes, float4* plane, bool plane_valid,
+                                    hipEvent_t* ev, hipStream_t st, uint32_t* pinned_mm4, uint32_t* n_visible, bool* clash) {
+    if (n_visible) *n_visible = n;
+    if (clash) *clash = false;
     if (!n) return hipSuccess;
-    DepthMV mv;
+    DepthMVP mv;
     memcpy(mv.M, model, sizeof mv.M);
     memcpy(mv.V, view, sizeof mv.V);
+    memcpy(mv.P, proj, sizeof mv.P);
+    mv.cull = cull ? 1u : 0u;
     uint32_t key_offset = 0;
-    const hipError_t e = keys_and_sort(rec, n, view, &mv, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, ev, st, &key_offset, pinned_mm);
+    const hipError_t e = keys_and_sort(rec, n, view, &mv, keys_in, keys_out, vals_out, temp, temp_bytes, plane, plane_valid, ev, st, &key_offset, pinned_mm4,
+                                       n_visible, clash);
     return e != hipSuccess ? e : hipGetLastError();
 }
 

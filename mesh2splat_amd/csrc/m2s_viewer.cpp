@@ -193,18 +193,30 @@ static m2s_status prepass_impl(m2s_ctx* c, const m2s_prepass_params* p, const vo
     unsigned long long* res = &c->h_total[m2s_ctx::kPinnedPrepass];
     res[0] = 0; res[1] = 0;
     if (k.arrival_order) HIPCHK(c, hipMemsetAsync(c->d_pp_chain, 0, sizeof(unsigned long long), c->stream));
+    // Without a depth image the prepass's only test is the frustum test, a function of the position: the sort applies it to the keys
+    // (view_project, the prepass's own function), the culled records sort behind the survivors, and the prepass runs over the survivors
+    // alone — dense: no compaction, no look-back, no read of a record that is not drawn.
+    bool dense = false;
+    uint32_t n_run = (uint32_t)n;
     if (sorted) {
         const bool plane_valid = c->d_pos_plane && c->pos_plane_of == c->last_records && c->pos_plane_n == n && c->pos_plane_epoch == c->records_epoch;
         uint32_t* u = c->d_sort_u32;     // keys_in | (unused) | keys_out | vals_out = the permutation
-        HIPCHK(c, sort_prepass_permutation((const float4*)d_records, (uint32_t)n, k.M, k.V, u, u + 2 * n, u + 3 * n, c->d_sort_temp, c->sort_temp_cap,
-                                           (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream,
-                                           reinterpret_cast<uint32_t*>(&c->h_total[m2s_ctx::kPinnedSortMM])));
+        uint32_t* pinned4 = reinterpret_cast<uint32_t*>(&c->h_total[m2s_ctx::kPinnedSortMM]);
+        bool cull = k.depth_test == 0u, clash = false;
+        HIPCHK(c, sort_prepass_permutation((const float4*)d_records, (uint32_t)n, k.M, k.V, k.P, cull, u, u + 2 * n, u + 3 * n, c->d_sort_temp, c->sort_temp_cap,
+                                           (float4*)c->d_pos_plane, plane_valid, c->profiling ? c->ev : nullptr, c->stream, pinned4, &n_run, &clash));
         if (c->d_pos_plane) { c->pos_plane_of = c->last_records; c->pos_plane_n = n; c->pos_plane_epoch = c->records_epoch; }
+        if (cull && clash) {   // a survivor whose depth bits ARE the marker of the culled ones (a NaN with that payload): sort everything, compact in the prepass
+            cull = false;
+            HIPCHK(c, sort_prepass_permutation((const float4*)d_records, (uint32_t)n, k.M, k.V, k.P, false, u, u + 2 * n, u + 3 * n, c->d_sort_temp, c->sort_temp_cap,
+                                               (float4*)c->d_pos_plane, true, c->profiling ? c->ev : nullptr, c->stream, pinned4, &n_run, &clash));
+        }
+        dense = cull;
         perm = u + 3 * n;
     }
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, launch_prepass(k, (const float4*)d_records, (uint32_t)n, (float4*)(sorted ? c->d_sorted_quads : c->d_quads), c->d_pp_depths, c->d_pp_chain + 1,
-                             epoch, c->d_pp_chain, &res[0], reinterpret_cast<uint32_t*>(&res[1]), c->stream, perm));
+    if (n_run) HIPCHK(c, launch_prepass(k, (const float4*)d_records, n_run, (float4*)(sorted ? c->d_sorted_quads : c->d_quads), c->d_pp_depths, c->d_pp_chain + 1,
+                                        epoch, c->d_pp_chain, &res[0], reinterpret_cast<uint32_t*>(&res[1]), c->stream, perm, dense));
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     if (k.arrival_order) HIPCHK(c, hipMemcpyAsync(&res[0], c->d_pp_chain, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -216,7 +228,9 @@ static m2s_status prepass_impl(m2s_ctx* c, const m2s_prepass_params* p, const vo
             HIPCHK(c, hipEventElapsedTime(&c->last_sort_ms, c->ev[0], c->ev[4]));
         }
     }
+    if (reinterpret_cast<uint32_t*>(&res[1])[1] == 2u) return fail(c, M2S_ERR_HIP, "prepass_sorted: the sort's frustum test and the prepass's disagree (internal error)");
     if (reinterpret_cast<uint32_t*>(&res[1])[1]) return fail(c, M2S_ERR_HIP, "prepass: look-back chain timed out");
+    if (dense) res[0] = n_run;                  // (the survivors were counted by the sort; the dense prepass appends nothing)
     if (sorted) c->sq_n = res[0]; else c->pp_visible = res[0];
     if (out_visible) *out_visible = res[0];
     return M2S_OK;

@@ -272,12 +272,15 @@ def test_the_last_cull_test_is_reproduced_on_needles(conv, oracle):
     assert_prepass_matches(got, want, p.render_mode, "needles")
 
 
-@pytest.mark.parametrize("name", ["colour", "ply_classic"])
+@pytest.mark.parametrize("name", ["colour", "ply_classic", "inside", "depth_test", "model_trs"])
 def test_prepass_sorted_is_prepass_then_radix_sort_in_one_pass(conv, oracle, name):
     """m2s_prepass_sorted: the frame's depth sort taken FIRST (permutation by the depth bits the prepass is going to store), the prepass
     through it — against m2s_prepass + m2s_sort_prepass on the same records (byte for byte) and against the oracle's prepass ordered by
     numpy's stable argsort.  Duplicated records (equal keys: stability), hostile records (NaN / huge / culled), a model matrix that is
-    not the identity, a second frame from another camera (the position plane of the first is reused), new records (it is not)."""
+    not the identity, a second frame from another camera (the position plane of the first is reused), new records (it is not).
+    Without a depth image ("colour", "ply_classic", "model_trs"; "inside": a camera inside the object, most records behind the eye) the sort
+    applies the frustum test itself and the prepass runs densely over the survivors; with one ("depth_test") the prepass compacts as in
+    m2s_prepass."""
     from dataclasses import replace
     p = dict(CASES)[name]
     rec = np.concatenate([prepass_cases.base_records(oracle, 20, 96), prepass_cases.hostile_records(4096)])
@@ -295,6 +298,8 @@ def test_prepass_sorted_is_prepass_then_radix_sort_in_one_pass(conv, oracle, nam
         gk, _, _ = conv.prepass(p)
         two_calls = conv.sort_prepass()
         assert gk == wk and same_bits(two_calls, want).all()
+        if name == "inside" and frame == 0:
+            assert 0 < wk < rec.shape[0] // 2          # (most of the records are culled: the dense prepass runs over a minority)
         conv.set_profiling(True)
         fused = conv.prepass_sorted(p)
         conv.set_profiling(False)
@@ -314,3 +319,20 @@ def test_prepass_sorted_is_prepass_then_radix_sort_in_one_pass(conv, oracle, nam
     far[:, 0:3] = 1e6
     conv.upload_records(far)
     assert conv.prepass_sorted(p, download=False) == 0
+
+
+def test_prepass_sorted_when_a_survivors_depth_bits_are_the_culled_marker(conv, oracle):
+    """The sort marks culled records with the key 0xFFFFFFFF.  A record whose own depth IS that bit pattern (a NaN position with an all-ones
+    payload is not culled: every comparison of the frustum test is false) makes the marker ambiguous: m2s_prepass_sorted then sorts
+    everything and lets the prepass compact, as with a depth image.  Either way: the bytes of m2s_prepass + m2s_sort_prepass."""
+    p = dict(CASES)["colour"]
+    rec = prepass_cases.base_records(oracle, 12, 64).copy()
+    allones = np.array([0xFFFFFFFF], np.uint32).view(np.float32)[0]
+    rec[5::97, 0] = allones
+    rec[7::131, 2] = allones
+    conv.upload_records(rec)
+    gk, _, _ = conv.prepass(p)
+    two_calls = conv.sort_prepass()
+    fused = conv.prepass_sorted(p)
+    assert fused.shape == two_calls.shape == (gk, 24)
+    assert np.array_equal(bits(fused), bits(two_calls))
