@@ -92,6 +92,24 @@ __device__ __forceinline__ uint8_t* block_class(const float4* setup, uint32_t n_
     return reinterpret_cast<uint8_t*>(tall_header(setup, n_tri) + 4 + (size_t)kTallCap * kTallChunks);
 }
 
+#ifdef M2S_TIMELINE
+// Measurement build only (tools/timeline_probe.py; never part of the shipping library): every wave of the two kernels leaves
+// 100 MHz timestamps behind — k_count_scan eight per wave (its phases), k_emit2 start / end / batches / kind per wave.
+constexpr uint32_t kTlCountBlocks = 8192, kTlEmitWgs = 32768;
+__device__ unsigned long long g_tl_count[kTlCountBlocks * 4 * 8];
+__device__ unsigned long long g_tl_emit[kTlEmitWgs * 4 * 4];
+#define TLC(k) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0 && bid < kTlCountBlocks) g_tl_count[((size_t)bid * 4 + wave) * 8 + (k)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+struct TlEmitScope {
+    unsigned long long* p; unsigned long long nb, kind;
+    __device__ TlEmitScope(uint32_t wg, uint32_t wave, int lane) : p(nullptr), nb(0), kind(0) {
+        if (lane == 0 && wg < kTlEmitWgs) { p = &g_tl_emit[((size_t)wg * 4 + wave) * 4]; p[0] = wall_clock64(); }
+    }
+    __device__ ~TlEmitScope() { if (p) { p[1] = wall_clock64(); p[2] = nb; p[3] = kind; } }
+};
+#else
+#define TLC(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
     Raster r;
     const int x0 = (int)(s.ts.org & 0xFFFu), y0 = (int)(s.ts.org >> 12);
@@ -127,6 +145,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     const bool valid = t < sc.n_tri;
     const uint32_t lastT = min(blockBase + kCountBlock, sc.n_tri) - 1;
     bool uniform_mesh;
+    TLC(0);
     const uint32_t m0 = mesh_of_range(sc, blockBase, lastT, uniform_mesh);   // one scalar load (was: a binary search)
 
     float p[9];
@@ -147,6 +166,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     }
     const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
     uint32_t c = 0, c64 = 0;
+    TLC(1);
     if (ok && rows <= M2S_COUNT_ROWS) {
         RowWalker rw;
         row_walker_init(rs, rs.y0, rw);
@@ -158,6 +178,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         }
     }
     uint32_t tall_slot = 0;
+    TLC(2);
     {   // triangles spanning more rows: the whole wave counts one triangle, 64 rows at a time, one row per lane — and leaves the
         // running sums in the tall-triangle table (see kTallCap) for k_emit2.  Triangles of 65 .. M2S_COUNT_ROWS rows, counted by
         // their own lanes above, get a table entry as well (two chunks: 0 and the sum after 64 rows): a slice of k_emit2 that
@@ -198,6 +219,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         }
     }
     // ---- counts -> offsets: workgroup scan + decoupled look-back (chain word = one per workgroup) ----
+    TLC(3);
     const uint32_t incl = wave_incl_scan(c, lane);
     const bool wave_tall = __ballot(ok && rows > kRowsThread) != 0ull;
     if (lane == 63) { wsum[wave] = incl; wtall[wave] = wave_tall ? 1u : 0u; }
@@ -218,6 +240,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     // stand-in; without any setup 0.027 ms, without the look-back 0.030 ms: the two used to add up on the critical path.)
     if (wave == 0 && lane == 0)
         chain_store(&chain[bid], (bid == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
+    TLC(4);
     if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
         if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
@@ -235,6 +258,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
     }
 
+    TLC(5);
     if (wave == 0) {
         const uint32_t b = bid;
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
@@ -249,6 +273,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         }
     }
     __syncthreads();
+    TLC(6);
     const unsigned long long base = *base_sp;
     const unsigned long long o0 = base + woff + (incl - c);
     if (valid) {
@@ -271,6 +296,7 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         const uint32_t tt = __shfl(t, src);
         for (unsigned long long mm = f + lane; mm <= l && mm < n_start; mm += 64) start[mm] = tt;
     }
+    TLC(7);
 }
 
 
@@ -415,6 +441,10 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     const uint8_t* __restrict__ cls = block_class(setup, T);
     // the first workgroups of the launch (one per block of triangles, rounded up to whole groups of eight) take the FINE blocks
     const uint32_t n_tb = (T + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock, n_fine_wg = (n_tb + 7u) & ~7u;
+#ifdef M2S_TIMELINE
+    TlEmitScope tl(blockIdx.x, wave, lane);
+    tl.kind = blockIdx.x < n_fine_wg ? ((blockIdx.x < n_tb && cls[blockIdx.x]) ? 1 : 2) : 3;
+#endif
     if (blockIdx.x < n_fine_wg) {
         if (blockIdx.x < n_tb && cls[blockIdx.x]) emit_fine_block(sc, off, nw, setup, out, blockIdx.x, *reinterpret_cast<FineLds*>(lds_raw));
         return;
@@ -445,6 +475,9 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
         // ---- the batch: up to 64 consecutive triangles, one per lane.  A fine block is stepped over; a batch that would run from a
         // dense block into a fine one ends at the block boundary.  Everything the decision needs is requested at once (the classes of
         // this block and the next, the offsets at both possible ends, the lanes' own offsets): one round trip, as before round 5 ----
+#ifdef M2S_TIMELINE
+        tl.nb++;
+#endif
         const uint32_t blk = t_cur / (uint32_t)kCountBlock;
         const uint32_t blk_end = min((blk + 1u) * (uint32_t)kCountBlock, T);
         const uint32_t t_full = min(t_cur + 64u, T);
@@ -613,3 +646,16 @@ void launch_scratch_warm(hipStream_t st) { hipLaunchKernelGGL(k_scratch_warm, di
 hipError_t preload_multipass() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_emit2)); }
 
 }  // namespace m2s
+
+#ifdef M2S_TIMELINE
+extern "C" int m2s_debug_timeline(void* count, size_t count_bytes, void* emit, size_t emit_bytes) {
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(m2s::g_tl_count), std::min(count_bytes, sizeof(m2s::g_tl_count))) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(emit, HIP_SYMBOL(m2s::g_tl_emit), std::min(emit_bytes, sizeof(m2s::g_tl_emit))) != hipSuccess) return 2;
+    return 0;
+}
+extern "C" int m2s_debug_timeline_clear() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(m2s::g_tl_emit)) != hipSuccess) return 1;
+    return hipMemset(p, 0, sizeof(m2s::g_tl_emit)) == hipSuccess ? 0 : 2;
+}
+#endif
