@@ -34,10 +34,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
     return v;
 }
+// (round 6: through the DPP scan above — six dependent ds_bpermute round trips took 0.5 us per call inside k_count_scan's tall-triangle
+// loop, one call per 64 rows: the floor of the heterogeneous scene held its block's aggregate, and with it every block's look-back, for 18 us)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving
@@ -484,6 +484,95 @@ __device__ __forceinline__ void row_walker_next(W& w, int& xa, int& xb) {
     }
     if (hi < lo) { xa = 0; xb = -1; }
     else { xa = (int)lo; xb = (int)hi; }
+}
+
+// ---- the walker in 32 bits (round 6) -----------------------------------------------------------------------------------------
+// The per-wave timeline of k_count_scan (tools/timeline_probe.py) showed what its blocks wait for: ONE wave walking rows — 38 rows
+// per lane in a column mesh 8-13 us, the two floor triangles of the heterogeneous scene 15 us — at ~100 instructions per row, most
+// of them 64-bit compares / selects / adds on quotients that the closed form allows to reach 2^44, plus a second, divergent branch
+// per edge for horizontal edges.  Here the same Bresenham steps on 32-bit quotients (an edge's x at a row of the triangle stays
+// within a few thousand pixels unless the edge is nearly horizontal AND the triangle tall: the init checks every quotient over the
+// rows it is going to visit and says so — the caller then takes the 64-bit walker, wave-uniformly) and WITHOUT the horizontal
+// branch: an edge with a == 0 does not bound x at all, it passes or fails whole rows, beta(k) = beta(0) + k * 256 b * stride >= 1,
+// i.e. it only narrows the range of rows [k0, k1] — one closed-form division at the init; in the loop such an edge is neutral
+// (q = -2^30 as a lower bound, D = 1: never a carry).  ~33 full-rate instructions per row.  Spans identical to row_span / RowWalker
+// for every visited row; rows outside [k0, k1] are empty (tests: every count test, tests/test_round6_math.py::test_walker32_*).
+struct RowWalker32 {
+    int q[3];
+    uint32_t r[3];
+    int sq[3];
+    uint32_t sr[3];
+    uint32_t D[3];       // 256 |a|, or 1 for an edge without an x bound
+    int lower;           // bit i: edge i bounds x from below
+    int x0, x1;
+    int k0, k1;          // rows y + k0 * stride .. y + k1 * stride pass the horizontal edges (k0 > k1: none); the walker stands at k0
+};
+constexpr long long kWalk32 = 1ll << 29;
+// rows y, y + stride, ..., y + (n - 1) * stride of triangle s.  false: a quotient may leave the 32-bit walker's range.
+__device__ __forceinline__ bool row_walker32_init(const Raster& s, int y, int stride, int n, RowWalker32& w) {
+    long long k0 = 0, k1 = (long long)n - 1;
+    {   // (a triangle with two horizontal edges has no area and never gets here: ONE division)
+        const bool h0 = s.a[0] == 0, h1 = s.a[1] == 0, h2 = s.a[2] == 0;
+        if (h0 || h1 || h2) {
+            // (selected by masks, not by an index: an indexed pick among s.b[] / s.c[] sends the whole Raster to scratch memory)
+            const int bh = (h0 ? s.b[0] : 0) | (h1 ? s.b[1] : 0) | (h2 ? s.b[2] : 0);
+            const long long ch = (h0 ? s.c[0] : 0ll) | (h1 ? s.c[1] : 0ll) | (h2 ? s.c[2] : 0ll);
+            const int bit = (h0 ? s.bias : 0) | (h1 ? s.bias >> 1 : 0) | (h2 ? s.bias >> 2 : 0);
+            const long long beta = (long long)bh * (256ll * y + 128) + ch + (bit & 1);
+            const long long bs = 256ll * bh * stride;
+            // beta(k) is linear: if the first and the last row pass, every row does — the usual case (the edge is the triangle's top
+            // or bottom; only a row whose centres lie ON it, or a box clamped by the viewport, can fail): no division then
+            if (beta < 1 || beta + k1 * bs < 1) {
+                if (bs != 0) {
+                    const long long f = floordiv_pos(bs > 0 ? bs - beta : beta - 1, bs > 0 ? bs : -bs);
+                    if (bs > 0) k0 = f > k0 ? f : k0;       // k >= ceil((1 - beta) / bs)
+                    else k1 = f < k1 ? f : k1;              // k <= floor((beta - 1) / -bs)
+                } else k1 = -1;
+            }
+        }
+    }
+    w.x0 = s.x0; w.x1 = s.x1;
+    w.lower = 0;
+    if (k0 > k1) { k0 = 0; k1 = -1; }
+    w.k0 = (int)k0; w.k1 = (int)k1;
+    const int yy = y + (int)k0 * stride;
+    const long long steps = k1 - k0;                      // -1: no row at all
+    const long long Py = 256ll * yy + 128;
+    bool safe = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const long long alpha = 256ll * s.a[i];
+        const long long beta = 128ll * s.a[i] + (long long)s.b[i] * Py + s.c[i] + ((s.bias >> i) & 1);
+        const long long bs = 256ll * s.b[i] * stride;
+        long long q;
+        walker_edge(alpha, beta, bs, q, w.r[i], w.sq[i], w.sr[i], w.D[i]);
+        if (alpha > 0 || alpha == 0) w.lower |= 1 << i;
+        if (alpha == 0) { q = -2 * kWalk32; w.D[i] = 1u; }                  // (walker_edge left r = sq = sr = 0)
+        else if (steps >= 0) {
+            // the last row's quotient lies in [qe, qe + steps], qe = q + steps * sq: |sq| < 2^29 and steps < 2^12, so the fp32 estimate
+            // of |qe| is off by less than 2^19 — tested against 2^28, the exact q against 2^29 by its sign extension
+            const float qe = fabsf((float)q + (float)(int)steps * (float)w.sq[i]);
+            safe = safe && (q >> 29) == (q >> 63) && qe < 268435456.0f;
+        }
+        w.q[i] = (int)q;
+    }
+    return safe || steps < 0;
+}
+// span of the current row (empty iff xb < xa; xb - xa + 1 >= -2^31 / 2), then advance by one step
+__device__ __forceinline__ void row_walker32_next(RowWalker32& w, int& xa, int& xb) {
+    int lo = w.x0, hi = w.x1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const bool l = (w.lower >> i) & 1;
+        const int ql = l ? w.q[i] : (int)0x80000000, qh = l ? 0x7FFFFFFF : w.q[i];
+        lo = ql > lo ? ql : lo;
+        hi = qh < hi ? qh : hi;
+        const uint32_t t = w.r[i] + w.sr[i];                                  // < 2^32: both < D < 2^31
+        const bool c = t >= w.D[i];
+        w.r[i] = c ? t - w.D[i] : t;
+        w.q[i] += w.sq[i] + (c ? 1 : 0);
+    }
+    xa = lo; xb = hi;
 }
 
 __device__ __forceinline__ Raster shfl_raster(const Raster& s, int src) {

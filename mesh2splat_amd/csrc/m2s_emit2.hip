@@ -138,7 +138,7 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
 M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* __restrict__ off, uint32_t* __restrict__ start, uint32_t n_start,
                                      unsigned long long* __restrict__ chain, uint32_t epoch, unsigned long long* __restrict__ total_out,
                                      float4* __restrict__ setup, uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
-                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp) {
+                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp, float4* stash) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = bid * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
@@ -153,28 +153,47 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     Raster rs;
     bool ok = false;
     uint32_t m = m0;
-    float4 uvb0 = make_float4(0, 0, 0, 0);
-    float2 uvb1 = make_float2(0, 0);
     if (valid) {
         load_positions(sc.tri, t, p);
-        uvb0 = sc.tri.B0[t];
-        uvb1 = sc.tri.B1[t];
+        const float4 uvb0 = sc.tri.B0[t];
+        const float2 uvb1 = sc.tri.B1[t];
         // (a workgroup inside one mesh — the common case — reads the mesh uniforms with scalar loads)
         if (uniform_mesh) geo_setup_mp(p, kConstMesh(sc.meshes + m0), g);
         else { m = find_mesh(sc, sc.tri_first + t); geo_setup_mp(p, sc.meshes + m, g); }
         ok = raster_setup(g, R, rs);
+        // Positions and texture coordinates wait in LDS for the second half of the kernel (tri_shade_setup, behind the published
+        // aggregate) instead of in fifteen registers across the row loops: with them the kernel spilled 80 bytes per lane once the 32-bit
+        // walker joined it (the spill traffic cost the C4 stand-in more than the walker saved), and reading them again from global
+        // memory put a 3 us round trip — behind every wave's 112-byte-strided TriSetup stores — where 0.1 us of LDS does.
+        if (ok) {
+            float4* const mine_s = stash + wave * (7 * 64) + lane;      // [wave][k][lane]: the wave's own 7 KB
+            mine_s[0 * 64] = make_float4(p[0], p[1], p[2], p[3]);
+            mine_s[1 * 64] = make_float4(p[4], p[5], p[6], p[7]);
+            mine_s[2 * 64] = make_float4(p[8], uvb1.x, uvb1.y, 0.0f);
+            mine_s[3 * 64] = uvb0;
+            // ... and so does the geometry stage's output, which only the second half reads (the raster setup is done with it)
+            mine_s[4 * 64] = make_float4(g.xx, g.xy, g.xz, g.nx);
+            mine_s[5 * 64] = make_float4(g.ny, g.nz, g.ou[0], g.ou[1]);
+            mine_s[6 * 64] = make_float4(g.ou[2], g.ov[0], g.ov[1], g.ov[2]);
+        }
     }
     const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
     uint32_t c = 0, c64 = 0;
     TLC(1);
-    if (ok && rows <= M2S_COUNT_ROWS) {
-        RowWalker rw;
-        row_walker_init(rs, rs.y0, rw);
-        for (int y = rs.y0; y <= rs.y1; ++y) {
-            int xa, xb;
-            row_walker_next(rw, xa, xb);
-            if (y == rs.y0 + 64) c64 = c;      // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
-            c += (uint32_t)max(xb - xa + 1, 0);
+    // (the 32-bit walker, m2s_devfn.h; a triangle outside its range — a nearly horizontal long edge — joins the wave-counted ones below)
+    const bool mine = ok && rows <= M2S_COUNT_ROWS;
+    bool walked = false;
+    {
+        RowWalker32 rw;
+        rw.k0 = 0; rw.k1 = -1;
+        if (mine) walked = row_walker32_init(rs, rs.y0, 1, rows, rw);
+        if (walked) {
+            for (int k = rw.k0; k <= rw.k1; ++k) {
+                int xa, xb;
+                row_walker32_next(rw, xa, xb);
+                if (k == 64) c64 = c;          // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
+                c += (uint32_t)max(xb - xa + 1, 0);
+            }
         }
     }
     uint32_t tall_slot = 0;
@@ -183,8 +202,8 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         // running sums in the tall-triangle table (see kTallCap) for k_emit2.  Triangles of 65 .. M2S_COUNT_ROWS rows, counted by
         // their own lanes above, get a table entry as well (two chunks: 0 and the sum after 64 rows): a slice of k_emit2 that
         // starts in their lower half skips the upper one.
-        unsigned long long big = __ballot(ok && rows > M2S_COUNT_ROWS);
-        const bool two = ok && rows > 64 && rows <= M2S_COUNT_ROWS && c != 0;
+        unsigned long long big = __ballot(ok && !walked);
+        const bool two = walked && rows > 64 && c != 0;
         const unsigned long long twos = __ballot(two);
         uint32_t* const hdr = tall_header(setup, sc.n_tri);
         // the wave's table slots in ONE atomic (one global round trip per wave, not one per tall triangle in front of its count)
@@ -206,14 +225,26 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
             const bool listed = slot < kTallCap;
             uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
             uint32_t run = 0, ci = 0;
-            RowWalkerS rw;       // lane l: rows y0 + l, y0 + l + 64, ... (one closed-form setup per lane, then division-free steps)
-            if (b.y0 + lane <= b.y1) row_walker_init_strided(b, b.y0 + lane, 64, rw);
-            for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
-                const int y = yc + lane;
-                int xa = 0, xb = -1;
-                if (y <= b.y1) row_walker_next(rw, xa, xb);
-                if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
-                run += wave_sum((uint32_t)max(xb - xa + 1, 0));
+            // lane l: rows y0 + l, y0 + l + 64, ... (one closed-form setup per lane, then division-free steps — in 32 bits if every lane may)
+            RowWalker32 rw;
+            bool safe = true;
+            rw.k0 = 0; rw.k1 = -1;
+            if (b.y0 + lane <= b.y1) safe = row_walker32_init(b, b.y0 + lane, 64, (b.y1 - b.y0 - lane) / 64 + 1, rw);
+            if (__ballot(!safe) == 0ull) {
+                for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
+                    int xa = 0, xb = -1;
+                    if ((int)ci >= rw.k0 && (int)ci <= rw.k1) row_walker32_next(rw, xa, xb);
+                    if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
+                    run += wave_sum((uint32_t)max(xb - xa + 1, 0));
+                }
+            } else {   // the closed form per row (two fp64 reciprocals per edge and row): any triangle, rarely
+                for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
+                    const int y = yc + lane;
+                    int xa = 0, xb = -1;
+                    if (y <= b.y1) row_span(b, y, xa, xb);
+                    if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
+                    run += wave_sum((uint32_t)max(xb - xa + 1, 0));
+                }
             }
             if (lane == src) { c = run; tall_slot = listed ? slot + 1u : 0u; }
         }
@@ -241,21 +272,48 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     if (wave == 0 && lane == 0)
         chain_store(&chain[bid], (bid == 0 ? kFlagPrefix : kFlagAgg) | etag | ((unsigned long long)tot & kValMask));
     TLC(4);
-    if (c) {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
+    {   // the per-triangle half of the fragment stage, once: k_emit2 only reads it
         TriSetup s;
-        if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
-        else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
-        s.ts.mesh |= m;
-        const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
-        s.a0 = rs.a[0]; s.b0 = rs.b[0];
-        s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
-        s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
-        s.tall = tall_slot;
-        s.pad[0] = s.pad[1] = 0;
-        const float4* src4 = reinterpret_cast<const float4*>(&s);
-        float4* dst4 = setup + (size_t)t * 7;
+        float4* const wave_s = stash + wave * (7 * 64);
+        if (c) {
+            // positions, texture coordinates and the geometry stage's output come back from the workgroup's LDS (see `stash` above)
+            const float4* const mine_s = wave_s + lane;
+            const float4 s0 = mine_s[0 * 64], s1 = mine_s[1 * 64], s2 = mine_s[2 * 64], s3 = mine_s[3 * 64];
+            p[0] = s0.x; p[1] = s0.y; p[2] = s0.z; p[3] = s0.w; p[4] = s1.x; p[5] = s1.y; p[6] = s1.z; p[7] = s1.w; p[8] = s2.x;
+            const float4 uvb0 = s3;
+            const float2 uvb1 = make_float2(s2.y, s2.z);
+            {
+                const float4 g0 = mine_s[4 * 64], g1 = mine_s[5 * 64], g2 = mine_s[6 * 64];
+                g.xx = g0.x; g.xy = g0.y; g.xz = g0.z; g.nx = g0.w; g.ny = g1.x; g.nz = g1.y;
+                g.ou[0] = g1.z; g.ou[1] = g1.w; g.ou[2] = g2.x; g.ov[0] = g2.y; g.ov[1] = g2.z; g.ov[2] = g2.w;
+            }
+            if (uniform_mesh) tri_shade_setup(p, g, rs, kConstMesh(sc.meshes + m0), uvb0, uvb1, s.ts);
+            else tri_shade_setup(p, g, rs, sc.meshes + m, uvb0, uvb1, s.ts);
+            s.ts.mesh |= m;
+            const long long Px0 = 256ll * rs.x0 + 128, Py0 = 256ll * rs.y0 + 128;
+            s.a0 = rs.a[0]; s.b0 = rs.b[0];
+            s.e0 = (long long)rs.a[0] * Px0 + (long long)rs.b[0] * Py0 + rs.c[0];
+            s.ext = (uint32_t)rs.x1 | ((uint32_t)rs.y1 << 12) | ((uint32_t)rs.bias << 24);
+            s.tall = tall_slot;
+            s.pad[0] = s.pad[1] = 0;
+        }
+        // The records leave through the wave's 7 KB of LDS as seven contiguous 1 KB runs (one triangle = 112 bytes: a lane storing its
+        // own record touches a line per 16 bytes — 448 write requests per wave, and the L2's request rate, not its bandwidth, kept the
+        // waves of the C4 stand-in 7 us in these stores: tools/timeline_probe.py).  Pieces of triangles without fragments stay unwritten.
+        wave_lds_sync();                                  // every lane has read its stash entries
+        if (c) {
+            const float4* src4 = reinterpret_cast<const float4*>(&s);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) dst4[k] = src4[k];
+            for (int k = 0; k < 7; ++k) wave_s[lane * 7 + k] = src4[k];
+        }
+        wave_lds_sync();
+        const unsigned long long cmask = __ballot(c != 0);
+        float4* const dst4 = setup + (size_t)(blockBase + (uint32_t)wave * 64u) * 7;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t q = (uint32_t)lane + 64u * j;
+            if ((cmask >> (q / 7u)) & 1ull) dst4[q] = wave_s[q];
+        }
     }
 
     TLC(5);
@@ -309,9 +367,10 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     __shared__ uint32_t wsum[kCountBlock / 64];
     __shared__ uint32_t wtall[kCountBlock / 64];
     __shared__ unsigned long long base_s;
+    __shared__ float4 stash[7 * kCountBlock];      // 28 KB: positions, texture coordinates and geometry-stage output of the block's triangles (count_scan_block)
     const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
 #ifndef M2S_PERSISTENT_COUNT
-    count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s);
+    count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s, stash);
 #else
     // tickets: words 2 and 3 of the tall-triangle table's header (zero when allocated; the last workgroup out zeroes them again)
     __shared__ uint32_t s_bid;
@@ -322,7 +381,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
         __syncthreads();
         const uint32_t bid = s_bid;
         if (bid >= n_tb) break;
-        count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s);
+        count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s, stash);
     }
     if (threadIdx.x == 0) {
         __threadfence();

@@ -103,3 +103,151 @@ def test_floor_division_by_an_approximate_reciprocal_plus_one_integer_correction
         assert np.array_equal(q, want), rel
         r = num - q * den
         assert ((r >= 0) & (r < den)).all()
+
+
+# ---- the 32-bit row walker (m2s_devfn.h: RowWalker32, row_walker32_init / _next) ---------------------------------------------------
+def _span_reference(a, b, c, bias, x0, x1, y):
+    Py = 256 * y + 128
+    lo, hi = x0, x1
+    for i in range(3):
+        alpha = 256 * a[i]
+        beta = 128 * a[i] + b[i] * Py + c[i] + bias[i]
+        if alpha > 0:
+            lo = max(lo, (alpha - beta) // alpha)
+        elif alpha < 0:
+            hi = min(hi, (beta - 1) // -alpha)
+        elif beta < 1:
+            hi = lo - 1
+    return max(hi - lo + 1, 0), lo
+
+
+def _walker32(a, b, c, bias, x0, x1, y, stride, n):
+    """Transcription of row_walker32_init + the caller's loop: list of (k, count, first x) of the rows it visits, and `safe`."""
+    W = 1 << 29
+    k0, k1 = 0, n - 1
+    Py = 256 * y + 128
+    for i in range(3):
+        if a[i] == 0:
+            beta = b[i] * Py + c[i] + bias[i]
+            bs = 256 * b[i] * stride
+            if bs > 0:
+                k0 = max(k0, (bs - beta) // bs)
+            elif bs < 0:
+                k1 = min(k1, (beta - 1) // -bs)
+            elif beta < 1:
+                k1 = -1
+    if k0 > k1:
+        return [], True
+    yy = y + k0 * stride
+    steps = k1 - k0
+    Py = 256 * yy + 128
+    q, r, sq, sr, D, lower = [0] * 3, [0] * 3, [0] * 3, [0] * 3, [1] * 3, [True] * 3
+    safe = True
+    for i in range(3):
+        alpha = 256 * a[i]
+        beta = 128 * a[i] + b[i] * Py + c[i] + bias[i]
+        bs = 256 * b[i] * stride
+        if alpha == 0:
+            q[i] = -2 * W
+            continue
+        d = abs(alpha)
+        nmr = alpha - beta if alpha > 0 else beta - 1
+        st = -bs if alpha > 0 else bs
+        q[i], r[i] = nmr // d, nmr % d
+        sq[i], sr[i] = st // d, st % d
+        D[i] = d
+        lower[i] = alpha > 0
+        # (the kernel's test: the exact first quotient by its sign extension, the last one through an fp32 estimate against 2^28)
+        qe = abs(np.float32(np.float32(max(min(q[i], 2 ** 31 - 1), -2 ** 31)) + np.float32(np.float32(steps) * np.float32(sq[i]))))
+        safe = safe and -W <= q[i] < W and bool(qe < np.float32(268435456.0))
+    rows = []
+    if not safe:
+        return rows, False
+    for k in range(k0, k1 + 1):
+        lo, hi = x0, x1
+        for i in range(3):
+            assert -(1 << 31) <= q[i] < (1 << 31), "a quotient left 32 bits although the init called the triangle safe"
+            if lower[i]:
+                lo = max(lo, q[i])
+            else:
+                hi = min(hi, q[i])
+            t = r[i] + sr[i]
+            assert t < (1 << 32)
+            carry = t >= D[i]
+            r[i] = t - D[i] if carry else t
+            q[i] += sq[i] + (1 if carry else 0)
+        assert -(1 << 31) <= hi - lo + 1 < (1 << 31)
+        rows.append((k, max(hi - lo + 1, 0), lo))
+    return rows, True
+
+
+def _edges(X, Y):
+    area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0])
+    if area2 == 0:
+        return None
+    sgn = -1 if area2 < 0 else 1
+    a, b, c, bias = [], [], [], []
+    for i in range(3):
+        ia, ib = (i + 1) % 3, (i + 2) % 3
+        dy, dx = Y[ib] - Y[ia], X[ib] - X[ia]
+        a.append(-dy * sgn); b.append(dx * sgn); c.append((dy * X[ia] - dx * Y[ia]) * sgn)
+        bias.append(1 if (a[i] > 0 or (a[i] == 0 and b[i] > 0)) else 0)
+    return a, b, c, bias
+
+
+def test_walker32_visits_the_closed_form_spans_and_only_skips_empty_rows():
+    """Every row the 32-bit walker visits has row_span's span; every row it skips (outside [k0, k1]: a horizontal edge fails it) is
+    empty; a triangle it declines (a quotient beyond 2^29 somewhere over its rows) is declined at the init, never mid-walk.  Random
+    triangles, triangles with an exactly horizontal edge (the rings of a cylinder, every axis-aligned quad), slivers whose long edge is
+    one sub-pixel off horizontal (the declined class), both strides."""
+    rng = np.random.default_rng(20260930)
+    seen_h = seen_unsafe = seen_skip = 0
+    for it in range(1500):
+        R = int(rng.choice([256, 1024, 4096]))
+        kind = it % 5
+        X = [int(v) for v in rng.integers(-2000, R * 256 + 2000, 3)]
+        Y = [int(v) for v in rng.integers(-2000, R * 256 + 2000, 3)]
+        if kind == 1:      # one exactly horizontal edge, sometimes on a pixel-centre row
+            Y[1] = Y[0] = int(rng.integers(0, R)) * 256 + int(rng.choice([128, 0, 77]))
+        elif kind == 2:    # sliver: nearly horizontal long edge
+            Y[1] = Y[0] + int(rng.choice([-2, -1, 1, 2])); X[1] = X[0] + int(rng.choice([-1, 1])) * int(rng.integers(R * 128, R * 256))
+            Y[2] = int(rng.integers(-2000, R * 256 + 2000))
+        elif kind == 3:    # small triangle
+            X = [X[0] + int(v) for v in rng.integers(-2000, 2000, 3)]; Y = [Y[0] + int(v) for v in rng.integers(-2000, 2000, 3)]
+        e = _edges(X, Y)
+        if e is None:
+            continue
+        a, b, c, bias = e
+        x0, x1 = max((min(X) - 128 + 255) >> 8, 0), min((max(X) - 128) >> 8, R - 1)
+        y0, y1 = max((min(Y) - 128 + 255) >> 8, 0), min((max(Y) - 128) >> 8, R - 1)
+        if x0 > x1 or y0 > y1:
+            continue
+        seen_h += 0 in a
+        for stride, lanes in ((1, (0,)), (64, (0, 1, 17, 63))):
+            for lane in lanes:
+                y = y0 + lane
+                if y > y1:
+                    continue
+                n = (y1 - y) // stride + 1
+                rows, safe = _walker32(a, b, c, bias, x0, x1, y, stride, n)
+                if not safe:
+                    seen_unsafe += 1
+                    continue
+                visited = {k: (cnt, lo) for k, cnt, lo in rows}
+                for k in range(n):
+                    want, wlo = _span_reference(a, b, c, bias, x0, x1, y + k * stride)
+                    if k in visited:
+                        assert visited[k][0] == want and (want == 0 or visited[k][1] == wlo), (X, Y, stride, lane, k)
+                    else:
+                        seen_skip += 1
+                        assert want == 0, (X, Y, stride, lane, k)
+    assert seen_h > 100 and seen_unsafe > 20 and seen_skip > 20
+
+
+def test_walker32_is_what_the_kernel_source_says():
+    """The transcription above follows the shipped header: the constants and the carry rule it depends on are in m2s_devfn.h."""
+    src = open(os.path.join(ROOT, "mesh2splat_amd", "csrc", "m2s_devfn.h")).read()
+    assert "constexpr long long kWalk32 = 1ll << 29;" in src
+    assert "q = -2 * kWalk32; w.D[i] = 1u;" in src
+    assert "const bool c = t >= w.D[i];" in src and "w.q[i] += w.sq[i] + (c ? 1 : 0);" in src
+    assert "safe = safe && (q >> 29) == (q >> 63) && qe < 268435456.0f;" in src

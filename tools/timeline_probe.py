@@ -54,7 +54,7 @@ tc = (tc - T0) * 10           # ns
 print(json.dumps({"workload": name, "R": R, "gaussians": int(tot), "pipeline": str(c.last_pipeline), "kernel_ms": kms, "blocks": nb}))
 span = tc[:, :, 7].max()
 print(f"k_count_scan: span {span} ns over {nb} blocks; starts: median {np.median(tc[:, 0, 0]):.0f} max {tc[:, :, 0].max()} ns")
-ph = ["load+GS+raster_setup", "lane row loops", "tall loop", "scan+sync1", "publish", "TriSetup", "lookback+sync2", "off/start"]
+ph = ["load+GS+raster_setup", "lane row loops", "tall loop", "scan+sync1+publish", "TriSetup", "lookback+sync2", "off/start"]
 w_end = tc[:, :, 7].max(axis=1)
 w_pub = tc[:, :, 4].max(axis=1)
 print("  percentiles of block end      (ns):", [int(np.percentile(w_end, q)) for q in (10, 50, 90, 99, 100)])
