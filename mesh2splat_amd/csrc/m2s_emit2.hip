@@ -127,18 +127,20 @@ __device__ __forceinline__ Raster raster_from_setup(const TriSetup& s) {
 // ============================================================================================
 // k_count_scan
 // ============================================================================================
-// The body of k_count_scan for block `bid` of the scene (the shipping kernel passes its own block index; inlined).
-// -DM2S_PERSISTENT_COUNT builds the round-5 experiment again — at most 1024 workgroups that take blocks by ticket, this body as a
-// NON-inlined function — for tools/crash_probe.py (profiles/r06/count_scan_fault_analysis.md); it is not part of the library.
-#ifdef M2S_PERSISTENT_COUNT
-#define M2S_COUNT_BODY __device__ __noinline__
-#else
-#define M2S_COUNT_BODY __device__ __forceinline__
-#endif
-M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* __restrict__ off, uint32_t* __restrict__ start, uint32_t n_start,
-                                     unsigned long long* __restrict__ chain, uint32_t epoch, unsigned long long* __restrict__ total_out,
-                                     float4* __restrict__ setup, uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
-                                     const uint32_t bid, const uint32_t n_tb, uint32_t* wsum, uint32_t* wtall, unsigned long long* base_sp, float4* stash) {
+// k_count_scan in two halves (round 6).  Half A of block `bid`: everything up to the published aggregate and the TriSetup records; it
+// hands the triangles' counts and block-local offsets on in registers.  Half B: the look-back, off[] made global, start[].  A workgroup runs A of its own block,
+// then A of whatever EXTRA blocks it can take by ticket, then the B halves.  A scene with a few more blocks than the GPU holds
+// workgroups (the heterogeneous scene: 1043 for 1024 slots; Sponza has 262 k triangles) used to run them as a second generation that
+// could only start when the first workgroup of the first one left — and every workgroup of the first generation waits, in its
+// look-back, for the slowest aggregate before it (timeline: 19 blocks alone on the GPU from 23 to 34 us of the kernel).  Now such a
+// launch holds exactly the resident workgroups and the extra blocks are counted by the workgroups that finish their own A first, WHILE
+// the slow ones are still counting; nobody waits before every aggregate it is going to produce is out, so the look-backs cannot
+// deadlock.  (The persistent forms of rounds 5 / 6 ticketed EVERY block and kept the look-back inside the loop:
+// profiles/r06/count_scan_fault_analysis.md.)
+__device__ __forceinline__ void count_block_a(const SceneDev& sc, uint32_t R, uint32_t* __restrict__ off,
+                                              unsigned long long* __restrict__ chain, uint32_t epoch, float4* __restrict__ setup,
+                                              const uint32_t bid, uint32_t* wsum, uint32_t* wtall, float4* stash,
+                                              uint32_t& c_out, unsigned long long& loc_out, uint32_t& tot_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blockBase = bid * kCountBlock;
     const uint32_t t = blockBase + threadIdx.x;
@@ -316,13 +318,29 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
         }
     }
 
+    // what half B needs: the triangle's count, its offset inside the block, the block's aggregate (registers: both halves are
+    // straight-line code of one kernel)
+    c_out = c; loc_out = (unsigned long long)woff + (incl - c); tot_out = tot;
     TLC(5);
+}
+
+// Half B of block `bid` (after half A of the same block by the same workgroup).
+__device__ __forceinline__ void count_block_b(const SceneDev& sc, uint32_t* __restrict__ off, uint32_t* __restrict__ start, uint32_t n_start,
+                                              unsigned long long* __restrict__ chain, uint32_t epoch, unsigned long long* __restrict__ total_out,
+                                              uint32_t* __restrict__ status, unsigned long long* __restrict__ total_host,
+                                              const uint32_t bid, const uint32_t n_tb, unsigned long long* base_sp,
+                                              const uint32_t c, const unsigned long long loc, const uint32_t tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blockBase = bid * kCountBlock;
+    const uint32_t t = blockBase + threadIdx.x;
+    const bool valid = t < sc.n_tri;
+    const unsigned long long etag = (unsigned long long)epoch << kEpochShift;
     if (wave == 0) {
         const uint32_t b = bid;
         const unsigned long long base = b == 0 ? 0ull : lookback(chain, b, lane, epoch, status);
         if (lane == 0) {
             if (b) chain_store(&chain[b], kFlagPrefix | etag | ((base + tot) & kValMask));
-            *base_sp = base;
+            base_sp[0] = base;
             if (b == n_tb - 1) {
                 *total_out = base + tot;
                 // the counter the host waits for: written by the kernel itself (like the single-pass kernels), no copy behind the pipeline
@@ -332,8 +350,8 @@ M2S_COUNT_BODY void count_scan_block(const SceneDev& sc, uint32_t R, uint32_t* _
     }
     __syncthreads();
     TLC(6);
-    const unsigned long long base = *base_sp;
-    const unsigned long long o0 = base + woff + (incl - c);
+    const unsigned long long base = base_sp[0];
+    const unsigned long long o0 = base + loc;
     if (valid) {
         // offsets are 32-bit (the host rejects totals beyond 2^32 - 1); saturate instead of wrapping
         const unsigned long long o1 = o0 + c;
@@ -366,28 +384,34 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
                                                             unsigned long long* __restrict__ total_host /* pinned, or nullptr */) {
     __shared__ uint32_t wsum[kCountBlock / 64];
     __shared__ uint32_t wtall[kCountBlock / 64];
-    __shared__ unsigned long long base_s;
-    __shared__ float4 stash[7 * kCountBlock];      // 28 KB: positions, texture coordinates and geometry-stage output of the block's triangles (count_scan_block)
+    __shared__ unsigned long long base_s[1];
+    __shared__ uint32_t s_next;
+    __shared__ float4 stash[7 * kCountBlock];      // 28 KB: positions, texture coordinates and geometry-stage output of the block's triangles (count_block_a)
     const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
-#ifndef M2S_PERSISTENT_COUNT
-    count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, blockIdx.x, n_tb, wsum, wtall, &base_s, stash);
-#else
-    // tickets: words 2 and 3 of the tall-triangle table's header (zero when allocated; the last workgroup out zeroes them again)
-    __shared__ uint32_t s_bid;
+    const uint32_t G = gridDim.x, n_extra = n_tb - G;            // (the launcher: G == n_tb, or the resident workgroups if the rest fits kMaxExtra each)
+    // tickets: word 2 of the tall-triangle table's header (zero when allocated; k_emit2 / the launcher of a counting-only conversion zero it again)
     uint32_t* const tk = tall_header(setup, sc.n_tri) + 2;
-    for (;;) {
-        __syncthreads();                       // every wave is done with the previous block's shared words
-        if (threadIdx.x == 0) s_bid = atomicAdd(&tk[0], 1u);
+    // (straight-line code, at most ONE extra block per workgroup: as a loop over tickets the kernel keeps its scene pointers live
+    // across the back edge and spills 128 bytes per lane — what rounds 5 and 6 ran into with their persistent forms)
+    uint32_t c1, tot1, c2 = 0, tot2 = 0;
+    unsigned long long loc1, loc2 = 0;
+    count_block_a(sc, R, off, chain, epoch, setup, blockIdx.x, wsum, wtall, stash, c1, loc1, tot1);
+    uint32_t extra = 0xFFFFFFFFu;
+    if (n_extra != 0) {
+        __syncthreads();                       // every wave is done with the shared words of the first block
+        if (threadIdx.x == 0) {
+            const uint32_t e = atomicAdd(tk, 1u);
+            s_next = e < n_extra ? G + e : 0xFFFFFFFFu;
+        }
         __syncthreads();
-        const uint32_t bid = s_bid;
-        if (bid >= n_tb) break;
-        count_scan_block(sc, R, off, start, n_start, chain, epoch, total_out, setup, status, total_host, bid, n_tb, wsum, wtall, &base_s, stash);
+        extra = s_next;
+        if (extra != 0xFFFFFFFFu) count_block_a(sc, R, off, chain, epoch, setup, extra, wsum, wtall, stash, c2, loc2, tot2);
     }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&tk[1], 1u) == gridDim.x - 1u) { tk[0] = 0u; tk[1] = 0u; }
+    count_block_b(sc, off, start, n_start, chain, epoch, total_out, status, total_host, blockIdx.x, n_tb, base_s, c1, loc1, tot1);
+    if (extra != 0xFFFFFFFFu) {
+        __syncthreads();                       // base_s of the first block has been read by every wave
+        count_block_b(sc, off, start, n_start, chain, epoch, total_out, status, total_host, extra, n_tb, base_s, c2, loc2, tot2);
     }
-#endif
 }
 
 // ============================================================================================
@@ -517,7 +541,7 @@ __global__ void __launch_bounds__(kBlock, M2S_EMIT2_WAVES) k_emit2(SceneDev sc, 
     // at all (plain round-robin).  Turns keep the locality and spread the expensive regions over all XCDs; k_emit2 has no
     // inter-workgroup dependency, so any mapping is correct.
     // the tall-triangle table's slot counter goes back to zero for the next conversion (k_emit2 itself only reads the table)
-    if (bid == 0 && threadIdx.x == 0) tall_header(setup, T)[0] = 0;
+    if (bid == 0 && threadIdx.x == 0) { tall_header(setup, T)[0] = 0; tall_header(setup, T)[2] = 0; }   // (... and k_count_scan's tickets)
     const uint32_t per_wg = kSlice * (kBlock / 64);
     const uint32_t nblk = (uint32_t)((nw + per_wg - 1) / per_wg);
     const uint32_t xcd = bid & 7u, turn = (bid >> 3) / run, in_run = (bid >> 3) % run;
@@ -666,9 +690,18 @@ void launch_count_scan(const SceneDev& sc, uint32_t R, uint32_t* off, uint32_t* 
                        uint32_t epoch, unsigned long long* total, void* setup, uint32_t* status, unsigned long long* total_host, hipStream_t st) {
     if (!sc.n_tri) return;
     uint32_t grid = count_scan_blocks(sc.n_tri);
-#ifdef M2S_PERSISTENT_COUNT
-    if (grid > 1024u) grid = 1024u;
-#endif
+    // more blocks than resident workgroups, but few enough for tickets: the launch is the resident set (see count_block_a)
+    static const uint32_t resident = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return (uint32_t)cus * (uint32_t)M2S_COUNT_WAVES;      // kCountBlock / 64 = 4 waves per workgroup, M2S_COUNT_WAVES per SIMD, 4 SIMDs
+    }();
+    uint32_t res = resident;
+    if (const char* v = debug_env("M2S_COUNT_RESIDENT")) res = (uint32_t)strtoul(v, nullptr, 10);   // debug: 0 = one workgroup per block, always
+    // ... and few enough that most workgroups leave after their own block whatever happens: a workgroup with an extra block waits, in that
+    // block's look-back, for workgroups dispatched AFTER it — if the GPU is shared (the other lane's kernels, another process) not all of
+    // the launch is resident at once, and the workgroups without an extra block are the ones that make room
+    if (res && grid > res && grid - res <= res / 8u) grid = res;
     hipLaunchKernelGGL(k_count_scan, dim3(grid), dim3(kCountBlock), 0, st, sc, R, off, start, n_start, chain,
                        epoch & 0xFFFFu, total, (float4*)setup, status, total_host);
 }
@@ -677,7 +710,7 @@ void launch_emit2(const SceneDev& sc, uint32_t R, const uint32_t* off, const uin
                   uint64_t limit, const void* setup, float4* out, hipStream_t st) {
     if (!sc.n_tri) return;
     if (!limit) {   // a counting-only conversion: nothing to emit, but the tall-triangle table's slot counter still goes back to zero
-        (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 4, st);
+        (void)hipMemsetAsync((char*)const_cast<void*>(setup) + setup_tall_offset(sc.n_tri), 0, 16, st);
         return;
     }
     const uint32_t per_wg = kSlice * (kBlock / 64);

@@ -240,3 +240,30 @@ def test_row_walker_counts_mid_size_triangles(conv, oracle, R, tri_size, n):
     assert np.array_equal(got, want)
     rows_hint = np.sqrt(want.max())
     assert rows_hint > 20            # the case really contains mid-size / big triangles
+
+
+@pytest.mark.parametrize("n", [148, 156, 157])
+def test_count_scan_extra_blocks_by_ticket(hiplib, oracle, n):
+    """k_count_scan launches the resident workgroups only when a scene has a few more blocks of 256 triangles than the GPU holds
+    workgroups (1024 on an MI355X) and hands the extra blocks out by ticket (m2s_emit2.hip, count_block_a / count_block_b): cube-spheres
+    of 262 848 / 292 032 / 295 788 triangles = 3 and 117 extra blocks, and 132 (over the limit of an eighth: one workgroup per block, as
+    before).  Same bytes as the single-pass kernel, the oracle's count per triangle; twice, so that the tickets were reset."""
+    scene = synth.cube_sphere(n, tex_size=64)
+    R = 192
+    want = oracle.count_per_triangle(scene, R)
+    a, b = Converter(0), Converter(0)
+    a.set_pipeline("team")
+    b.set_pipeline("multipass")
+    outs = []
+    for c in (a, b):
+        c.upload_scene(scene)
+        c.set_max_gaussians(0)
+    for c in (a, b, b):
+        total = c.convert(R)
+        assert total == int(want.sum())
+        outs.append(c.download())
+    assert b.last_pipeline == "multipass"
+    assert np.array_equal(b.download_triangle_counts(), want)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[1].view(np.uint32), outs[2].view(np.uint32))
+    a.close(); b.close()
