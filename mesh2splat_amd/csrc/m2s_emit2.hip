@@ -16,6 +16,11 @@
 //                 112-byte TriSetup record, and the SAME kernel turns the counts into output offsets with a decoupled
 //                 look-back over the context's chain words (one word per workgroup): no scan kernel, no offsets kernel.
 //                 It also fills start[]: the triangle that owns output record m * 512.
+//                 (Round 6, from the kernel's per-wave timeline — tools/timeline_probe.py on a -DM2S_TIMELINE build: the rows are
+//                 walked in 32 bits (RowWalker32, m2s_devfn.h), positions / texture coordinates / geometry-stage output wait in
+//                 28 KB of LDS across the row loops instead of in registers, the TriSetup records leave as contiguous 1 KB runs, and
+//                 the kernel is two halves — count_block_a up to the published aggregate, count_block_b from the look-back on — so
+//                 that a launch of the resident workgroups can take a few EXTRA blocks by ticket: see count_block_a.)
 //   k_emit2       every WAVE owns 512 consecutive output records and never synchronises with another wave: it loads the
 //                 TriSetup of the (typically 5-60) triangles overlapping its slice, expands them into an LDS entry list
 //                 (row walker; triangles of more than 32 rows wave-cooperatively), and shades strips of 64 entries
@@ -196,6 +201,7 @@ __device__ __forceinline__ void count_block_a(const SceneDev& sc, uint32_t R, ui
                 if (k == 64) c64 = c;          // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
                 c += (uint32_t)max(xb - xa + 1, 0);
             }
+            if (rw.k1 < 64) c64 = c;           // (a horizontal edge ends the walk above row 64: everything lies in the first chunk)
         }
     }
     uint32_t tall_slot = 0;
