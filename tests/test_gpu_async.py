@@ -210,3 +210,31 @@ def test_two_lanes_multipass_gives_the_same_records(hiplib, oracle, forced):
     assert c.convert(640) == wants[640][0]
     assert np.array_equal(c.download().view(np.uint32), wants[640][1].view(np.uint32))
     c.close()
+
+
+def test_two_lanes_with_extra_blocks_by_ticket(hiplib):
+    """The heterogeneous scene has 1043 blocks of 256 triangles for 1024 resident workgroups: k_count_scan launches the resident set and
+    hands 19 extra blocks out by ticket (m2s_emit2.hip).  On two lanes its workgroups share the GPU with the other lane's k_emit2 — not
+    all of a launch is resident at once, and a workgroup with an extra block waits for workgroups dispatched after it: sixty overlapped
+    conversions must all deliver the blocking conversion's counter and bytes (a stalled look-back would surface as an error)."""
+    scene = synth.sponza_like(tex_scale=0.25)
+    c = Converter(0)
+    c.upload_scene(scene)
+    R = 1024
+    want_total = c.convert(R)
+    assert c.last_pipeline == "multipass" and c.num_triangles > 1024 * 256
+    want = c.download()
+    c.set_async_lanes(2)
+    for depth in (2, 4):
+        for _ in range(depth):
+            c.submit(R)
+        for i in range(30):
+            assert c.wait() == want_total
+            if i % 10 == 0:
+                assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32))
+            c.submit(R)
+        for _ in range(depth):
+            assert c.wait() == want_total
+        assert np.array_equal(c.download().view(np.uint32), want.view(np.uint32))
+    c.set_async_lanes(1)
+    c.close()
