@@ -109,6 +109,17 @@ __device__ __forceinline__ bool f3_get_base(F3Ctl& C, unsigned long long* chain,
     return true;
 }
 
+#ifdef M2S_TIMELINE
+// measurement build only (tools/timeline_probe.py): 100 MHz timestamps per wave — start, counts known, entries expanded, first strip,
+// last strip done, end — and the strips the wave shaded
+__device__ unsigned long long g_tl_f3[16384 * 4 * 8];
+#define TLF(k) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0 && blockIdx.x < 16384u) g_tl_f3[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TLFV(k, v) do { if (lane == 0 && blockIdx.x < 16384u) g_tl_f3[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = (v); } while (0)
+#else
+#define TLF(k) do { } while (0)
+#define TLFV(k, v) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDev sc, uint32_t R, unsigned long long* __restrict__ chain,
                                                       unsigned long long limit, float4* __restrict__ out,
                                                       unsigned long long* __restrict__ total_out,
@@ -134,6 +145,7 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
     }
     const bool band_first = in_runs && (round & rmask) == 0u;     // first unit of its run: its base is the run's, known
     if (lb * (uint32_t)kL3Team >= n_batches) return;
+    TLF(0);
     // LDS is not zero on entry: one barrier at the very start makes the flags trustworthy (see k_fused2)
     if (lane == 0) { C.counted[wave] = 0; C.expanded[wave] = 0; }
     if (wave == 0 && lane == 0) {
@@ -254,6 +266,7 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
         if (anybig) __hip_atomic_fetch_or(&C.flags, kF3Irregular, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     l3_store(&C.counted[wave], 1u);
+    TLF(1);
 
     // ======================= where do my entries go?  counts of the waves before me =======================
     uint32_t stream0 = 0;              // stream position of my first entry
@@ -310,6 +323,8 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
         }
     }
     l3_store(&C.expanded[wave], 1u);   // release: TriShadeS, tskip, entries (set even on error so that nobody waits for it)
+    TLF(2);
+    [[maybe_unused]] unsigned long long tl_strips = 0;
 
     // ======================= fragment phase: strips of the workgroup's stream =======================
     // the stream's length needs every wave's count
@@ -322,6 +337,7 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
     }
     float4* const stage = S.stage[wave];
     uint32_t exp_seen = 0;             // bit k: wave k's expansion has been seen (after that its flag is not polled again)
+    TLF(3);
     while (alive) {
         uint32_t s = 0;
         if (lane == 0) s = __hip_atomic_fetch_add(&C.claimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -332,6 +348,9 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
                        stream_total = c3 + l3_uniform(&C.total_c[3]);
         const uint32_t pos0 = s * 64u;
         if (s >= kL3Stop / 64u || pos0 >= stream_total) break;
+#ifdef M2S_TIMELINE
+        ++tl_strips;
+#endif
         const uint32_t n = min(64u, stream_total - pos0);
         if (exp_seen != 15u) {   // the waves whose entries this strip contains must have expanded them
             const uint32_t lo[4] = { 0u, c1, c2, c3 }, hi[4] = { c1, c2, c3, stream_total };
@@ -419,6 +438,8 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
             }
         }
     }
+    TLF(4);
+    TLFV(6, tl_strips);
     // ======================= epilogue: the workgroup's inclusive prefix / the counter =======================
     // (by the wave of the last batch; the base is resolved here if no strip needed it, e.g. a workgroup without fragments)
     const uint32_t err = l3_load(&C.flags) & 0xFFu;
@@ -434,6 +455,8 @@ __global__ void __launch_bounds__(kL3Threads, M2S_FUSED3_WAVES) k_fused3(SceneDe
     }
     // status[1] != 0 is what the host acts on; 2 = "a workgroup's entries do not fit", 1 = a bounded wait gave up
     if (err && lane == 0) __hip_atomic_store(&status[1], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    TLF(5);
+    TLFV(7, (unsigned long long)lb);
 }
 
 void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, uint64_t limit, float4* out,
@@ -452,6 +475,18 @@ void launch_fused3(const SceneDev& sc, uint32_t R, unsigned long long* chain, ui
                        epoch & 0xFFFFu, biglist, bigmeta, tpw, r, bt);
 }
 
+#ifdef M2S_TIMELINE
+}  // namespace m2s
+extern "C" int m2s_debug_timeline_f3(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(m2s::g_tl_f3), std::min(bytes, sizeof(m2s::g_tl_f3))) == hipSuccess ? 0 : 1;
+}
+extern "C" int m2s_debug_timeline_f3_clear() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(m2s::g_tl_f3)) != hipSuccess) return 1;
+    return hipMemset(p, 0, sizeof(m2s::g_tl_f3)) == hipSuccess ? 0 : 2;
+}
+namespace m2s {
+#endif
 hipError_t preload_fused3() { hipFuncAttributes a; return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fused3)); }
 
 }  // namespace m2s
