@@ -434,36 +434,6 @@ __device__ __forceinline__ void row_walker_init(const Raster& s, int y, RowWalke
         walker_edge(alpha, beta, (long long)bs, w.q[i], w.r[i], w.sq[i], w.sr[i], w.D[i]);
     }
 }
-// The same walker for loops that visit every S-th row (the wave-cooperative paths: lane l walks rows y0 + l, y0 + l + 64, ...: one
-// closed-form setup per lane instead of one row_span — two fp64 divisions per edge — per lane and chunk): the numerators advance by
-// S row steps at a time, so sq / sr are the quotient and remainder of S * step, and beta of a horizontal edge moves by S * 256 b
-// (beyond 32 bits for S = 64: long long).
-struct RowWalkerS {
-    long long q[3];
-    uint32_t r[3];
-    int sq[3];           // floor(S * step / D): |S * step| < 2^37, D >= 256 -> |sq| < 2^29
-    uint32_t sr[3];
-    uint32_t D[3];
-    long long beta[3];
-    long long bstep[3];
-    int lower;
-    int x0, x1;
-};
-__device__ __forceinline__ void row_walker_init_strided(const Raster& s, int y, int stride, RowWalkerS& w) {
-    const long long Py = 256ll * y + 128;
-    w.lower = 0;
-    w.x0 = s.x0; w.x1 = s.x1;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const long long alpha = 256ll * s.a[i];
-        const long long beta = 128ll * s.a[i] + (long long)s.b[i] * Py + s.c[i] + ((s.bias >> i) & 1);
-        const long long bs = 256ll * s.b[i] * stride;
-        w.beta[i] = beta;
-        w.bstep[i] = bs;
-        if (alpha > 0) w.lower |= 1 << i;
-        walker_edge(alpha, beta, bs, w.q[i], w.r[i], w.sq[i], w.sr[i], w.D[i]);
-    }
-}
 // span of the current row, then advance to the next one
 template <class W>
 __device__ __forceinline__ void row_walker_next(W& w, int& xa, int& xb) {

@@ -6,7 +6,7 @@ inputs drawn from the whole admissible domain, including its corners:
 
   raster_small        (m2s_devfn.h)  small triangles: edge values from the edge's own vertex, 24 x 24-bit products
   small_coverage      (m2s_devfn.h)  sign bits shifted into rows of a mask, wave-uniform trip counts
-  RowWalkerS          (m2s_devfn.h)  the row walker stepped 64 rows at a time
+  RowWalkerS          (m2s_devfn.h)  the row walker stepped 64 rows at a time (round 6: the 32-bit walker with stride 64 took its place)
   depth sort          (m2s_sort.hip) sorting key - min over the bits of max - min
 """
 import numpy as np
@@ -163,7 +163,8 @@ def row_span_reference(a, b, c, bias, x0, x1, y):
 
 
 def test_strided_row_walker_equals_the_closed_form():
-    """RowWalkerS (row_walker_init_strided + row_walker_next): quotient and remainder of every edge bound stepped by S rows at a time."""
+    """Quotient and remainder of every edge bound stepped by S rows at a time (round 5: RowWalkerS; since round 6 the 32-bit walker with
+    stride 64, m2s_devfn.h row_walker32_init — tests/test_round6_math.py has its transcription; the identity is the same)."""
     S = 64
     for _ in range(300):
         R = int(RNG.choice([256, 1024, 4096]))
