@@ -127,7 +127,12 @@ __global__ void __launch_bounds__(kBlock) k_gather_records(const float4* __restr
     const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (q >= (size_t)n * 6) return;
     const uint32_t r = (uint32_t)(q / 6), k = (uint32_t)(q - (size_t)r * 6);
-    dst[q] = src[(size_t)val[r] * 6 + k];
+    // (non-temporal store: the sorted copy is read by another launch, not by this one — the one-shot copy of tools/copy_probe.hip
+    // gains 6 % from it on the same boxes)
+    const float4 v = src[(size_t)val[r] * 6 + k];
+    float4* const d = &dst[q];
+    __builtin_nontemporal_store(v.x, &d->x); __builtin_nontemporal_store(v.y, &d->y);
+    __builtin_nontemporal_store(v.z, &d->z); __builtin_nontemporal_store(v.w, &d->w);
 }
 // the sorted keys of a reduced-range sort are `key - offset`: put the offset back (only when somebody asks for the keys)
 __global__ void __launch_bounds__(kBlock) k_add_to_keys(uint32_t* __restrict__ key, uint32_t n, uint32_t offset) {
