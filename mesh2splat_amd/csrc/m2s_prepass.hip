@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
         src[r] = valid[r] ? (perm ? perm[gid] : gid) : 0u;
         const float4* gsrc = rec + (size_t)src[r] * 6;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) g[r][j] = gsrc[j];
+        for (int j = 0; j < 6; ++j) g[r][j] = gsrc[j];      // (non-temporal LOADS of the records: measured, no difference)
     }
     float4 q[kPPRec][6];
     float dvs[kPPRec];
@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(kPPWaves * 64) k_prepass(const PrepassK k, con
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const uint32_t idx = (uint32_t)j * 64u + (uint32_t)lane;
-            if (idx < n4) dst[idx] = S[idx];
+            if (idx < n4) nt_store(&dst[idx], S[idx]);       // (the quads are read by the next pass, not by this one: non-temporal, like the records)
         }
-        if ((uint32_t)lane < cnt[r]) depths[base + lane] = s_depth[wave][lane];
+        if ((uint32_t)lane < cnt[r]) __builtin_nontemporal_store(s_depth[wave][lane], &depths[base + lane]);
         base += cnt[r];
     }
 }
