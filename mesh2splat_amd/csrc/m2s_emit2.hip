@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(kCountBlock, M2S_COUNT_WAVES) k_count_scan(Sce
     __shared__ uint32_t s_next;
     __shared__ float4 stash[7 * kCountBlock];      // 28 KB: positions, texture coordinates and geometry-stage output of the block's triangles (count_block_a)
     const uint32_t n_tb = (sc.n_tri + (uint32_t)kCountBlock - 1u) / (uint32_t)kCountBlock;
-    const uint32_t G = gridDim.x, n_extra = n_tb - G;            // (the launcher: G == n_tb, or the resident workgroups if the rest fits kMaxExtra each)
+    const uint32_t G = gridDim.x, n_extra = n_tb - G;            // (the launcher: G == n_tb, or the resident workgroups if the rest is at most an eighth of them: one extra block each, at most)
     // tickets: word 2 of the tall-triangle table's header (zero when allocated; k_emit2 / the launcher of a counting-only conversion zero it again)
     uint32_t* const tk = tall_header(setup, sc.n_tri) + 2;
     // (straight-line code, at most ONE extra block per workgroup: as a loop over tickets the kernel keeps its scene pointers live
