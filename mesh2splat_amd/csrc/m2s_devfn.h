@@ -528,6 +528,26 @@ __device__ __forceinline__ bool row_walker32_init(const Raster& s, int y, int st
     }
     return safe || steps < 0;
 }
+// floor(x / D) and the remainder for 0 <= x < 4096 D + D, D < 2^31 (a walker jumping up to 4095 rows ahead): the quotient stays below 2^13, so an
+// fp32 estimate (three roundings of 2^-24 relative each) is off by at most one and the exact remainder settles it — no fp64.
+__device__ __forceinline__ uint32_t jump_quot(unsigned long long x, uint32_t D, uint32_t& rem) {
+    uint32_t e = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)D));
+    long long r = (long long)x - (long long)((unsigned long long)e * D);
+    if (r < 0) { e -= 1u; r += D; }
+    else if (r >= (long long)D) { e += 1u; r -= D; }
+    rem = (uint32_t)r;
+    return e;
+}
+// the walker d rows further down (0 <= d < 4096; the init has vouched for every quotient on the way: 32-bit wrap-around arithmetic is exact)
+__device__ __forceinline__ void row_walker32_jump(RowWalker32& w, uint32_t d) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint32_t rem;
+        const uint32_t e = jump_quot((unsigned long long)w.r[i] + (unsigned long long)d * w.sr[i], w.D[i], rem);
+        w.q[i] = (int)((uint32_t)w.q[i] + d * (uint32_t)w.sq[i] + e);
+        w.r[i] = rem;
+    }
+}
 // span of the current row (empty iff xb < xa; xb - xa + 1 >= -2^31 / 2), then advance by one step
 __device__ __forceinline__ void row_walker32_next(RowWalker32& w, int& xa, int& xb) {
     int lo = w.x0, hi = w.x1;

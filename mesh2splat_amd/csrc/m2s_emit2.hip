@@ -187,44 +187,118 @@ __device__ __forceinline__ void count_block_a(const SceneDev& sc, uint32_t R, ui
     const int rows = ok ? rs.y1 - rs.y0 + 1 : 0;
     uint32_t c = 0, c64 = 0;
     TLC(1);
-    // (the 32-bit walker, m2s_devfn.h; a triangle outside its range — a nearly horizontal long edge — joins the wave-counted ones below)
+    // The 32-bit walker (m2s_devfn.h) of EVERY triangle, at its first row that passes the horizontal edges; a triangle outside the walker's
+    // range — a nearly horizontal long edge — is counted by the whole wave through the closed form, below.
     const bool mine = ok && rows <= M2S_COUNT_ROWS;
-    bool walked = false;
-    {
-        RowWalker32 rw;
-        rw.k0 = 0; rw.k1 = -1;
-        if (mine) walked = row_walker32_init(rs, rs.y0, 1, rows, rw);
-        if (walked) {
-            for (int k = rw.k0; k <= rw.k1; ++k) {
-                int xa, xb;
-                row_walker32_next(rw, xa, xb);
-                if (k == 64) c64 = c;          // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
-                c += (uint32_t)max(xb - xa + 1, 0);
-            }
-            if (rw.k1 < 64) c64 = c;           // (a horizontal edge ends the walk above row 64: everything lies in the first chunk)
+    RowWalker32 rw;
+    rw.k0 = 0; rw.k1 = -1;
+    bool safe32 = false;
+    if (ok) safe32 = row_walker32_init(rs, rs.y0, 1, rows, rw);
+    const bool walked = mine && safe32;
+    if (walked) {
+        RowWalker32 w = rw;
+        for (int k = w.k0; k <= w.k1; ++k) {
+            int xa, xb;
+            row_walker32_next(w, xa, xb);
+            if (k == 64) c64 = c;          // (running sum in front of the second 64-row chunk: the tall-triangle table, below)
+            c += (uint32_t)max(xb - xa + 1, 0);
         }
+        if (w.k1 < 64) c64 = c;            // (a horizontal edge ends the walk above row 64: everything lies in the first chunk)
     }
     uint32_t tall_slot = 0;
     TLC(2);
-    {   // triangles spanning more rows: the whole wave counts one triangle, 64 rows at a time, one row per lane — and leaves the
-        // running sums in the tall-triangle table (see kTallCap) for k_emit2.  Triangles of 65 .. M2S_COUNT_ROWS rows, counted by
-        // their own lanes above, get a table entry as well (two chunks: 0 and the sum after 64 rows): a slice of k_emit2 that
-        // starts in their lower half skips the upper one.
-        unsigned long long big = __ballot(ok && !walked);
+    {   // Triangles of more rows are counted by the whole wave, in CHUNKS of 64 rows — and leave the running sums in front of every chunk
+        // in the tall-triangle table (see kTallCap) for k_emit2.  Triangles of 65 .. M2S_COUNT_ROWS rows, counted by their own lanes
+        // above, get a table entry as well (two chunks: 0 and the sum after 64 rows): a slice of k_emit2 that starts in their lower
+        // half skips the upper one.
+        const bool tall32 = ok && !mine && safe32;
+        unsigned long long big = __ballot(ok && !walked && !tall32);       // (outside the 32-bit walker's range: the closed form, one triangle at a time)
+        const unsigned long long talls = __ballot(tall32);
         const bool two = walked && rows > 64 && c != 0;
         const unsigned long long twos = __ballot(two);
         uint32_t* const hdr = tall_header(setup, sc.n_tri);
         // the wave's table slots in ONE atomic (one global round trip per wave, not one per tall triangle in front of its count)
         uint32_t slot = 0;
-        if ((big | twos) != 0ull && lane == 0) slot = atomicAdd(&hdr[0], (uint32_t)(__popcll(big) + __popcll(twos)));
+        if ((big | talls | twos) != 0ull && lane == 0) slot = atomicAdd(&hdr[0], (uint32_t)(__popcll(big) + __popcll(talls) + __popcll(twos)));
         slot = __builtin_amdgcn_readfirstlane(slot);
+        const unsigned long long below = (1ull << lane) - 1ull;
         if (two) {
-            const uint32_t mine = slot + (uint32_t)__popcll(big) + (uint32_t)__popcll(twos & ((1ull << lane) - 1ull));
-            if (mine < kTallCap) {
-                uint32_t* const row = hdr + 4 + (size_t)mine * kTallChunks;
+            const uint32_t my = slot + (uint32_t)__popcll(big) + (uint32_t)__popcll(talls) + (uint32_t)__popcll(twos & below);
+            if (my < kTallCap) {
+                uint32_t* const row = hdr + 4 + (size_t)my * kTallChunks;
                 row[0] = 0; row[1] = c64;
-                tall_slot = mine + 1u;
+                tall_slot = my + 1u;
             }
+        }
+        if (talls) {
+            // (triangle, chunk) TASKS, one per lane and round: the lane fetches the triangle's walker from the lane that owns it, jumps it to
+            // the chunk's first row and walks the chunk's rows itself.  Until round 6 the wave walked ONE triangle at a time, a row per
+            // lane and 64-row step, with a closed-form setup per lane and triangle (~800 instructions) and a wave-wide sum per step: the
+            // floor of the heterogeneous scene — two triangles — held its block's aggregate for 12-16 us, and a wave of 64 wall-sized
+            // triangles (any low-polygon mesh at a high density) would have walked them one after the other.
+            const uint32_t my = slot + (uint32_t)__popcll(big) + (uint32_t)__popcll(talls & below);
+            const uint32_t nch = tall32 ? (uint32_t)(rows + 63) >> 6 : 0u;                 // <= 64 (a pixel box has at most 4096 rows)
+            const uint32_t incl_c = wave_incl_scan(nch, lane);
+            const uint32_t n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)incl_c, 63);
+            // few chunks (a floor, a pair of walls): every chunk is cut into 2 / 4 / 8 tasks so that the one round has work for every lane
+            uint32_t sub = 0;
+            while (sub < 3u && (n_chunks << (sub + 1u)) <= 64u) ++sub;
+            const uint32_t rpt = 64u >> sub;                                                // rows per task
+            const uint32_t incl_t = incl_c << sub, excl_t = incl_t - (nch << sub), n_tasks = n_chunks << sub;
+            uint32_t carry = 0;                                                             // an owner's fragments in the chunks finished so far
+            for (uint32_t j0 = 0; j0 < n_tasks; j0 += 64u) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool task = j < n_tasks;
+                // the owner: the first lane whose inclusive count of chunks exceeds j (lanes without chunks repeat their predecessor's)
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t v = (uint32_t)__shfl((int)incl_t, mid);
+                    if (v > j) hi = mid; else lo = mid + 1;
+                }
+                const int owner = task ? min(lo, 63) : lane;
+                const uint32_t tidx = j - (uint32_t)__shfl((int)excl_t, owner);
+                const uint32_t cidx = tidx >> sub, part = tidx & ((1u << sub) - 1u);
+                RowWalker32 w;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    w.q[i] = __shfl(rw.q[i], owner); w.r[i] = (uint32_t)__shfl((int)rw.r[i], owner); w.sq[i] = __shfl(rw.sq[i], owner);
+                    w.sr[i] = (uint32_t)__shfl((int)rw.sr[i], owner); w.D[i] = (uint32_t)__shfl((int)rw.D[i], owner);
+                }
+                w.lower = __shfl(rw.lower, owner); w.x0 = __shfl(rw.x0, owner); w.x1 = __shfl(rw.x1, owner);
+                w.k0 = __shfl(rw.k0, owner); w.k1 = __shfl(rw.k1, owner);
+                const uint32_t o_slot = (uint32_t)__shfl((int)my, owner);
+                const uint32_t o_carry = (uint32_t)__shfl((int)carry, owner);
+                const int row0 = (int)(64u * cidx + part * rpt);
+                const int first = max(row0, w.k0), last = min(row0 + (int)rpt - 1, w.k1);
+                uint32_t sum = 0;
+                if (task && first <= last) {
+                    row_walker32_jump(w, (uint32_t)(first - w.k0));
+                    for (int k = first; k <= last; ++k) {
+                        int xa, xb;
+                        row_walker32_next(w, xa, xb);
+                        sum += (uint32_t)max(xb - xa + 1, 0);
+                    }
+                }
+                // running sums per triangle: a segmented scan over the round's lanes (the tasks of one triangle are neighbours) on top of
+                // what the owner carries from the rounds before
+                uint32_t seg = sum;
+                const uint32_t okey = task ? (uint32_t)owner : 0xFFFFFFFFu;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t v = (uint32_t)__shfl_up((int)seg, d);
+                    const uint32_t o = (uint32_t)__shfl_up((int)okey, d);
+                    if (lane >= d && o == okey) seg += v;
+                }
+                const uint32_t before = o_carry + seg - sum;                                // fragments of the triangle in front of this chunk
+                if (task && part == 0u && o_slot < kTallCap && cidx < kTallChunks) hdr[4 + (size_t)o_slot * kTallChunks + cidx] = before;
+                // every owner takes the total behind ITS last task of this round
+                const uint32_t a = max(excl_t, j0), b = min(incl_t, j0 + 64u);
+                const uint32_t got = (uint32_t)__shfl((int)(before + sum), b > a ? (int)(b - 1u - j0) : lane);
+                if (tall32 && b > a) carry = got;
+            }
+            if (tall32) { c = carry; tall_slot = my < kTallCap ? my + 1u : 0u; }
         }
         for (; big; ++slot) {
             const int src = __ffsll((long long)big) - 1;
@@ -233,26 +307,13 @@ __device__ __forceinline__ void count_block_a(const SceneDev& sc, uint32_t R, ui
             const bool listed = slot < kTallCap;
             uint32_t* const row = hdr + 4 + (size_t)slot * kTallChunks;
             uint32_t run = 0, ci = 0;
-            // lane l: rows y0 + l, y0 + l + 64, ... (one closed-form setup per lane, then division-free steps — in 32 bits if every lane may)
-            RowWalker32 rw;
-            bool safe = true;
-            rw.k0 = 0; rw.k1 = -1;
-            if (b.y0 + lane <= b.y1) safe = row_walker32_init(b, b.y0 + lane, 64, (b.y1 - b.y0 - lane) / 64 + 1, rw);
-            if (__ballot(!safe) == 0ull) {
-                for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
-                    int xa = 0, xb = -1;
-                    if ((int)ci >= rw.k0 && (int)ci <= rw.k1) row_walker32_next(rw, xa, xb);
-                    if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
-                    run += wave_sum((uint32_t)max(xb - xa + 1, 0));
-                }
-            } else {   // the closed form per row (two fp64 reciprocals per edge and row): any triangle, rarely
-                for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
-                    const int y = yc + lane;
-                    int xa = 0, xb = -1;
-                    if (y <= b.y1) row_span(b, y, xa, xb);
-                    if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
-                    run += wave_sum((uint32_t)max(xb - xa + 1, 0));
-                }
+            // the closed form per row (two fp64 reciprocals per edge and row), lane l: rows y0 + l, y0 + l + 64, ...
+            for (int yc = b.y0; yc <= b.y1; yc += 64, ++ci) {
+                const int y = yc + lane;
+                int xa = 0, xb = -1;
+                if (y <= b.y1) row_span(b, y, xa, xb);
+                if (listed && lane == 0 && ci < kTallChunks) row[ci] = run;
+                run += wave_sum((uint32_t)max(xb - xa + 1, 0));
             }
             if (lane == src) { c = run; tall_slot = listed ? slot + 1u : 0u; }
         }

@@ -1,5 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
 import numpy as np
+import os
 import pytest
 
 from mesh2splat_amd import synth
@@ -266,4 +267,29 @@ def test_count_scan_extra_blocks_by_ticket(hiplib, oracle, n):
     assert np.array_equal(b.download_triangle_counts(), want)
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     assert np.array_equal(outs[1].view(np.uint32), outs[2].view(np.uint32))
+    a.close(); b.close()
+
+
+def test_many_wave_counted_triangles_per_wave(hiplib, oracle):
+    """A low-polygon scene at a high density: every triangle of twelve tilted 6 x 6 patches is taller than 128 pixel rows at R = 1536 —
+    k_count_scan's (triangle, chunk) tasks with dozens of wave-counted triangles per wave, several rounds, chunks cut by the patches'
+    exactly horizontal edges.  The oracle's count per triangle, the team kernel's bytes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from tall_probe import scene_of
+    scene = scene_of(12)
+    R = 1536
+    want = oracle.count_per_triangle(scene, R)
+    a, b = Converter(0), Converter(0)
+    a.set_pipeline("team")
+    b.set_pipeline("multipass")
+    outs = []
+    for c in (a, b):
+        c.upload_scene(scene)
+        c.set_max_gaussians(0)
+        assert c.convert(R) == int(want.sum())
+        outs.append(c.download())
+    assert b.last_pipeline == "multipass"
+    assert np.array_equal(b.download_triangle_counts(), want)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     a.close(); b.close()
